@@ -1,0 +1,202 @@
+/*
+ * threecrate_hip.h -- C ABI of the MI355X (gfx950) normals + ICP backend for threecrate.
+ *
+ * This is the drop-in boundary.  The reference has no FFI on this
+ * path; callers link Rust crates and call free functions / GpuContext methods.  Each entry
+ * point below names the reference signature it stands in for (paths relative to
+ * /root/reference).  A Rust `extern "C"` shim maps them 1:1 back onto
+ *   threecrate-algorithms: estimate_normals / estimate_normals_with_config /
+ *                          estimate_normals_radius / icp / icp_detailed /
+ *                          icp_point_to_point / icp_point_to_plane(_detailed)
+ *   threecrate-gpu:        GpuContext::new, gpu_estimate_normals, gpu_icp,
+ *                          gpu_icp_point_to_plane, gpu_batch_icp
+ *
+ * Memory layouts (threecrate-core):
+ *   Point3f         = 3 x f32, AoS               (threecrate-core/src/point.rs:8)
+ *   NormalPoint3f   = {position[3], normal[3]}   (threecrate-core/src/point.rs:31-36, #[repr(C)])
+ *   Isometry3<f32>  = unit quaternion (i, j, k, w) + translation (x, y, z) = 7 x f32
+ *                     (nalgebra storage order; re-export threecrate-core/src/lib.rs:26)
+ *
+ * All calls are blocking (like the reference's `device.poll(Wait)`), never throw or abort
+ * across the ABI, and report errors as tc_status + tc_last_error_message().  A tc_context is
+ * bound to one HIP device and one stream and is NOT thread-safe (one context per thread /
+ * GPU, like one GpuContext); different contexts may be used concurrently.
+ *
+ * There is NO CPU fallback: without a HIP device every compute entry point returns TC_GPU.
+ */
+#ifndef THREECRATE_HIP_H
+#define THREECRATE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TC_ABI_VERSION 1
+
+/* threecrate_core::Error variants used on the path (threecrate-core/src/error.rs:7-28) */
+typedef enum tc_status {
+    TC_OK = 0,
+    TC_INVALID_DATA = 1,   /* Error::InvalidData  */
+    TC_ALGORITHM = 2,      /* Error::Algorithm    */
+    TC_GPU = 3,            /* Error::Gpu (HIP / device failure) */
+    TC_UNSUPPORTED = 4     /* Error::Unsupported  */
+} tc_status;
+
+typedef struct tc_context tc_context;
+
+/* NormalEstimationConfig (threecrate-algorithms/src/normals.rs:17-37); defaults via tc_normal_config_default */
+typedef struct tc_normal_config {
+    uint64_t k_neighbors;             /* default 10 */
+    float    radius;                  /* Option<f32>: valid iff has_radius */
+    int32_t  has_radius;
+    int32_t  consistent_orientation;  /* default 1 */
+    int32_t  has_viewpoint;           /* Option<Point3f>: valid iff has_viewpoint */
+    float    viewpoint[3];
+} tc_normal_config;
+
+/* ICPResult (threecrate-algorithms/src/registration.rs:13-24) */
+typedef struct tc_icp_result {
+    float    transformation[7];  /* Isometry3<f32>: qi qj qk qw tx ty tz */
+    float    mse;
+    uint64_t iterations;
+    int32_t  converged;
+    uint64_t n_correspondences;  /* number of valid pairs of the last executed iteration */
+    /* Optional, caller-allocated, n_source entries (HOST memory for the host entry points,
+       DEVICE memory for the *_device entry points): matched target index per source point,
+       0xFFFFFFFF = no correspondence.  The reference's Vec<(usize,usize)> is the list of
+       (j, corr_target[j]) with corr_target[j] != 0xFFFFFFFF in ascending j. */
+    uint32_t *corr_target;
+} tc_icp_result;
+
+/* BatchICPJob / BatchICPResult (threecrate-gpu/src/icp.rs:132-147) */
+typedef struct tc_batch_icp_job {
+    const float *source; size_t n_source;
+    const float *target; size_t n_target;
+    size_t max_iterations;
+    float  convergence_threshold;
+    float  max_correspondence_distance;   /* < 0 : none */
+} tc_batch_icp_job;
+typedef struct tc_batch_icp_result {
+    float    transformation[7];
+    float    final_error;
+    uint64_t iterations;
+    int32_t  status;                      /* tc_status of this job */
+} tc_batch_icp_result;
+
+/* per-kernel timing (hipEvent on the context's stream), for roofline reporting */
+typedef struct tc_kernel_stat {
+    char     name[48];
+    uint64_t launches;
+    double   total_ms;
+} tc_kernel_stat;
+
+/* ---- context: GpuContext::new (threecrate-gpu/src/device.rs:16-50) ---- */
+int         tc_abi_version(void);
+int         tc_device_count(void);
+tc_status   tc_context_create(int device, tc_context **out);
+/* same, but run on a caller-owned hipStream_t (e.g. torch's current stream) */
+tc_status   tc_context_create_on_stream(int device, void *hip_stream, tc_context **out);
+void        tc_context_destroy(tc_context *ctx);
+const char *tc_last_error_message(const tc_context *ctx);
+tc_status   tc_synchronize(tc_context *ctx);
+void        tc_normal_config_default(tc_normal_config *cfg);   /* normals.rs:28-36 */
+
+/* ---- normals ----
+ * estimate_normals_with_config(&PointCloud<Point3f>, &NormalEstimationConfig)
+ *     -> Result<PointCloud<NormalPoint3f>>        (normals.rs:257-357)
+ * estimate_normals (normals.rs:238-247) = cfg{k}, estimate_normals_radius (normals.rs:368-380)
+ * = cfg{k=10, radius, consistent, viewpoint None}; gpu_estimate_normals
+ * (threecrate-gpu/src/normals.rs:443-461) has the same meaning.
+ * xyz: n x 3 f32.  out: n x 6 f32 (NormalPoint3f).  n == 0 -> TC_OK before the k check. */
+tc_status tc_estimate_normals(tc_context *ctx, const float *xyz, size_t n,
+                              const tc_normal_config *cfg, float *out_normal_points);
+/* same with xyz / out already resident in device memory (HBM) */
+tc_status tc_estimate_normals_device(tc_context *ctx, const float *d_xyz, size_t n,
+                                     const tc_normal_config *cfg, float *d_out_normal_points);
+
+/* ---- ICP point-to-point ----
+ * icp_detailed(source, target, init, max_iters, max_correspondence_distance: Option<f32>,
+ *              convergence_threshold) -> Result<ICPResult>   (registration.rs:258-370)
+ * max_correspondence_distance < 0 encodes None. */
+tc_status tc_icp_detailed(tc_context *ctx, const float *source, size_t n_source,
+                          const float *target, size_t n_target, const float init[7],
+                          size_t max_iters, float max_correspondence_distance,
+                          float convergence_threshold, tc_icp_result *result);
+tc_status tc_icp_detailed_device(tc_context *ctx, const float *d_source, size_t n_source,
+                          const float *d_target, size_t n_target, const float init[7],
+                          size_t max_iters, float max_correspondence_distance,
+                          float convergence_threshold, tc_icp_result *result);
+/* icp_point_to_point(source, target, init, max_iterations, convergence_threshold,
+ *                    max_correspondence_distance) (registration.rs:644-680):
+ * adds the convergence_threshold <= 0 -> InvalidData check.  gpu_icp
+ * (threecrate-gpu/src/icp.rs:977-994) maps here with init = identity. */
+tc_status tc_icp_point_to_point(tc_context *ctx, const float *source, size_t n_source,
+                          const float *target, size_t n_target, const float init[7],
+                          size_t max_iterations, float convergence_threshold,
+                          float max_correspondence_distance, tc_icp_result *result);
+/* icp(source, target, init, max_iters) -> Isometry3 (registration.rs:232-242):
+ * threshold 1e-6, no cut-off, any error returns `init`.  Always TC_OK unless ctx is NULL. */
+tc_status tc_icp(tc_context *ctx, const float *source, size_t n_source,
+                 const float *target, size_t n_target, const float init[7],
+                 size_t max_iters, float out_transformation[7]);
+
+/* ---- ICP point-to-plane ----
+ * icp_point_to_plane_detailed(source, target, target_normals: &[Vector3f], init, max_iters,
+ *     max_correspondence_distance, convergence_threshold)    (registration.rs:508-602)
+ * icp_point_to_plane (registration.rs:488-496) = (.., None -> -1.0f, 1e-6f);
+ * gpu_icp_point_to_plane (threecrate-gpu/src/icp.rs:1017-1036) has the same meaning.
+ * n_target_normals != n_target -> TC_INVALID_DATA (checked before max_iters).
+ * normal_stride = floats between consecutive normals: 3 for &[Vector3f]; 6 lets a caller pass
+ * &NormalPoint3f[0].normal of estimate_normals' output directly. */
+tc_status tc_icp_point_to_plane_detailed(tc_context *ctx, const float *source, size_t n_source,
+                          const float *target, size_t n_target,
+                          const float *target_normals, size_t n_target_normals, size_t normal_stride,
+                          const float init[7], size_t max_iters,
+                          float max_correspondence_distance, float convergence_threshold,
+                          tc_icp_result *result);
+tc_status tc_icp_point_to_plane_detailed_device(tc_context *ctx, const float *d_source, size_t n_source,
+                          const float *d_target, size_t n_target,
+                          const float *d_target_normals, size_t n_target_normals, size_t normal_stride,
+                          const float init[7], size_t max_iters,
+                          float max_correspondence_distance, float convergence_threshold,
+                          tc_icp_result *result);
+
+/* gpu_batch_icp(&GpuContext, &[BatchICPJob]) (threecrate-gpu/src/icp.rs:997-1002, 151-185):
+ * job i runs on ctxs[i % n_ctx]; jobs on different contexts (GPUs) run concurrently. */
+tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp_job *jobs,
+                       size_t n_jobs, tc_batch_icp_result *results);
+
+/* ---- sharded ICP building blocks (one big cloud over several GPUs) ----
+ * A shard session holds the replicated target index and this rank's slice of source points.
+ * Per iteration the host (threecrate_amd.distributed) calls reduce -> all-reduce of the
+ * packed sums (29 f64 words p2plane / 17 p2p) over RCCL -> apply.  Every rank applies the
+ * identical reduced buffer, so all ranks hold the same transform without a broadcast. */
+typedef struct tc_icp_shard tc_icp_shard;
+#define TC_ICP_SUMS_P2PLANE 29
+#define TC_ICP_SUMS_P2P     17
+#define TC_ICP_SUMS_STRIDE  32
+tc_status tc_icp_shard_create(tc_context *ctx, int point_to_plane,
+                              const float *d_source_slice, size_t n_source_slice,
+                              const float *d_target, size_t n_target,
+                              const float *d_target_normals, size_t normal_stride,
+                              const float init[7], float max_correspondence_distance,
+                              float convergence_threshold, tc_icp_shard **out);
+/* device pointer to TC_ICP_SUMS_STRIDE doubles: this rank's packed sums (all-reduce in place) */
+double     *tc_icp_shard_sums(tc_icp_shard *s);
+tc_status   tc_icp_shard_reduce(tc_icp_shard *s);              /* correspondences + local sums */
+tc_status   tc_icp_shard_apply(tc_icp_shard *s);               /* solve + compose + convergence (device) */
+tc_status   tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *result);
+void        tc_icp_shard_destroy(tc_icp_shard *s);
+
+/* ---- profiling ---- */
+void   tc_profile_enable(tc_context *ctx, int on);
+void   tc_profile_reset(tc_context *ctx);
+size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THREECRATE_HIP_H */

@@ -1,0 +1,124 @@
+/*
+ * tc_oracle.h -- CPU ORACLE for the threecrate normals + ICP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under threecrate_amd/ (the product) may
+ * include, link, dlopen or execute this code.  Only tests/, __graft_entry__
+ * smoke() and bench.py's cpu_baseline leg use it, and only as the checker /
+ * the timed CPU baseline.
+ *
+ * It is a plain-C restatement of the reference's CPU path:
+ *   threecrate-algorithms/src/nearest_neighbor.rs:37-298  (flat kd-tree)
+ *   threecrate-algorithms/src/normals.rs:135-380          (k-NN / radius PCA normals)
+ *   threecrate-algorithms/src/registration.rs:87-602      (p2p + p2plane ICP)
+ *   threecrate-algorithms/src/filtering.rs:38-133         (voxel_grid_filter)
+ * plus the small dense linear algebra the reference takes from nalgebra "0.34"
+ * (Cargo.toml:35; no Cargo.lock is committed so the patch version is unpinned;
+ * source absent from /root/reference) and std::collections::BinaryHeap.
+ * Those are restated from their published algorithms (see tc_oracle.c).
+ *
+ * PARITY STATUS: the reference is Rust and cannot be built or imported in this
+ * image (no rustc/cargo), and its own tests hold no golden vectors -- only
+ * tolerance-level known-answer assertions.  The oracle is pinned against every
+ * one of those assertions (tests/test_oracle_reference_kats.py) and against
+ * LAPACK / brute force (tests/test_oracle_linalg.py).  Bit-level outputs of
+ * nalgebra (eigenvector values, SVD factors) are pinned by nothing:
+ * bit-level parity is "unpinned"; tolerance-level parity is pinned.
+ */
+#ifndef TC_ORACLE_H
+#define TC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same numbering as tc_status in include/threecrate_hip.h */
+enum { TCO_OK = 0, TCO_INVALID_DATA = 1, TCO_ALGORITHM = 2 };
+
+typedef struct tco_icp_result {
+    float    transform[7];   /* qx qy qz qw tx ty tz (nalgebra Isometry3 storage order) */
+    float    mse;
+    uint64_t iterations;
+    int32_t  converged;
+    uint64_t n_corr;         /* number of valid pairs of the last executed iteration */
+    /* optional, caller allocated, capacity ns each; may be NULL */
+    uint64_t *corr_src;
+    uint64_t *corr_tgt;
+} tco_icp_result;
+
+/* opaque kd-tree (nearest_neighbor.rs:29-33) */
+typedef struct tco_kdtree tco_kdtree;
+tco_kdtree *tco_kdtree_new(const float *xyz, size_t n);
+void tco_kdtree_free(tco_kdtree *t);
+/* returns count (<= k); idx/dist sorted ascending, dist = sqrt(d2) (nearest_neighbor.rs:177-251) */
+size_t tco_kdtree_knn(const tco_kdtree *t, const float q[3], size_t k, uint64_t *idx, float *dist);
+/* returns count; results sorted ascending by distance; cap = capacity of idx/dist
+   (returns the needed count even if > cap) (nearest_neighbor.rs:254-298) */
+size_t tco_kdtree_radius(const tco_kdtree *t, const float q[3], float radius,
+                         uint64_t *idx, float *dist, size_t cap);
+/* BruteForceSearch (nearest_neighbor.rs:339-386); knn sorted ascending (stable) */
+size_t tco_brute_knn(const float *xyz, size_t n, const float q[3], size_t k, uint64_t *idx, float *dist);
+
+/* batch k-NN over many queries with the kd-tree (threads: 0 = all cores) */
+int tco_knn_batch(const float *xyz, size_t n, const float *queries, size_t nq, size_t k,
+                  uint64_t *idx, float *dist, uint32_t *counts, int threads);
+
+/*
+ * estimate_normals_with_config (normals.rs:257-357).
+ *   radius <= 0 : None.  viewpoint NULL : None (default viewpoint :275-303).
+ *   out = n x 6 floats {position, normal} (NormalPoint3f, core/point.rs:31-36).
+ */
+int tco_estimate_normals(const float *xyz, size_t n, size_t k, float radius, int has_radius,
+                         int consistent_orientation, const float *viewpoint,
+                         float *out6, int threads);
+
+/* icp_detailed (registration.rs:258-370).  max_dist < 0 : None. */
+int tco_icp_point_to_point(const float *src, size_t ns, const float *tgt, size_t nt,
+                           const float init[7], size_t max_iters, float max_dist, float conv_thr,
+                           tco_icp_result *res, int threads);
+/* icp_point_to_point (registration.rs:644-680): adds the conv_thr <= 0 check */
+int tco_icp_point_to_point_checked(const float *src, size_t ns, const float *tgt, size_t nt,
+                           const float init[7], size_t max_iters, float conv_thr, float max_dist,
+                           tco_icp_result *res, int threads);
+/* icp_point_to_plane_detailed (registration.rs:508-602); n_normals = target_normals.len() */
+int tco_icp_point_to_plane(const float *src, size_t ns, const float *tgt, size_t nt,
+                           const float *tgt_normals, size_t n_normals,
+                           const float init[7], size_t max_iters, float max_dist, float conv_thr,
+                           tco_icp_result *res, int threads);
+/* icp (registration.rs:232-242): any error -> returns init */
+void tco_icp(const float *src, size_t ns, const float *tgt, size_t nt,
+             const float init[7], size_t max_iters, float out[7], int threads);
+
+/* voxel_grid_filter (filtering.rs:38-133). out: caller allocated n x 3; *n_out set.
+   Output order = ascending (vx,vy,vz) key (the reference's HashMap order is unspecified). */
+int tco_voxel_grid_filter(const float *xyz, size_t n, float voxel, float *out, size_t *n_out);
+
+/* ---- per-iteration building blocks (used by the world_size-2 gloo tests) ---- */
+/* one p2plane iteration's packed system over source points [j0,j1): out29 =
+   21 upper-tri AtA (row-major i<=j), 6 Atb, sum b^2, count -- accumulated in f64. */
+int tco_p2plane_partial(const float *src, size_t j0, size_t j1, const tco_kdtree *tgt_tree,
+                        const float *tgt, const float *tgt_normals, const float T[7],
+                        float max_dist, double out29[29], uint32_t *corr /* len j1-j0 or NULL */);
+/* p2point packed sums: 3 sum s, 3 sum q, 9 sum s q^T (row-major), sum |s-q|^2, count = 17 */
+int tco_p2p_partial(const float *src, size_t j0, size_t j1, const tco_kdtree *tgt_tree,
+                    const float *tgt, const float T[7], float max_dist, double out17[17],
+                    uint32_t *corr);
+
+/* ---- small linear algebra exposed for the LAPACK cross-checks ---- */
+void tco_symmetric_eigen3(const float m[9] /*row-major*/, float evals[3], float evecs[9] /*columns, row-major*/);
+void tco_svd3(const float m[9], float u[9], float s[3], float vt[9]);
+int  tco_cholesky6_solve(const float a[36], const float b[6], float x[6]); /* 0 = not PD */
+int  tco_lu6_solve(const float a[36], const float b[6], float x[6]);       /* 0 = singular */
+void tco_quat_from_matrix(const float r[9], float q[4] /* i j k w */);
+void tco_kabsch(const float *s, const float *q, size_t n, float out7[7], int *ok);
+void tco_isometry_apply(const float T[7], const float p[3], float out[3]);
+void tco_isometry_mul(const float a[7], const float b[7], float out[7]);
+void tco_isometry_to_matrix(const float T[7], float m16[16] /* row-major 4x4 */);
+int  tco_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

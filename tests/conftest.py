@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One GpuContext for the whole GPU session.  Fails loudly (no skip, no fallback) when the
+    HIP library or the device is missing."""
+    import threecrate_amd as tc
+    c = tc.GpuContext(0)
+    yield c
+    c.close()

@@ -1,0 +1,112 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances are the ones BASELINE.json's north_star states: normals within 1e-4 cosine,
+ICP transform within 1e-5 Frobenius (4x4 homogeneous matrix).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import cos_abs, frob
+from threecrate_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-4
+FROB_TOL = 1e-5
+
+
+def _normals_report(gpu, ref):
+    c = cos_abs(gpu[:, 3:], ref[:, 3:])
+    bad = np.nonzero(c < 1.0 - COS_TOL)[0]
+    return c, bad
+
+
+@pytest.mark.parametrize("n,k", [(10000, 10), (20000, 16), (5000, 3), (3000, 32), (2000, 64), (50000, 20)])
+def test_normals_match_oracle_uniform(ctx, n, k):
+    pts = synth.uniform_cloud(n, seed=1)
+    gpu = ctx.estimate_normals(pts, k)
+    ref = O.estimate_normals(pts, k)
+    assert gpu.shape == (n, 6)
+    assert np.array_equal(gpu[:, :3], pts)          # position is copied through (normals.rs:349-352)
+    c, bad = _normals_report(gpu, ref)
+    assert len(bad) == 0, f"{len(bad)} normals beyond 1e-4 cosine, worst {1 - c.min():.3e} at {bad[:5]}"
+    # orientation rule is applied identically: signed agreement too
+    s = np.sum(gpu[:, 3:] * ref[:, 3:], axis=1)
+    assert (s > 0).mean() > 0.9999
+
+
+def test_normals_explicit_viewpoint_and_no_orientation(ctx):
+    import threecrate_amd as tc
+    pts = synth.uniform_cloud(8000, seed=3, scale=(2.0, 1.0, 0.5))
+    cfg = tc.NormalEstimationConfig(k_neighbors=12, viewpoint=(0.3, -4.0, 2.0))
+    gpu = ctx.estimate_normals_with_config(pts, cfg)
+    ref = O.estimate_normals(pts, 12, viewpoint=(0.3, -4.0, 2.0))
+    c, bad = _normals_report(gpu, ref)
+    assert len(bad) == 0
+    assert (np.sum(gpu[:, 3:] * ref[:, 3:], axis=1) > 0).mean() > 0.9999
+    cfg = tc.NormalEstimationConfig(k_neighbors=12, consistent_orientation=False)
+    gpu = ctx.estimate_normals_with_config(pts, cfg)
+    ref = O.estimate_normals(pts, 12, consistent_orientation=False)
+    c, bad = _normals_report(gpu, ref)
+    assert len(bad) == 0
+
+
+def test_normals_nonuniform_density(ctx):
+    # clustered cloud: exercises the ring-overflow pass (cells far denser / sparser than the mean)
+    rng = np.random.default_rng(5)
+    a = rng.normal(0, 0.02, (6000, 3)); b = rng.uniform(-1, 1, (3000, 3)); c = rng.normal(0.5, 0.2, (3000, 3))
+    pts = np.concatenate([a, b, c]).astype(np.float32)
+    gpu = ctx.estimate_normals(pts, 10)
+    ref = O.estimate_normals(pts, 10)
+    cc, bad = _normals_report(gpu, ref)
+    assert len(bad) == 0, f"{len(bad)} mismatches, worst {1 - cc.min():.3e}"
+
+
+@pytest.mark.parametrize("n", [10000, 40000])
+def test_icp_point_to_point_matches_oracle(ctx, n):
+    src, tgt, T = synth.registration_pair(n, seed=1)
+    g = ctx.icp_detailed(src, tgt, None, 20, None, 0.0)
+    r = O.icp_detailed(src, tgt, None, 20, None, 0.0)
+    assert g.iterations == 20 and not g.converged
+    assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= FROB_TOL
+    assert abs(g.mse - r.mse) <= 1e-9 + 1e-3 * abs(r.mse)
+    assert np.array_equal(g.correspondences, r.correspondences)
+
+
+@pytest.mark.parametrize("n", [10000, 40000])
+def test_icp_point_to_plane_matches_oracle(ctx, n):
+    src, tgt, T = synth.registration_pair(n, seed=2)
+    nrm = O.estimate_normals(tgt, 16)[:, 3:]
+    g = ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, 20, None, 0.0)
+    r = O.icp_point_to_plane_detailed(src, tgt, nrm, None, 20, None, 0.0)
+    assert g.iterations == 20 and not g.converged
+    assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= FROB_TOL
+    assert np.array_equal(g.correspondences, r.correspondences)
+    # default threshold: same iteration count / convergence flag
+    g = ctx.icp_point_to_plane(src, tgt, nrm, None, 50)
+    r = O.icp_point_to_plane(src, tgt, nrm, None, 50)
+    assert (g.converged, g.iterations) == (r.converged, r.iterations)
+    assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= FROB_TOL
+
+
+def test_icp_with_init_and_max_distance(ctx):
+    src, tgt, T = synth.registration_pair(15000, seed=4)
+    init = synth.yaw_isometry((0.002, 0.001, -0.001), 0.001)
+    g = ctx.icp_detailed(src, tgt, init, 15, 0.05, 1e-9)
+    r = O.icp_detailed(src, tgt, init, 15, 0.05, 1e-9)
+    assert (g.converged, g.iterations) == (r.converged, r.iterations)
+    assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= FROB_TOL
+    assert np.array_equal(g.correspondences, r.correspondences)
+
+
+def test_device_resident_path_matches_host_path(ctx):
+    torch = pytest.importorskip("torch")
+    src, tgt, T = synth.registration_pair(20000, seed=6)
+    dn = ctx.estimate_normals(torch.from_numpy(tgt).cuda(), 16)
+    hn = ctx.estimate_normals(tgt, 16)
+    assert np.array_equal(dn.cpu().numpy(), hn)     # bit-identical, deterministic
+    g1 = ctx.icp_point_to_plane_detailed(torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), dn, None, 10, None, 0.0)
+    g2 = ctx.icp_point_to_plane_detailed(src, tgt, hn, None, 10, None, 0.0)
+    assert np.array_equal(g1.transformation, g2.transformation)
+    assert np.array_equal(g1.correspondences, g2.correspondences)

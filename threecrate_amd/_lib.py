@@ -1,0 +1,105 @@
+"""ctypes binding of libthreecrate_hip.so (include/threecrate_hip.h).
+
+The shared library is the product; this module only declares its C ABI.  There is no
+Python / CPU fallback: if the library is missing, `load()` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libthreecrate_hip.so")
+
+TC_OK, TC_INVALID_DATA, TC_ALGORITHM, TC_GPU, TC_UNSUPPORTED = 0, 1, 2, 3, 4
+SUMS_P2PLANE, SUMS_P2P, SUMS_STRIDE = 29, 17, 32
+
+
+class NormalConfig(C.Structure):
+    _fields_ = [("k_neighbors", C.c_uint64), ("radius", C.c_float), ("has_radius", C.c_int32),
+                ("consistent_orientation", C.c_int32), ("has_viewpoint", C.c_int32),
+                ("viewpoint", C.c_float * 3)]
+
+
+class IcpResultC(C.Structure):
+    _fields_ = [("transformation", C.c_float * 7), ("mse", C.c_float), ("iterations", C.c_uint64),
+                ("converged", C.c_int32), ("n_correspondences", C.c_uint64),
+                ("corr_target", C.c_void_p)]
+
+
+class BatchJobC(C.Structure):
+    _fields_ = [("source", C.c_void_p), ("n_source", C.c_size_t), ("target", C.c_void_p),
+                ("n_target", C.c_size_t), ("max_iterations", C.c_size_t),
+                ("convergence_threshold", C.c_float), ("max_correspondence_distance", C.c_float)]
+
+
+class BatchResultC(C.Structure):
+    _fields_ = [("transformation", C.c_float * 7), ("final_error", C.c_float),
+                ("iterations", C.c_uint64), ("status", C.c_int32)]
+
+
+class KernelStatC(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+# every symbol include/threecrate_hip.h declares (tests/test_abi_symbols.py checks the header against this)
+EXPORTS = [
+    "tc_abi_version", "tc_device_count", "tc_context_create", "tc_context_create_on_stream",
+    "tc_context_destroy", "tc_last_error_message", "tc_synchronize", "tc_normal_config_default",
+    "tc_estimate_normals", "tc_estimate_normals_device", "tc_icp_detailed", "tc_icp_detailed_device",
+    "tc_icp_point_to_point", "tc_icp", "tc_icp_point_to_plane_detailed",
+    "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
+    "tc_icp_shard_reduce", "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
+    "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
+]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  threecrate_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, sz, f, i = C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_int
+    ctxpp = C.POINTER(C.c_void_p)
+    resp = C.POINTER(IcpResultC)
+    L.tc_abi_version.restype = i
+    L.tc_device_count.restype = i
+    L.tc_context_create.argtypes = [i, ctxpp]
+    L.tc_context_create_on_stream.argtypes = [i, vp, ctxpp]
+    L.tc_context_destroy.argtypes = [vp]
+    L.tc_context_destroy.restype = None
+    L.tc_last_error_message.argtypes = [vp]
+    L.tc_last_error_message.restype = C.c_char_p
+    L.tc_synchronize.argtypes = [vp]
+    L.tc_normal_config_default.argtypes = [C.POINTER(NormalConfig)]
+    L.tc_normal_config_default.restype = None
+    L.tc_estimate_normals.argtypes = [vp, f32p, sz, C.POINTER(NormalConfig), f32p]
+    L.tc_estimate_normals_device.argtypes = [vp, f32p, sz, C.POINTER(NormalConfig), f32p]
+    L.tc_icp_detailed.argtypes = [vp, f32p, sz, f32p, sz, f32p, sz, f, f, resp]
+    L.tc_icp_detailed_device.argtypes = [vp, f32p, sz, f32p, sz, f32p, sz, f, f, resp]
+    L.tc_icp_point_to_point.argtypes = [vp, f32p, sz, f32p, sz, f32p, sz, f, f, resp]
+    L.tc_icp.argtypes = [vp, f32p, sz, f32p, sz, f32p, sz, f32p]
+    L.tc_icp_point_to_plane_detailed.argtypes = [vp, f32p, sz, f32p, sz, f32p, sz, sz, f32p, sz, f, f, resp]
+    L.tc_icp_point_to_plane_detailed_device.argtypes = [vp, f32p, sz, f32p, sz, f32p, sz, sz, f32p, sz, f, f, resp]
+    L.tc_batch_icp.argtypes = [ctxpp, sz, C.POINTER(BatchJobC), sz, C.POINTER(BatchResultC)]
+    L.tc_icp_shard_create.argtypes = [vp, i, f32p, sz, f32p, sz, f32p, sz, f32p, f, f, ctxpp]
+    L.tc_icp_shard_sums.argtypes = [vp]
+    L.tc_icp_shard_sums.restype = C.c_void_p
+    L.tc_icp_shard_reduce.argtypes = [vp]
+    L.tc_icp_shard_apply.argtypes = [vp]
+    L.tc_icp_shard_finish.argtypes = [vp, sz, resp]
+    L.tc_icp_shard_destroy.argtypes = [vp]
+    L.tc_icp_shard_destroy.restype = None
+    L.tc_profile_enable.argtypes = [vp, i]
+    L.tc_profile_enable.restype = None
+    L.tc_profile_reset.argtypes = [vp]
+    L.tc_profile_reset.restype = None
+    L.tc_profile_read.argtypes = [vp, C.POINTER(KernelStatC), sz]
+    L.tc_profile_read.restype = sz
+    _lib = L
+    return L

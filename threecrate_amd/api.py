@@ -1,0 +1,389 @@
+"""Host-side mirror of the reference interface for the normals + ICP path.
+
+Names, argument meaning and error behaviour follow threecrate-algorithms (normals.rs,
+registration.rs) and the threecrate-gpu facade (device.rs, normals.rs, icp.rs); call shapes
+follow the pyo3 module (threecrate-python/src/lib.rs:827-1010): N x 3 float32 in,
+N x 6 / N x 3 normals and 4 x 4 float32 + mse + iterations + converged out.
+
+Every function runs the HIP path through the C ABI (include/threecrate_hip.h).  numpy inputs
+take the host entry points (H2D staging inside the library); torch CUDA tensors take the
+*_device entry points with zero copies.  There is no CPU fallback.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+IDENTITY = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float32)
+
+
+# ---- threecrate_core::Error (threecrate-core/src/error.rs:7-28) ------------------------------
+class Error(Exception):
+    pass
+
+
+class InvalidData(Error):
+    pass
+
+
+class AlgorithmError(Error):
+    pass
+
+
+class GpuError(Error):
+    pass
+
+
+class Unsupported(Error):
+    pass
+
+
+_ERR = {_lib.TC_INVALID_DATA: InvalidData, _lib.TC_ALGORITHM: AlgorithmError, _lib.TC_GPU: GpuError,
+        _lib.TC_UNSUPPORTED: Unsupported}
+
+
+@dataclass
+class NormalEstimationConfig:
+    """normals.rs:17-37"""
+    k_neighbors: int = 10
+    radius: Optional[float] = None
+    consistent_orientation: bool = True
+    viewpoint: Optional[tuple] = None
+
+
+@dataclass
+class ICPResult:
+    """registration.rs:13-24; `transformation` is the 7-float Isometry3 (qi qj qk qw tx ty tz)."""
+    transformation: np.ndarray
+    mse: float
+    iterations: int
+    converged: bool
+    correspondences: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.int64))
+    corr_target: object = None   # dense per-source target index (0xFFFFFFFF = none), numpy or torch
+
+    @property
+    def matrix(self):
+        """4 x 4 float32 homogeneous matrix (threecrate-python/src/lib.rs:48-61)."""
+        return isometry_to_matrix(self.transformation)
+
+
+def isometry_to_matrix(T):
+    x, y, z, w = [np.float32(v) for v in T[:4]]
+    two = np.float32(2)
+    ww, xx, yy, zz = w * w, x * x, y * y, z * z
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0] = ww + xx - yy - zz; m[0, 1] = x * y * two - w * z * two; m[0, 2] = w * y * two + x * z * two
+    m[1, 0] = w * z * two + x * y * two; m[1, 1] = ww - xx + yy - zz; m[1, 2] = y * z * two - w * x * two
+    m[2, 0] = x * z * two - w * y * two; m[2, 1] = w * x * two + y * z * two; m[2, 2] = ww - xx - yy + zz
+    m[:3, 3] = T[4:7]
+    return m
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _as_host(a, cols=3):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    if a.size == 0:
+        return a.reshape(0, cols)
+    return a.reshape(-1, cols)
+
+
+class GpuContext:
+    """GpuContext::new (threecrate-gpu/src/device.rs:16-50): one HIP device + one stream."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        if stream is None:
+            rc = self._L.tc_context_create(device, C.byref(h))
+        else:
+            rc = self._L.tc_context_create_on_stream(device, C.c_void_p(stream), C.byref(h))
+        if rc != _lib.TC_OK:
+            raise GpuError(f"no usable HIP device {device} (tc_status {rc}); threecrate_amd has no CPU fallback")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tc_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _lib.TC_OK:
+            msg = self._L.tc_last_error_message(self._h).decode()
+            raise _ERR.get(rc, Error)(msg)
+
+    # ---- profiling ----
+    def profile_enable(self, on=True):
+        self._L.tc_profile_enable(self._h, 1 if on else 0)
+
+    def profile_reset(self):
+        self._L.tc_profile_reset(self._h)
+
+    def profile_read(self):
+        buf = (_lib.KernelStatC * 64)()
+        n = self._L.tc_profile_read(self._h, buf, 64)
+        return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(n, 64))}
+
+    # ---- normals ----
+    def _cfg(self, config: NormalEstimationConfig):
+        c = _lib.NormalConfig()
+        self._L.tc_normal_config_default(C.byref(c))
+        c.k_neighbors = int(config.k_neighbors)
+        if config.radius is not None:
+            c.has_radius, c.radius = 1, float(config.radius)
+        c.consistent_orientation = 1 if config.consistent_orientation else 0
+        if config.viewpoint is not None:
+            c.has_viewpoint = 1
+            for i in range(3):
+                c.viewpoint[i] = float(config.viewpoint[i])
+        return c
+
+    def estimate_normals_with_config(self, cloud, config: NormalEstimationConfig):
+        """normals.rs:257-357 -> (N, 6) array of NormalPoint3f {position, normal}."""
+        c = self._cfg(config)
+        if _is_torch(cloud):
+            import torch
+            x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            out = torch.empty((x.shape[0], 6), dtype=torch.float32, device=x.device)
+            self._check(self._L.tc_estimate_normals_device(self._h, x.data_ptr(), x.shape[0], C.byref(c), out.data_ptr()))
+            return out
+        x = _as_host(cloud)
+        out = np.empty((x.shape[0], 6), np.float32)
+        self._check(self._L.tc_estimate_normals(self._h, x.ctypes.data, x.shape[0], C.byref(c), out.ctypes.data))
+        return out
+
+    def estimate_normals(self, cloud, k: int = 10):
+        """normals.rs:238-247"""
+        return self.estimate_normals_with_config(cloud, NormalEstimationConfig(k_neighbors=k))
+
+    def estimate_normals_radius(self, cloud, radius: float, consistent_orientation: bool):
+        """normals.rs:368-380"""
+        return self.estimate_normals_with_config(
+            cloud, NormalEstimationConfig(k_neighbors=10, radius=radius, consistent_orientation=consistent_orientation))
+
+    def compute_normals(self, points, k: int):
+        """GpuContext::compute_normals (threecrate-gpu/src/normals.rs:367-374): normals only (N, 3)."""
+        return self.estimate_normals(points, k)[:, 3:]
+
+    # ---- ICP ----
+    def _result(self, r, ns, corr, want_pairs):
+        T = np.array(list(r.transformation), np.float32)
+        res = ICPResult(T, float(r.mse), int(r.iterations), bool(r.converged), corr_target=corr)
+        if want_pairs and corr is not None:
+            ct = corr.cpu().numpy() if _is_torch(corr) else corr
+            ct = ct.astype(np.int64)
+            src = np.nonzero(ct != 0xFFFFFFFF)[0]
+            res.correspondences = np.stack([src, ct[src]], axis=1)
+        return res
+
+    def icp_detailed(self, source, target, init=None, max_iters=50, max_correspondence_distance=None,
+                     convergence_threshold=1e-6, correspondences=True, _checked=False):
+        """registration.rs:258-370"""
+        md = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance)
+        i7 = np.ascontiguousarray(IDENTITY if init is None else np.asarray(init, np.float32).reshape(7))
+        r = _lib.IcpResultC()
+        if _is_torch(source):
+            import torch
+            s = source.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            t = target.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
+            r.corr_target = corr.data_ptr() if corr is not None else None
+            if _checked and not (convergence_threshold > 0):
+                raise InvalidData("Convergence threshold must be positive")
+            self._check(self._L.tc_icp_detailed_device(self._h, s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0],
+                                                       i7.ctypes.data, max_iters, md, convergence_threshold, C.byref(r)))
+            if corr is not None:
+                corr = corr[: s.shape[0]].to(torch.int64) & 0xFFFFFFFF
+            return self._result(r, s.shape[0], corr, correspondences)
+        s, t = _as_host(source), _as_host(target)
+        corr = np.empty(max(1, s.shape[0]), np.uint32) if correspondences else None
+        r.corr_target = corr.ctypes.data if corr is not None else None
+        fn = self._L.tc_icp_point_to_point if _checked else self._L.tc_icp_detailed
+        a, b = (convergence_threshold, md) if _checked else (md, convergence_threshold)
+        self._check(fn(self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], i7.ctypes.data, max_iters, a, b, C.byref(r)))
+        return self._result(r, s.shape[0], None if corr is None else corr[: s.shape[0]], correspondences)
+
+    def icp_point_to_point(self, source, target, init=None, max_iterations=50, convergence_threshold=1e-6,
+                           max_correspondence_distance=None, correspondences=True):
+        """registration.rs:644-680 (adds the threshold > 0 check)"""
+        return self.icp_detailed(source, target, init, max_iterations, max_correspondence_distance,
+                                 convergence_threshold, correspondences, _checked=True)
+
+    def icp(self, source, target, init=None, max_iters=50):
+        """registration.rs:232-242: returns the 7-float isometry; any error returns `init`."""
+        i7 = np.ascontiguousarray(IDENTITY if init is None else np.asarray(init, np.float32).reshape(7))
+        if _is_torch(source):
+            try:
+                return self.icp_detailed(source, target, i7, max_iters, None, 1e-6, correspondences=False).transformation
+            except Error:
+                return i7.copy()
+        s, t = _as_host(source), _as_host(target)
+        out = np.zeros(7, np.float32)
+        self._check(self._L.tc_icp(self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], i7.ctypes.data, max_iters,
+                                   out.ctypes.data))
+        return out
+
+    def icp_point_to_plane_detailed(self, source, target, target_normals, init=None, max_iters=50,
+                                    max_correspondence_distance=None, convergence_threshold=1e-6, correspondences=True):
+        """registration.rs:508-602.  target_normals: (Nt, 3) Vector3f, or the (Nt, 6) NormalPoint3f
+        array returned by estimate_normals (its normal columns are used in place, stride 6)."""
+        md = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance)
+        i7 = np.ascontiguousarray(IDENTITY if init is None else np.asarray(init, np.float32).reshape(7))
+        r = _lib.IcpResultC()
+        if _is_torch(source):
+            import torch
+            s = source.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            t = target.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            n = target_normals.detach().to(torch.float32).contiguous()
+            stride = 6 if (n.dim() == 2 and n.shape[1] == 6) else 3
+            nptr = n.data_ptr() + (12 if stride == 6 else 0)
+            nn = n.shape[0] if n.dim() == 2 else n.numel() // 3
+            corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
+            r.corr_target = corr.data_ptr() if corr is not None else None
+            self._check(self._L.tc_icp_point_to_plane_detailed_device(
+                self._h, s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], nptr, nn, stride, i7.ctypes.data, max_iters,
+                md, convergence_threshold, C.byref(r)))
+            if corr is not None:
+                corr = corr[: s.shape[0]].to(torch.int64) & 0xFFFFFFFF
+            return self._result(r, s.shape[0], corr, correspondences)
+        s, t = _as_host(source), _as_host(target)
+        n = np.ascontiguousarray(np.asarray(target_normals, np.float32))
+        stride = 6 if (n.ndim == 2 and n.shape[1] == 6) else 3
+        nn = n.shape[0] if n.ndim == 2 else n.size // 3
+        nptr = n.ctypes.data + (12 if stride == 6 else 0)
+        corr = np.empty(max(1, s.shape[0]), np.uint32) if correspondences else None
+        r.corr_target = corr.ctypes.data if corr is not None else None
+        self._check(self._L.tc_icp_point_to_plane_detailed(
+            self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], nptr, nn, stride, i7.ctypes.data, max_iters, md,
+            convergence_threshold, C.byref(r)))
+        return self._result(r, s.shape[0], None if corr is None else corr[: s.shape[0]], correspondences)
+
+    def icp_point_to_plane(self, source, target, target_normals, init=None, max_iters=50):
+        """registration.rs:488-496"""
+        return self.icp_point_to_plane_detailed(source, target, target_normals, init, max_iters, None, 1e-6)
+
+
+# ---- module-level free functions with the reference's names ----------------------------------
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = GpuContext(0)
+    return _default_ctx
+
+
+def estimate_normals(cloud, k=10, ctx=None):
+    return (ctx or default_context()).estimate_normals(cloud, k)
+
+
+def estimate_normals_with_config(cloud, config, ctx=None):
+    return (ctx or default_context()).estimate_normals_with_config(cloud, config)
+
+
+def estimate_normals_radius(cloud, radius, consistent_orientation, ctx=None):
+    return (ctx or default_context()).estimate_normals_radius(cloud, radius, consistent_orientation)
+
+
+def icp(source, target, init=None, max_iters=50, ctx=None):
+    return (ctx or default_context()).icp(source, target, init, max_iters)
+
+
+def icp_detailed(source, target, init, max_iters, max_correspondence_distance=None, convergence_threshold=1e-6, ctx=None):
+    return (ctx or default_context()).icp_detailed(source, target, init, max_iters, max_correspondence_distance,
+                                                   convergence_threshold)
+
+
+def icp_point_to_point(source, target, init, max_iterations, convergence_threshold=1e-6,
+                       max_correspondence_distance=None, ctx=None):
+    return (ctx or default_context()).icp_point_to_point(source, target, init, max_iterations, convergence_threshold,
+                                                         max_correspondence_distance)
+
+
+def icp_point_to_point_default(source, target, init, max_iterations, ctx=None):
+    """registration.rs:694-701"""
+    return icp_point_to_point(source, target, init, max_iterations, 1e-6, None, ctx)
+
+
+def icp_point_to_plane(source, target, target_normals, init, max_iters, ctx=None):
+    return (ctx or default_context()).icp_point_to_plane(source, target, target_normals, init, max_iters)
+
+
+def icp_point_to_plane_detailed(source, target, target_normals, init, max_iters, max_correspondence_distance=None,
+                                convergence_threshold=1e-6, ctx=None):
+    return (ctx or default_context()).icp_point_to_plane_detailed(source, target, target_normals, init, max_iters,
+                                                                  max_correspondence_distance, convergence_threshold)
+
+
+# ---- threecrate-gpu facade (threecrate-gpu/src/lib.rs:48-60) ---------------------------------
+def gpu_estimate_normals(gpu_context, cloud, k):
+    """threecrate-gpu/src/normals.rs:443-461"""
+    return gpu_context.estimate_normals(cloud, k)
+
+
+def gpu_icp(gpu_context, source, target, max_iterations, convergence_threshold, max_correspondence_distance):
+    """threecrate-gpu/src/icp.rs:977-994 -> Isometry3 (7 floats); starts from identity (:202)."""
+    return gpu_context.icp_point_to_point(source, target, None, max_iterations, convergence_threshold,
+                                          max_correspondence_distance, correspondences=False).transformation
+
+
+def gpu_icp_point_to_plane(gpu_context, source, target, target_normals, max_iterations, convergence_threshold,
+                           max_correspondence_distance):
+    """threecrate-gpu/src/icp.rs:1017-1036"""
+    return gpu_context.icp_point_to_plane_detailed(source, target, target_normals, None, max_iterations,
+                                                   max_correspondence_distance, convergence_threshold, correspondences=False)
+
+
+@dataclass
+class BatchICPJob:
+    """threecrate-gpu/src/icp.rs:132-139"""
+    source: np.ndarray
+    target: np.ndarray
+    max_iterations: int
+    convergence_threshold: float
+    max_correspondence_distance: float
+
+
+@dataclass
+class BatchICPResult:
+    """threecrate-gpu/src/icp.rs:142-147 (+ per-job status)"""
+    transformation: np.ndarray
+    final_error: float
+    iterations: int
+    status: int = 0
+
+
+def gpu_batch_icp(gpu_contexts, jobs):
+    """threecrate-gpu/src/icp.rs:997-1002; job i runs on gpu_contexts[i % len]; contexts on
+    different GPUs run concurrently."""
+    ctxs = gpu_contexts if isinstance(gpu_contexts, (list, tuple)) else [gpu_contexts]
+    L = _lib.load()
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    keep = []
+    cj = (_lib.BatchJobC * max(1, len(jobs)))()
+    for i, j in enumerate(jobs):
+        s, t = _as_host(j.source), _as_host(j.target)
+        keep += [s, t]
+        cj[i].source, cj[i].n_source, cj[i].target, cj[i].n_target = s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0]
+        cj[i].max_iterations = j.max_iterations
+        cj[i].convergence_threshold = j.convergence_threshold
+        cj[i].max_correspondence_distance = j.max_correspondence_distance
+    cr = (_lib.BatchResultC * max(1, len(jobs)))()
+    rc = L.tc_batch_icp(arr, len(ctxs), cj, len(jobs), cr)
+    if rc != _lib.TC_OK:
+        raise InvalidData("tc_batch_icp: bad arguments")
+    return [BatchICPResult(np.array(list(cr[i].transformation), np.float32), float(cr[i].final_error),
+                           int(cr[i].iterations), int(cr[i].status)) for i in range(len(jobs))]

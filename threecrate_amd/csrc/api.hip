@@ -1,0 +1,343 @@
+// api.hip -- C ABI entry points of libthreecrate_hip: context, validation in the reference's
+// order and precedence, host<->device staging, error mapping.  No CPU fallback exists: every
+// compute entry point needs a HIP device and returns TC_GPU otherwise.
+#include "tc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace tc {
+
+tc_status fail(tc_context *ctx, tc_status st, const std::string &msg) {
+    if (ctx) ctx->last_error = msg;
+    return st;
+}
+
+tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return TC_OK;
+    if (b.p) {
+        // buffers may still be referenced by work in flight on the stream
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx, TC_GPU, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        (void)hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(ctx, TC_GPU, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return TC_OK;
+}
+
+ProfScope::ProfScope(tc_context *c, const char *name) : ctx(c) {
+    if (!ctx->profiling) return;
+    for (size_t i = 0; i < ctx->timers.size(); ++i)
+        if (ctx->timers[i].name == name) { idx = (int)i; break; }
+    if (idx < 0) { ctx->timers.push_back(KernelTimer{name, {}, 0, 0.0}); idx = (int)ctx->timers.size() - 1; }
+    auto get = [&]() {
+        hipEvent_t e = nullptr;
+        if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    e0 = get(); e1 = get();
+    (void)hipEventRecord(e0, ctx->stream);
+}
+ProfScope::~ProfScope() {
+    if (idx < 0) return;
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->timers[idx].pending.emplace_back(e0, e1);
+}
+
+static void free_buf(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+static void free_index(DeviceIndex &ix) {
+    free_buf(ix.pts); free_buf(ix.cell_start); free_buf(ix.normals); free_buf(ix.cell_of);
+    free_buf(ix.slot); free_buf(ix.fill); free_buf(ix.blocksum);
+}
+
+// NormalEstimationConfig -> cell edge factor: ring R0 = 2 must cover the (k+1)-NN sphere for all
+// but ~1e-3 of the queries of a locally uniform cloud (Poisson tail), the rest take the overflow pass.
+static float normals_cell_factor(size_t k) {
+    const double K1 = (double)k + 1.0;
+    const double lam = K1 + 3.1 * std::sqrt(K1) + 2.0;
+    const double c = std::cbrt(lam / 4.18879);
+    return (float)(0.95 * c / 2.0);
+}
+
+static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, float *d_out) {
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(cfg->k_neighbors), nullptr, nullptr)) return s;
+    float vp[3];
+    if (cfg->has_viewpoint) {
+        vp[0] = cfg->viewpoint[0]; vp[1] = cfg->viewpoint[1]; vp[2] = cfg->viewpoint[2];
+    } else {   // normals.rs:275-303 (f32, same operation order; min/max are order independent)
+        const GridGeom &g = ctx->tgt_index.geom;
+        const float cx = (g.minx + g.maxx) / 2.0f, cy = (g.miny + g.maxy) / 2.0f, cz = (g.minz + g.maxz) / 2.0f;
+        const float ex = g.maxx - g.minx, ey = g.maxy - g.miny, ez = g.maxz - g.minz;
+        const float extent = std::sqrt(ex * ex + ey * ey + ez * ez);
+        vp[0] = cx + 0.0f; vp[1] = cy + 0.0f; vp[2] = cz + extent;
+    }
+    return launch_normals(ctx, ctx->tgt_index, *cfg, vp, d_out);
+}
+
+}  // namespace tc
+
+using namespace tc;
+
+extern "C" {
+
+int tc_abi_version(void) { return TC_ABI_VERSION; }
+
+int tc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static tc_status context_create(int device, void *stream, bool own, tc_context **out) {
+    if (!out) return TC_INVALID_DATA;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return TC_GPU;
+    if (hipSetDevice(device) != hipSuccess) return TC_GPU;
+    tc_context *ctx = new tc_context();
+    ctx->device = device;
+    ctx->own_stream = own;
+    if (own) {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return TC_GPU; }
+    } else {
+        ctx->stream = (hipStream_t)stream;
+    }
+    ctx->pinned_cap = 1 << 16;
+    if (hipHostMalloc(&ctx->pinned, ctx->pinned_cap, hipHostMallocDefault) != hipSuccess) {
+        if (own) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return TC_GPU;
+    }
+    *out = ctx;
+    return TC_OK;
+}
+
+tc_status tc_context_create(int device, tc_context **out) { return context_create(device, nullptr, true, out); }
+tc_status tc_context_create_on_stream(int device, void *hip_stream, tc_context **out) {
+    return context_create(device, hip_stream, false, out);
+}
+
+void tc_context_destroy(tc_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_index(ctx->tgt_index); free_index(ctx->src_index);
+    free_buf(ctx->in_a); free_buf(ctx->in_b); free_buf(ctx->in_c); free_buf(ctx->out_a); free_buf(ctx->bbox);
+    free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->overflow);
+    for (auto &t : ctx->timers) for (auto &p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *tc_last_error_message(const tc_context *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+tc_status tc_synchronize(tc_context *ctx) {
+    if (!ctx) return TC_INVALID_DATA;
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+void tc_normal_config_default(tc_normal_config *cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->k_neighbors = 10;            // normals.rs:28-36
+    cfg->has_radius = 0;
+    cfg->consistent_orientation = 1;
+    cfg->has_viewpoint = 0;
+}
+
+// ---- normals --------------------------------------------------------------------------------
+static tc_status normals_validate(tc_context *ctx, size_t n, const tc_normal_config *cfg, bool *empty) {
+    *empty = false;
+    if (!ctx || !cfg) return TC_INVALID_DATA;
+    if (n == 0) { *empty = true; return TC_OK; }                                        // normals.rs:261-263
+    if (cfg->k_neighbors < 3) return fail(ctx, TC_INVALID_DATA, "k_neighbors must be at least 3");   // :265-269
+    return TC_OK;
+}
+
+tc_status tc_estimate_normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg,
+                                     float *d_out) {
+    bool empty;
+    if (tc_status s = normals_validate(ctx, n, cfg, &empty)) return s;
+    if (empty) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = normals_device(ctx, d_xyz, n, cfg, d_out)) return s;
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+tc_status tc_estimate_normals(tc_context *ctx, const float *xyz, size_t n, const tc_normal_config *cfg, float *out) {
+    bool empty;
+    if (tc_status s = normals_validate(ctx, n, cfg, &empty)) return s;
+    if (empty) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = ensure(ctx, ctx->in_a, n * 3 * sizeof(float))) return s;
+    if (tc_status s = ensure(ctx, ctx->out_a, n * 6 * sizeof(float))) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (tc_status s = normals_device(ctx, (const float *)ctx->in_a.p, n, cfg, (float *)ctx->out_a.p)) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out_a.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+// ---- ICP ------------------------------------------------------------------------------------
+static tc_status icp_validate(tc_context *ctx, size_t ns, size_t nt, size_t max_iters, const tc_icp_result *res) {
+    if (!ctx || !res) return TC_INVALID_DATA;
+    if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");   // registration.rs:266-270
+    if (max_iters == 0) return fail(ctx, TC_INVALID_DATA, "Max iterations must be positive");             // :272-276
+    if (ns >= 0xFFFFFFF0ull || nt >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    return TC_OK;
+}
+
+tc_status tc_icp_detailed_device(tc_context *ctx, const float *d_source, size_t n_source, const float *d_target,
+                                 size_t n_target, const float init[7], size_t max_iters, float max_dist, float conv_thr,
+                                 tc_icp_result *result) {
+    if (tc_status s = icp_validate(ctx, n_source, n_target, max_iters, result)) return s;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return icp_run(ctx, false, d_source, n_source, d_target, n_target, nullptr, 0, init, max_iters, max_dist, conv_thr, result, true);
+}
+
+tc_status tc_icp_detailed(tc_context *ctx, const float *source, size_t n_source, const float *target, size_t n_target,
+                          const float init[7], size_t max_iters, float max_dist, float conv_thr, tc_icp_result *result) {
+    if (tc_status s = icp_validate(ctx, n_source, n_target, max_iters, result)) return s;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = ensure(ctx, ctx->in_a, n_source * 3 * sizeof(float))) return s;
+    if (tc_status s = ensure(ctx, ctx->in_b, n_target * 3 * sizeof(float))) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, source, n_source * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_b.p, target, n_target * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return icp_run(ctx, false, (const float *)ctx->in_a.p, n_source, (const float *)ctx->in_b.p, n_target, nullptr, 0, init,
+                   max_iters, max_dist, conv_thr, result, false);
+}
+
+tc_status tc_icp_point_to_point(tc_context *ctx, const float *source, size_t n_source, const float *target, size_t n_target,
+                                const float init[7], size_t max_iterations, float conv_thr, float max_dist,
+                                tc_icp_result *result) {
+    if (tc_status s = icp_validate(ctx, n_source, n_target, max_iterations, result)) return s;
+    if (!(conv_thr > 0.0f)) return fail(ctx, TC_INVALID_DATA, "Convergence threshold must be positive");   // registration.rs:665-669
+    return tc_icp_detailed(ctx, source, n_source, target, n_target, init, max_iterations, max_dist, conv_thr, result);
+}
+
+tc_status tc_icp(tc_context *ctx, const float *source, size_t n_source, const float *target, size_t n_target,
+                 const float init[7], size_t max_iters, float out[7]) {
+    if (!ctx || !out || !init) return TC_INVALID_DATA;
+    tc_icp_result r;
+    std::memset(&r, 0, sizeof(r));
+    tc_status s = tc_icp_detailed(ctx, source, n_source, target, n_target, init, max_iters, -1.0f, 1e-6f, &r);   // registration.rs:238
+    if (s == TC_OK) std::memcpy(out, r.transformation, 7 * sizeof(float));
+    else std::memcpy(out, init, 7 * sizeof(float));                                                             // :240
+    return TC_OK;
+}
+
+static tc_status p2plane_validate(tc_context *ctx, size_t ns, size_t nt, size_t nn, size_t stride, size_t max_iters,
+                                  const tc_icp_result *res) {
+    if (!ctx || !res) return TC_INVALID_DATA;
+    if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");            // registration.rs:517-521
+    if (nn != nt) return fail(ctx, TC_INVALID_DATA, "target_normals length must equal the number of target points"); // :522-526
+    if (max_iters == 0) return fail(ctx, TC_INVALID_DATA, "Max iterations must be positive");                        // :527-531
+    if (stride < 3) return fail(ctx, TC_INVALID_DATA, "normal_stride must be >= 3");
+    if (ns >= 0xFFFFFFF0ull || nt >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    return TC_OK;
+}
+
+tc_status tc_icp_point_to_plane_detailed_device(tc_context *ctx, const float *d_source, size_t n_source,
+                                                const float *d_target, size_t n_target, const float *d_normals,
+                                                size_t n_normals, size_t stride, const float init[7], size_t max_iters,
+                                                float max_dist, float conv_thr, tc_icp_result *result) {
+    if (tc_status s = p2plane_validate(ctx, n_source, n_target, n_normals, stride, max_iters, result)) return s;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return icp_run(ctx, true, d_source, n_source, d_target, n_target, d_normals, stride, init, max_iters, max_dist, conv_thr,
+                   result, true);
+}
+
+tc_status tc_icp_point_to_plane_detailed(tc_context *ctx, const float *source, size_t n_source, const float *target,
+                                         size_t n_target, const float *normals, size_t n_normals, size_t stride,
+                                         const float init[7], size_t max_iters, float max_dist, float conv_thr,
+                                         tc_icp_result *result) {
+    if (tc_status s = p2plane_validate(ctx, n_source, n_target, n_normals, stride, max_iters, result)) return s;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t nbytes = ((n_normals - 1) * stride + 3) * sizeof(float);
+    if (tc_status s = ensure(ctx, ctx->in_a, n_source * 3 * sizeof(float))) return s;
+    if (tc_status s = ensure(ctx, ctx->in_b, n_target * 3 * sizeof(float))) return s;
+    if (tc_status s = ensure(ctx, ctx->in_c, nbytes)) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, source, n_source * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_b.p, target, n_target * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_c.p, normals, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    return icp_run(ctx, true, (const float *)ctx->in_a.p, n_source, (const float *)ctx->in_b.p, n_target,
+                   (const float *)ctx->in_c.p, stride, init, max_iters, max_dist, conv_thr, result, false);
+}
+
+tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp_job *jobs, size_t n_jobs,
+                       tc_batch_icp_result *results) {
+    if (!ctxs || n_ctx == 0 || (!jobs && n_jobs) || (!results && n_jobs)) return TC_INVALID_DATA;
+    static const float identity[7] = {0, 0, 0, 1, 0, 0, 0};   // gpu/icp.rs:202: always starts from identity
+    auto worker = [&](size_t c) {
+        for (size_t j = c; j < n_jobs; j += n_ctx) {
+            tc_icp_result r;
+            std::memset(&r, 0, sizeof(r));
+            const tc_batch_icp_job &jb = jobs[j];
+            tc_status s = tc_icp_point_to_point(ctxs[c], jb.source, jb.n_source, jb.target, jb.n_target, identity,
+                                                jb.max_iterations, jb.convergence_threshold, jb.max_correspondence_distance, &r);
+            std::memcpy(results[j].transformation, s == TC_OK ? r.transformation : identity, 7 * sizeof(float));
+            results[j].final_error = r.mse;
+            results[j].iterations = r.iterations;
+            results[j].status = (int32_t)s;
+        }
+    };
+    if (n_ctx == 1) { worker(0); return TC_OK; }
+    std::vector<std::thread> th;
+    for (size_t c = 0; c < n_ctx; ++c) th.emplace_back(worker, c);
+    for (auto &t : th) t.join();
+    return TC_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+void tc_profile_enable(tc_context *ctx, int on) { if (ctx) ctx->profiling = on != 0; }
+
+static void profile_collect(tc_context *ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->timers) {
+        for (auto &p : t.pending) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t.total_ms += ms; t.launches += 1; }
+            ctx->event_pool.push_back(p.first);
+            ctx->event_pool.push_back(p.second);
+        }
+        t.pending.clear();
+    }
+}
+
+void tc_profile_reset(tc_context *ctx) {
+    if (!ctx) return;
+    profile_collect(ctx);
+    for (auto &t : ctx->timers) { t.launches = 0; t.total_ms = 0.0; }
+}
+
+size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap) {
+    if (!ctx) return 0;
+    profile_collect(ctx);
+    size_t n = 0;
+    for (auto &t : ctx->timers) {
+        if (n < cap && out) {
+            std::memset(&out[n], 0, sizeof(out[n]));
+            std::strncpy(out[n].name, t.name.c_str(), sizeof(out[n].name) - 1);
+            out[n].launches = t.launches;
+            out[n].total_ms = t.total_ms;
+        }
+        ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,336 @@
+// grid.hip -- device-built uniform-grid index (replaces KdTree::new, nearest_neighbor.rs:37-159).
+//
+// Pipeline (all on ctx->stream):
+//   bbox_kernel      : min/max of the cloud (order-independent atomics on ordered-int floats)
+//   cell_hist_kernel : cell id per point + histogram
+//   scan_*           : exclusive prefix sum of the histogram -> cell_start
+//   scatter_kernel   : counting-sort scatter (atomic slot order, not yet deterministic)
+//   rank_gather_kernel : stable re-rank inside each cell by original index -> deterministic
+//                      cell-sorted float4 {x, y, z, original-index bits}
+// HBM traffic per point: 12 B read (AoS xyz) + 4 B cell id + 16 B sorted record + 4 B slot
+// (SURVEY 8d "index build" figure: 32 B/pt).
+#include "tc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace tc {
+
+// ---- ordered-int encoding of floats for atomicMin / atomicMax ------------------------------
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float ord2f(uint32_t u) {
+    uint32_t v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+}
+
+__device__ __forceinline__ void isometry_apply(const float q[4], const float t[3], float x, float y, float z,
+                                               float &ox, float &oy, float &oz) {
+    // nalgebra UnitQuaternion * Point3: t2 = 2 (qv x p); p' = t2*w + qv x t2 + p; then + translation
+    float tx = (q[1] * z - q[2] * y) * 2.0f;
+    float ty = (q[2] * x - q[0] * z) * 2.0f;
+    float tz = (q[0] * y - q[1] * x) * 2.0f;
+    float cx = q[1] * tz - q[2] * ty;
+    float cy = q[2] * tx - q[0] * tz;
+    float cz = q[0] * ty - q[1] * tx;
+    ox = ((tx * q[3] + cx) + x) + t[0];
+    oy = ((ty * q[3] + cy) + y) + t[1];
+    oz = ((tz * q[3] + cz) + z) + t[2];
+}
+
+__global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, uint32_t *__restrict__ box) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);   // fminf ignores NaN
+        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            atomicMin(&box[c], f2ord(mn[c]));
+            atomicMax(&box[3 + c], f2ord(mx[c]));
+        }
+    }
+}
+
+// cell id per point (+ histogram).  With `st` != null the point is first moved by the
+// isometry in *st (ICP source ordering by target cell); the stored record keeps the raw point.
+__global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g,
+                                                       const IcpState *__restrict__ st,
+                                                       uint32_t *__restrict__ cell_of, uint32_t *__restrict__ hist) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    if (st) {
+        float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]}, t[3] = {st->t[0], st->t[1], st->t[2]};
+        float ox, oy, oz;
+        isometry_apply(q, t, x, y, z, ox, oy, oz);
+        x = ox; y = oy; z = oz;
+    }
+    int ix = cell_coord(x, g.minx, g.inv_h, g.gx);
+    int iy = cell_coord(y, g.miny, g.inv_h, g.gy);
+    int iz = cell_coord(z, g.minz, g.inv_h, g.gz);
+    uint32_t c = ((uint32_t)iz * g.gy + iy) * g.gx + ix;
+    cell_of[i] = c;
+    atomicAdd(&hist[c], 1u);
+}
+
+constexpr int kScanItems = 8;
+constexpr int kScanBlock = 256;
+constexpr int kScanTile = kScanItems * kScanBlock;
+
+__global__ void __launch_bounds__(kScanBlock) scan_reduce_kernel(const uint32_t *__restrict__ in, uint32_t n,
+                                                                 uint32_t *__restrict__ blocksum) {
+    __shared__ uint32_t wsum[kScanBlock / 64];
+    uint32_t base = blockIdx.x * kScanTile;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t i = base + k * kScanBlock + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// single block: in-place exclusive scan of blocksum[0..nb)
+__global__ void __launch_bounds__(1024) scan_top_kernel(uint32_t *__restrict__ blocksum, uint32_t nb) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = (i < nb) ? blocksum[i] : 0;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_up(inc, o);
+            if ((threadIdx.x & 63) >= (unsigned)o) inc += t;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
+        uint32_t carry = carry_s;
+        if (i < nb) blocksum[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t n,
+                                                                const uint32_t *__restrict__ blocksum,
+                                                                uint32_t *__restrict__ out /* n+1 */) {
+    __shared__ uint32_t wtot[kScanBlock / 64];
+    // thread owns kScanItems CONSECUTIVE items so the in-thread prefix is sequential
+    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t i = base + k;
+        v[k] = (i < n) ? in[i] : 0;
+        s += v[k];
+    }
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o);
+        if ((threadIdx.x & 63) >= (unsigned)o) inc += t;
+    }
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
+    uint32_t run = blocksum[blockIdx.x] + woff + inc - s;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t i = base + k;
+        if (i < n) out[i] = run;
+        run += v[k];
+        if (i == n - 1) out[n] = run;
+    }
+}
+
+__global__ void __launch_bounds__(256) scatter_kernel(const uint32_t *__restrict__ cell_of, uint32_t n,
+                                                     const uint32_t *__restrict__ cell_start,
+                                                     uint32_t *__restrict__ fill, uint32_t *__restrict__ slot) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = cell_of[i];
+    uint32_t pos = cell_start[c] + atomicAdd(&fill[c], 1u);
+    slot[pos] = i;
+}
+
+// stable re-rank inside the cell (ascending original index) + gather into the sorted record array
+__global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restrict__ xyz, uint32_t n,
+                                                         const uint32_t *__restrict__ cell_of,
+                                                         const uint32_t *__restrict__ cell_start,
+                                                         const uint32_t *__restrict__ slot,
+                                                         float4 *__restrict__ pts) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t i = slot[p];
+    uint32_t c = cell_of[i];
+    uint32_t s = cell_start[c], e = cell_start[c + 1];
+    uint32_t rank;
+    if (e - s <= 4096u) {
+        rank = 0;
+        for (uint32_t j = s; j < e; ++j) rank += (slot[j] < i) ? 1u : 0u;
+    } else {
+        rank = p - s;   // pathological cell: keep the atomic order (documented in DESIGN.md)
+    }
+    float4 r;
+    r.x = xyz[3 * (size_t)i]; r.y = xyz[3 * (size_t)i + 1]; r.z = xyz[3 * (size_t)i + 2];
+    r.w = __uint_as_float(i);
+    pts[s + rank] = r;
+}
+
+__global__ void __launch_bounds__(256) gather_normals_kernel(const float4 *__restrict__ pts, uint32_t n,
+                                                            const float *__restrict__ nrm, size_t stride,
+                                                            float4 *__restrict__ out) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t i = __float_as_uint(pts[p].w);
+    const float *s = nrm + (size_t)i * stride;
+    out[p] = make_float4(s[0], s[1], s[2], 0.0f);
+}
+
+GridView view_of(const DeviceIndex &ix) {
+    GridView v;
+    v.g = ix.geom;
+    v.pts = (const float4 *)ix.pts.p;
+    v.cell_start = (const uint32_t *)ix.cell_start.p;
+    return v;
+}
+
+// Cell edge from the bounding box: h = f * (measure / n)^(1/d) over the non-degenerate axes.
+static void derive_geom(GridGeom &g, const float mn[3], const float mx[3], size_t n, float f) {
+    g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
+    g.maxx = mx[0]; g.maxy = mx[1]; g.maxz = mx[2];
+    g.cx = 0.5f * (mn[0] + mx[0]); g.cy = 0.5f * (mn[1] + mx[1]); g.cz = 0.5f * (mn[2] + mx[2]);
+    double e[3] = {(double)mx[0] - mn[0], (double)mx[1] - mn[1], (double)mx[2] - mn[2]};
+    double emax = std::max(e[0], std::max(e[1], e[2]));
+    double h = 1.0;
+    if (!(emax > 0.0) || !std::isfinite(emax)) {
+        h = 1.0;
+    } else {
+        double measure = 1.0;
+        int dims = 0;
+        for (int a = 0; a < 3; ++a)
+            if (e[a] > 1e-6 * emax) { measure *= e[a]; ++dims; }
+        h = f * std::pow(measure / (double)std::max<size_t>(n, 1), 1.0 / (double)dims);
+        if (!(h > 0.0) || !std::isfinite(h)) h = emax;
+        h = std::max(h, emax * 1e-4);   // at most 10^4 cells per axis
+    }
+    const double max_cells = std::max<double>(8.0 * (double)n, 4096.0);
+    for (int guard = 0; guard < 200; ++guard) {
+        double gx = std::floor(e[0] / h) + 1.0, gy = std::floor(e[1] / h) + 1.0, gz = std::floor(e[2] / h) + 1.0;
+        if (gx * gy * gz <= max_cells && gx * gy * gz < 2.0e9) {
+            g.gx = (int)gx; g.gy = (int)gy; g.gz = (int)gz;
+            break;
+        }
+        h *= 1.2;
+    }
+    g.h = (float)h;
+    g.inv_h = 1.0f / g.h;
+    g.ncell = (uint32_t)g.gx * (uint32_t)g.gy * (uint32_t)g.gz;
+    g.n = (uint32_t)n;
+}
+
+tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n, float cell_factor,
+                      const GridGeom *reuse_geom, const IcpState *d_state_transform) {
+    if (n == 0 || n >= 0xFFFFFFF0ull) return fail(ctx, TC_INVALID_DATA, "build_index: bad point count");
+    hipStream_t st = ctx->stream;
+    const uint32_t n32 = (uint32_t)n;
+    const int nb = (int)((n + 255) / 256);
+
+    if (reuse_geom) {
+        ix.geom = *reuse_geom;
+        ix.geom.n = n32;
+    } else {
+        if (tc_status s = ensure(ctx, ctx->bbox, 6 * sizeof(uint32_t))) return s;
+        TC_HIP_TRY(ctx, hipMemsetAsync(ctx->bbox.p, 0xFF, 3 * sizeof(uint32_t), st));
+        TC_HIP_TRY(ctx, hipMemsetAsync((uint32_t *)ctx->bbox.p + 3, 0x00, 3 * sizeof(uint32_t), st));
+        {
+            ProfScope ps(ctx, "bbox");
+            hipLaunchKernelGGL(bbox_kernel, dim3(std::min(nb, 1024)), dim3(256), 0, st, d_xyz, n32, (uint32_t *)ctx->bbox.p);
+        }
+        uint32_t *hb = (uint32_t *)ctx->pinned;
+        TC_HIP_TRY(ctx, hipMemcpyAsync(hb, ctx->bbox.p, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+        float mn[3], mx[3];
+        for (int c = 0; c < 3; ++c) { mn[c] = ord2f(hb[c]); mx[c] = ord2f(hb[3 + c]); }
+        for (int c = 0; c < 3; ++c)
+            if (!(mn[c] <= mx[c]) || !std::isfinite(mn[c]) || !std::isfinite(mx[c])) { mn[c] = 0.0f; mx[c] = 0.0f; }
+        derive_geom(ix.geom, mn, mx, n, cell_factor);
+    }
+    const GridGeom g = ix.geom;
+
+    if (tc_status s = ensure(ctx, ix.pts, n * sizeof(float4))) return s;
+    if (tc_status s = ensure(ctx, ix.cell_of, n * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.slot, n * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.fill, (size_t)g.ncell * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.cell_start, ((size_t)g.ncell + 1) * sizeof(uint32_t))) return s;
+    const uint32_t nscan = (g.ncell + kScanTile - 1) / kScanTile;
+    if (tc_status s = ensure(ctx, ix.blocksum, (size_t)nscan * sizeof(uint32_t))) return s;
+
+    TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)g.ncell * sizeof(uint32_t), st));
+    {
+        ProfScope ps(ctx, "cell_hist");
+        hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform,
+                           (uint32_t *)ix.cell_of.p, (uint32_t *)ix.fill.p);
+    }
+    {
+        ProfScope ps(ctx, "cell_scan");
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nscan), dim3(kScanBlock), 0, st, (const uint32_t *)ix.fill.p, g.ncell,
+                           (uint32_t *)ix.blocksum.p);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, (uint32_t *)ix.blocksum.p, nscan);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, (const uint32_t *)ix.fill.p, g.ncell,
+                           (const uint32_t *)ix.blocksum.p, (uint32_t *)ix.cell_start.p);
+    }
+    TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)g.ncell * sizeof(uint32_t), st));
+    {
+        ProfScope ps(ctx, "cell_scatter");
+        hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)ix.cell_of.p, n32,
+                           (const uint32_t *)ix.cell_start.p, (uint32_t *)ix.fill.p, (uint32_t *)ix.slot.p);
+    }
+    {
+        ProfScope ps(ctx, "cell_rank_gather");
+        hipLaunchKernelGGL(rank_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, (const uint32_t *)ix.cell_of.p,
+                           (const uint32_t *)ix.cell_start.p, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p);
+    }
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
+tc_status gather_normals(tc_context *ctx, DeviceIndex &ix, const float *d_normals, size_t stride) {
+    const size_t n = ix.geom.n;
+    if (tc_status s = ensure(ctx, ix.normals, n * sizeof(float4))) return s;
+    ProfScope ps(ctx, "gather_normals");
+    hipLaunchKernelGGL(gather_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float4 *)ix.pts.p, (uint32_t)n, d_normals, stride, (float4 *)ix.normals.p);
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
+}  // namespace tc

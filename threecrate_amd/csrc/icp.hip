@@ -1,0 +1,660 @@
+// icp.hip -- HK3 icp_correspond_reduce + device-side solve for point-to-point and
+// point-to-plane ICP (threecrate-algorithms/src/registration.rs:258-370, :508-602).
+//
+// One iteration = two launches on the context's stream, no host round trip:
+//   icp_correspond_reduce_kernel : per source point (visited in target-cell order):
+//        ts = current_transform * s            (registration.rs:285-289 / :540-544, same f32 formula)
+//        exact 1-NN of ts in the target grid   (:87-107; ring search with an exact stopping rule
+//                                               that also covers queries outside the grid)
+//        write the matched target index        (ICPResult.correspondences, :22-23)
+//        accumulate the packed normal equations of the iteration in f64:
+//          p2plane: 21 upper-tri AtA + 6 Atb + sum b^2 + count = 29 words (:409-428, :453-471)
+//          p2point: sum s, sum q, sum s q^T, sum |s-q|^2, count = 17 words (:154-172, :206-218)
+//        wave64 shuffle reduction -> LDS -> one row of per-block partials (fixed order,
+//        no float atomics: results are bit-reproducible run to run).
+//   icp_finalize_kernel : fixed-order sum of the partials, 6x6 Cholesky/LU (p2plane) or 3x3
+//        Kabsch via one-sided Jacobi SVD (p2point) in f64, compose `delta * current`, mse,
+//        |prev_mse - mse| < threshold test, all state kept in an IcpState in HBM.
+// Algorithmic HBM bytes per source point and iteration: 12 src + 12 matched target
+// + 12 matched normal + 4 index out = 40 B (p2plane), 28 B (p2point).
+#include "tc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace tc {
+
+__device__ __forceinline__ void iso_apply(const float q[4], const float t[3], float x, float y, float z,
+                                          float &ox, float &oy, float &oz) {
+    // nalgebra: t2 = (qv x p) * 2; p' = (t2 * w + qv x t2) + p; then + translation
+    float tx = (q[1] * z - q[2] * y) * 2.0f;
+    float ty = (q[2] * x - q[0] * z) * 2.0f;
+    float tz = (q[0] * y - q[1] * x) * 2.0f;
+    float cx = q[1] * tz - q[2] * ty;
+    float cy = q[2] * tx - q[0] * tz;
+    float cz = q[0] * ty - q[1] * tx;
+    ox = ((tx * q[3] + cx) + x) + t[0];
+    oy = ((ty * q[3] + cy) + y) + t[1];
+    oz = ((tz * q[3] + cz) + z) + t[2];
+}
+
+__device__ __forceinline__ uint32_t xcd_remap_icp(uint32_t b, uint32_t nb) {
+    const uint32_t per = nb >> 3;          // nb is a multiple of 8
+    return (b & 7u) * per + (b >> 3);
+}
+
+// exact nearest record of the target grid to (x, y, z); query may lie outside the grid
+__device__ __forceinline__ void nn_search(const GridView &gv, float x, float y, float z, float max_dist,
+                                          float &best, uint32_t &bestj) {
+    const GridGeom &g = gv.g;
+    const float qx = fminf(fmaxf(x, g.minx), g.maxx), qy = fminf(fmaxf(y, g.miny), g.maxy),
+                qz = fminf(fmaxf(z, g.minz), g.maxz);
+    const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx);
+    const int cy = cell_coord(qy, g.miny, g.inv_h, g.gy);
+    const int cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
+    float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy,
+          fz = (qz - g.minz) * g.inv_h - (float)cz;
+    float mf = fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz));
+    mf = fmaxf(mf, 0.0f);
+    best = INFINITY;
+    bestj = 0xFFFFFFFFu;
+    auto span = [&](uint32_t row, int xa, int xb) {
+        const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
+        for (uint32_t j = s; j < e; ++j) {
+            const float4 c = gv.pts[j];
+            const float v = d2_nc(c.x, c.y, c.z, x, y, z);
+            if (v < best) { best = v; bestj = j; }
+        }
+    };
+    for (int R = 1;; ++R) {
+        const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
+        const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
+        const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
+        for (int zz = z0; zz <= z1; ++zz) {
+            for (int yy = y0; yy <= y1; ++yy) {
+                const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
+                const bool edge = (zz == cz - R) || (zz == cz + R) || (yy == cy - R) || (yy == cy + R);
+                if (R == 1 || edge) {
+                    span(row, x0, x1);
+                } else {   // interior rows of a shell: only the two end cells are new
+                    if (cx - R >= 0) span(row, cx - R, cx - R);
+                    if (cx + R <= g.gx - 1) span(row, cx + R, cx + R);
+                }
+            }
+        }
+        const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
+                            (cz - R <= 0) && (cz + R >= g.gz - 1);
+        const float bound = ((float)R + mf - 2e-3f) * g.h;
+        if (covers || best <= bound * bound) break;
+        if (max_dist >= 0.0f && bound > max_dist) break;   // everything unscanned would be rejected
+    }
+}
+
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *__restrict__ out_row) {
+    __shared__ double sm[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        acc[i] = v;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) sm[w][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
+        double s = 0.0;
+        if (threadIdx.x < NACC) s = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+        out_row[threadIdx.x] = s;
+    }
+}
+
+template <bool P2PLANE>
+__global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
+    GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
+    const IcpState *__restrict__ st, uint32_t *__restrict__ corr, uint32_t *__restrict__ corr_pos,
+    double *__restrict__ partials) {
+    constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
+    if (st->done) return;
+    const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
+    const float t[3] = {st->t[0], st->t[1], st->t[2]};
+    const float max_dist = st->max_dist;
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+
+    const uint32_t lb = xcd_remap_icp(blockIdx.x, gridDim.x);
+    const uint32_t beg = lb * chunk;
+    const uint32_t end = min(beg + chunk, ns);
+    for (uint32_t j = beg + threadIdx.x; j < end; j += kIcpBlock) {
+        const float4 s = src[j];
+        float x, y, z;
+        iso_apply(q, t, s.x, s.y, s.z, x, y, z);
+        float best; uint32_t bj;
+        nn_search(tgt, x, y, z, max_dist, best, bj);
+        bool valid = bj != 0xFFFFFFFFu;
+        if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
+        const uint32_t so = __float_as_uint(s.w);
+        if (!valid) {
+            corr[so] = 0xFFFFFFFFu;
+            if (!P2PLANE) corr_pos[j] = 0xFFFFFFFFu;
+            continue;
+        }
+        const float4 c = tgt.pts[bj];
+        corr[so] = __float_as_uint(c.w);
+        if (P2PLANE) {
+            const float4 n = tgt_nrm[bj];
+            // registration.rs:417-427 in f32: c = s x n ; a = [c, n] ; b = n . (d - s)
+            const float a0 = y * n.z - z * n.y, a1 = z * n.x - x * n.z, a2 = x * n.y - y * n.x;
+            const float dx = c.x - x, dy = c.y - y, dz = c.z - z;
+            const float b = n.x * dx + n.y * dy + n.z * dz;
+            const double a[6] = {(double)a0, (double)a1, (double)a2, (double)n.x, (double)n.y, (double)n.z};
+            const double bd = (double)b;
+            int o = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = r; cc < 6; ++cc) { acc[o] = fma(a[r], a[cc], acc[o]); ++o; }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[21 + r] = fma(a[r], bd, acc[21 + r]);
+            acc[27] = fma(bd, bd, acc[27]);
+            acc[28] += 1.0;
+        } else {
+            corr_pos[j] = bj;
+            // shifted by the target bbox centre so that H = sum s q^T - n ms mq^T does not cancel
+            const double sx = (double)x - (double)tgt.g.cx, sy = (double)y - (double)tgt.g.cy, sz = (double)z - (double)tgt.g.cz;
+            const double qx = (double)c.x - (double)tgt.g.cx, qy = (double)c.y - (double)tgt.g.cy, qz = (double)c.z - (double)tgt.g.cz;
+            acc[0] += sx; acc[1] += sy; acc[2] += sz;
+            acc[3] += qx; acc[4] += qy; acc[5] += qz;
+            acc[6] = fma(sx, qx, acc[6]);   acc[7] = fma(sx, qy, acc[7]);   acc[8] = fma(sx, qz, acc[8]);
+            acc[9] = fma(sy, qx, acc[9]);   acc[10] = fma(sy, qy, acc[10]); acc[11] = fma(sy, qz, acc[11]);
+            acc[12] = fma(sz, qx, acc[12]); acc[13] = fma(sz, qy, acc[13]); acc[14] = fma(sz, qz, acc[14]);
+            const float ex = x - c.x, ey = y - c.y, ez = z - c.z;          // registration.rs:214
+            acc[15] += (double)(ex * ex + ey * ey + ez * ez);
+            acc[16] += 1.0;
+        }
+    }
+    block_reduce_store<NACC>(acc, partials + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE);
+}
+
+// mse of the last correspondences under the final transform (registration.rs:343-361)
+__global__ void __launch_bounds__(kIcpBlock) icp_final_mse_kernel(GridView tgt, const float4 *__restrict__ src, uint32_t ns,
+                                                                  uint32_t chunk, const IcpState *__restrict__ st,
+                                                                  const uint32_t *__restrict__ corr_pos,
+                                                                  double *__restrict__ partials) {
+    if (st->done) return;
+    const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
+    const float t[3] = {st->t[0], st->t[1], st->t[2]};
+    double acc[2] = {0.0, 0.0};
+    const uint32_t lb = xcd_remap_icp(blockIdx.x, gridDim.x);
+    const uint32_t beg = lb * chunk, end = min(beg + chunk, ns);
+    for (uint32_t j = beg + threadIdx.x; j < end; j += kIcpBlock) {
+        const uint32_t bj = corr_pos[j];
+        if (bj == 0xFFFFFFFFu) continue;
+        const float4 s = src[j];
+        float x, y, z;
+        iso_apply(q, t, s.x, s.y, s.z, x, y, z);
+        const float4 c = tgt.pts[bj];
+        const float ex = x - c.x, ey = y - c.y, ez = z - c.z;
+        acc[0] += (double)(ex * ex + ey * ey + ez * ez);
+        acc[1] += 1.0;
+    }
+    block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE);
+}
+
+// ---- small f64 solvers (one lane) -----------------------------------------------------------
+__device__ bool chol6_solve(const double A[6][6], const double b[6], double x[6]) {
+    double L[6][6];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) L[i][j] = A[i][j];
+    for (int j = 0; j < 6; ++j) {
+        for (int k = 0; k < j; ++k) {
+            const double f = L[j][k];
+            for (int r = j; r < 6; ++r) L[r][j] -= f * L[r][k];
+        }
+        const double d = L[j][j];
+        if (!(d > 0.0)) return false;     // Cholesky::new -> None on a non-positive pivot
+        const double sd = sqrt(d);
+        L[j][j] = sd;
+        for (int r = j + 1; r < 6; ++r) L[r][j] /= sd;
+    }
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i][k] * x[k];
+        x[i] = s / L[i][i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = x[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
+        x[i] = s / L[i][i];
+    }
+    return true;
+}
+
+__device__ bool lu6_solve(const double Ain[6][6], const double b[6], double x[6]) {
+    double A[6][6];
+    for (int i = 0; i < 6; ++i) { x[i] = b[i]; for (int j = 0; j < 6; ++j) A[i][j] = Ain[i][j]; }
+    for (int i = 0; i < 6; ++i) {
+        int piv = i; double best = fabs(A[i][i]);
+        for (int r = i + 1; r < 6; ++r) { const double v = fabs(A[r][i]); if (v > best) { best = v; piv = r; } }
+        if (A[piv][i] == 0.0) continue;
+        if (piv != i) {
+            for (int c = 0; c < 6; ++c) { const double tt = A[i][c]; A[i][c] = A[piv][c]; A[piv][c] = tt; }
+            const double tt = x[i]; x[i] = x[piv]; x[piv] = tt;
+        }
+        const double inv = 1.0 / A[i][i];
+        for (int r = i + 1; r < 6; ++r) {
+            const double f = A[r][i] * inv;
+            A[r][i] = f;
+            for (int c = i + 1; c < 6; ++c) A[r][c] -= f * A[i][c];
+            x[r] -= f * x[i];
+        }
+    }
+    for (int i = 5; i >= 0; --i) {
+        if (A[i][i] == 0.0) return false;
+        double s = x[i];
+        for (int c = i + 1; c < 6; ++c) s -= A[i][c] * x[c];
+        x[i] = s / A[i][i];
+    }
+    return true;
+}
+
+__device__ __forceinline__ void quat_mul_f(const float a[4], const float b[4], float o[4]) {
+    const float w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    const float i = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    const float j = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    const float k = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[0] = i; o[1] = j; o[2] = k; o[3] = w;
+}
+
+// current = delta * current  (Isometry3 product, registration.rs:321 / :576)
+__device__ void compose(IcpState *st, const float dq[4], const float dt[3]) {
+    const float cq[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
+    const float ct[3] = {st->t[0], st->t[1], st->t[2]};
+    const float zero[3] = {0.0f, 0.0f, 0.0f};
+    float rx, ry, rz;
+    iso_apply(dq, zero, ct[0], ct[1], ct[2], rx, ry, rz);    // R_delta * t_current
+    float nq[4];
+    quat_mul_f(dq, cq, nq);
+    st->q[0] = nq[0]; st->q[1] = nq[1]; st->q[2] = nq[2]; st->q[3] = nq[3];
+    st->t[0] = dt[0] + rx; st->t[1] = dt[1] + ry; st->t[2] = dt[2] + rz;
+}
+
+// Kabsch rotation from the 3x3 cross-covariance H = sum p q^T (registration.rs:166-194):
+// H = U S V^T by one-sided Jacobi (H V = U S), R = V U^T, reflection fixed on the smallest
+// singular direction (the reference negates row 2 of V^T after its descending sort).
+__device__ void kabsch_rotation(const double Hin[3][3], double R[3][3]) {
+    double H[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { H[i][j] = Hin[i][j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p) for (int qq = p + 1; qq < 3; ++qq) {
+            double alpha = 0, beta = 0, gamma = 0;
+            for (int i = 0; i < 3; ++i) { alpha += H[i][p] * H[i][p]; beta += H[i][qq] * H[i][qq]; gamma += H[i][p] * H[i][qq]; }
+            if (gamma == 0.0 || fabs(gamma) <= 1e-18 * sqrt(alpha * beta)) continue;
+            off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
+            const double zeta = (beta - alpha) / (2.0 * gamma);
+            const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+            for (int i = 0; i < 3; ++i) {
+                const double hp = H[i][p], hq = H[i][qq];
+                H[i][p] = c * hp - s * hq; H[i][qq] = s * hp + c * hq;
+                const double vp = V[i][p], vq = V[i][qq];
+                V[i][p] = c * vp - s * vq; V[i][qq] = s * vp + c * vq;
+            }
+        }
+        if (off < 1e-15) break;
+    }
+    double sig[3], U[3][3];
+    for (int j = 0; j < 3; ++j) sig[j] = sqrt(H[0][j] * H[0][j] + H[1][j] * H[1][j] + H[2][j] * H[2][j]);
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i) for (int j = i + 1; j < 3; ++j) if (sig[order[j]] > sig[order[i]]) { int t0 = order[i]; order[i] = order[j]; order[j] = t0; }
+    const int i0 = order[0], i1 = order[1], i2 = order[2];
+    const double smax = sig[i0];
+    for (int i = 0; i < 3; ++i) { U[i][i0] = 0; U[i][i1] = 0; U[i][i2] = 0; }
+    if (smax > 0.0) for (int i = 0; i < 3; ++i) U[i][i0] = H[i][i0] / smax; else U[0][i0] = 1.0;
+    if (sig[i1] > 1e-14 * smax && sig[i1] > 0.0) {
+        for (int i = 0; i < 3; ++i) U[i][i1] = H[i][i1] / sig[i1];
+    } else {   // rank 1: any unit vector orthogonal to u0
+        double ax = fabs(U[0][i0]), ay = fabs(U[1][i0]), az = fabs(U[2][i0]);
+        double e[3] = {0, 0, 0};
+        e[(ax <= ay && ax <= az) ? 0 : (ay <= az ? 1 : 2)] = 1.0;
+        double d = e[0] * U[0][i0] + e[1] * U[1][i0] + e[2] * U[2][i0];
+        double v[3] = {e[0] - d * U[0][i0], e[1] - d * U[1][i0], e[2] - d * U[2][i0]};
+        double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        for (int i = 0; i < 3; ++i) U[i][i1] = v[i] / nv;
+    }
+    bool u2_from_cross = !(sig[i2] > 1e-14 * smax && sig[i2] > 0.0);
+    if (!u2_from_cross) {
+        for (int i = 0; i < 3; ++i) U[i][i2] = H[i][i2] / sig[i2];
+    } else {
+        U[0][i2] = U[1][i0] * U[2][i1] - U[2][i0] * U[1][i1];
+        U[1][i2] = U[2][i0] * U[0][i1] - U[0][i0] * U[2][i1];
+        U[2][i2] = U[0][i0] * U[1][i1] - U[1][i0] * U[0][i1];
+    }
+    // R = V U^T
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + V[i][2] * U[j][2];
+    const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                       R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+    if (det < 0.0) {   // registration.rs:187-191
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] -= 2.0 * V[i][i2] * U[j][i2];
+    }
+}
+
+__device__ void rotmat_to_quat(const double m[3][3], float q[4]) {
+    const double tr = m[0][0] + m[1][1] + m[2][2];
+    double w, i, j, k;
+    if (tr > 0.0) {
+        const double d = sqrt(tr + 1.0) * 2.0;
+        w = 0.25 * d; i = (m[2][1] - m[1][2]) / d; j = (m[0][2] - m[2][0]) / d; k = (m[1][0] - m[0][1]) / d;
+    } else if (m[0][0] > m[1][1] && m[0][0] > m[2][2]) {
+        const double d = sqrt(1.0 + m[0][0] - m[1][1] - m[2][2]) * 2.0;
+        w = (m[2][1] - m[1][2]) / d; i = 0.25 * d; j = (m[0][1] + m[1][0]) / d; k = (m[0][2] + m[2][0]) / d;
+    } else if (m[1][1] > m[2][2]) {
+        const double d = sqrt(1.0 + m[1][1] - m[0][0] - m[2][2]) * 2.0;
+        w = (m[0][2] - m[2][0]) / d; i = (m[0][1] + m[1][0]) / d; j = 0.25 * d; k = (m[1][2] + m[2][1]) / d;
+    } else {
+        const double d = sqrt(1.0 + m[2][2] - m[0][0] - m[1][1]) * 2.0;
+        w = (m[1][0] - m[0][1]) / d; i = (m[0][2] + m[2][0]) / d; j = (m[1][2] + m[2][1]) / d; k = 0.25 * d;
+    }
+    const double nq = sqrt(w * w + i * i + j * j + k * k);
+    q[0] = (float)(i / nq); q[1] = (float)(j / nq); q[2] = (float)(k / nq); q[3] = (float)(w / nq);
+}
+
+// convergence bookkeeping shared by both variants (registration.rs:324-339 / :578-592)
+__device__ void finish_iteration(IcpState *st, float mse, uint32_t n) {
+    st->iterations += 1;
+    st->mse = mse;
+    st->n_corr = n;
+    const float change = fabsf(st->prev_mse - mse);
+    if (change < st->conv_thr) { st->converged = 1; st->done = 1; return; }
+    st->prev_mse = mse;
+}
+
+template <bool P2PLANE>
+__global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
+                                                          IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply) {
+    if (st->done) return;
+    __shared__ double sm[8][TC_ICP_SUMS_STRIDE];
+    if (do_sum) {
+        const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+        double s = 0.0;
+        for (uint32_t b = grp; b < nblocks; b += 8) s += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
+        sm[grp][col] = s;
+        __syncthreads();
+        if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
+            double tot = 0.0;
+#pragma unroll
+            for (int gi = 0; gi < 8; ++gi) tot += sm[gi][threadIdx.x];
+            st->sums[threadIdx.x] = tot;
+        }
+        __syncthreads();
+    }
+    if (!do_apply || threadIdx.x != 0) return;
+    const double *S = st->sums;
+    if (P2PLANE) {
+        const double cnt = S[28];
+        if (cnt < 6.0) { st->status = TC_ALGORITHM; st->done = 1; return; }     // registration.rs:568-572
+        double A[6][6], b[6], x[6];
+        int o = 0;
+        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r][c] = S[o]; A[c][r] = S[o]; ++o; }
+        for (int r = 0; r < 6; ++r) b[r] = S[21 + r];
+        if (!chol6_solve(A, b, x)) {
+            if (!lu6_solve(A, b, x)) { st->status = TC_ALGORITHM; st->done = 1; return; }   // :432-438
+        }
+        // Rz(x2) * Ry(x1) * Rx(x0) as axis-angle quaternions (:441-444), f32 like the reference
+        const float hx = (float)x[0] / 2.0f, hy = (float)x[1] / 2.0f, hz = (float)x[2] / 2.0f;
+        const float qx[4] = {sinf(hx), 0.0f, 0.0f, cosf(hx)};
+        const float qy[4] = {0.0f, sinf(hy), 0.0f, cosf(hy)};
+        const float qz[4] = {0.0f, 0.0f, sinf(hz), cosf(hz)};
+        float zy[4], rot[4];
+        quat_mul_f(qz, qy, zy);
+        quat_mul_f(zy, qx, rot);
+        const float dt[3] = {(float)x[3], (float)x[4], (float)x[5]};
+        compose(st, rot, dt);
+        finish_iteration(st, (float)(S[27] / cnt), (uint32_t)cnt);
+    } else {
+        const double cnt = S[16];
+        if (cnt < 3.0) { st->status = TC_ALGORITHM; st->done = 1; return; }     // registration.rs:311-315
+        const double ms[3] = {S[0] / cnt, S[1] / cnt, S[2] / cnt}, mq[3] = {S[3] / cnt, S[4] / cnt, S[5] / cnt};
+        double H[3][3], R[3][3];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] = S[6 + 3 * r + c] - cnt * ms[r] * mq[c];
+        kabsch_rotation(H, R);
+        const double cs[3] = {ms[0] + (double)g.cx, ms[1] + (double)g.cy, ms[2] + (double)g.cz};
+        const double cq[3] = {mq[0] + (double)g.cx, mq[1] + (double)g.cy, mq[2] + (double)g.cz};
+        float dq[4];
+        rotmat_to_quat(R, dq);
+        float dt[3];
+        for (int r = 0; r < 3; ++r) dt[r] = (float)(cq[r] - (R[r][0] * cs[0] + R[r][1] * cs[1] + R[r][2] * cs[2]));
+        compose(st, dq, dt);
+        finish_iteration(st, (float)(S[15] / cnt), (uint32_t)cnt);
+    }
+}
+
+// after the last iteration: not-converged epilogue (registration.rs:343-369 / :595-601)
+__global__ void icp_finish_kernel(IcpState *__restrict__ st, const double *__restrict__ partials, uint32_t nblocks, int p2plane) {
+    if (threadIdx.x != 0 || st->done) return;
+    st->converged = 0;
+    if (p2plane) {
+        st->mse = st->prev_mse;
+    } else {
+        double s = 0.0, c = 0.0;
+        for (uint32_t b = 0; b < nblocks; ++b) { s += partials[(size_t)b * TC_ICP_SUMS_STRIDE]; c += partials[(size_t)b * TC_ICP_SUMS_STRIDE + 1]; }
+        st->mse = (c > 0.0) ? (float)(s / c) : st->prev_mse;
+    }
+    st->done = 1;
+}
+
+// ---- host orchestration ---------------------------------------------------------------------
+struct IcpLaunch {
+    uint32_t nblocks = 0, chunk = 0;
+};
+static IcpLaunch plan_launch(size_t ns) {
+    IcpLaunch l;
+    uint32_t nb = (uint32_t)std::min<size_t>((ns + kIcpBlock - 1) / kIcpBlock, (size_t)kMaxPartialBlocks);
+    nb = std::max<uint32_t>((nb + 7) / 8 * 8, 8);
+    uint32_t chunk = (uint32_t)((ns + nb - 1) / nb);
+    chunk = (chunk + kIcpBlock - 1) / kIcpBlock * kIcpBlock;
+    l.nblocks = nb; l.chunk = chunk;
+    return l;
+}
+
+static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, const float4 *nrm, const float4 *src,
+                             uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr, uint32_t *corr_pos,
+                             double *partials, bool do_sum, bool do_apply, bool do_reduce) {
+    hipStream_t s = ctx->stream;
+    if (do_reduce) {
+        ProfScope ps(ctx, p2plane ? "icp_correspond_reduce_p2plane" : "icp_correspond_reduce_p2p");
+        if (p2plane)
+            hipLaunchKernelGGL(icp_correspond_reduce_kernel<true>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
+                               l.chunk, st, corr, corr_pos, partials);
+        else
+            hipLaunchKernelGGL(icp_correspond_reduce_kernel<false>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
+                               l.chunk, st, corr, corr_pos, partials);
+    }
+    if (do_sum || do_apply) {
+        ProfScope ps(ctx, "icp_finalize");
+        if (p2plane)
+            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(256), 0, s, partials, l.nblocks, st, tv.g, do_sum ? 1 : 0,
+                               do_apply ? 1 : 0);
+        else
+            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(256), 0, s, partials, l.nblocks, st, tv.g, do_sum ? 1 : 0,
+                               do_apply ? 1 : 0);
+    }
+}
+
+static float icp_cell_factor() { return 1.13f; }   // ~1.45 pts/cell: ring 1 is exact for ~99.8 % of uniform queries
+
+struct IcpSetup {
+    IcpLaunch l;
+    GridView tv;
+};
+
+static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
+                           const float *d_nrm, size_t nstride, const float init[7], float max_dist, float conv_thr,
+                           IcpSetup &out) {
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_tgt, nt, icp_cell_factor(), nullptr, nullptr)) return s;
+    if (p2plane)
+        if (tc_status s = gather_normals(ctx, ctx->tgt_index, d_nrm, nstride)) return s;
+    if (tc_status s = ensure(ctx, ctx->state, sizeof(IcpState))) return s;
+    IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
+    std::memset(hs, 0, sizeof(IcpState));
+    for (int i = 0; i < 4; ++i) hs->q[i] = init[i];
+    for (int i = 0; i < 3; ++i) hs->t[i] = init[4 + i];
+    hs->prev_mse = INFINITY;
+    hs->conv_thr = conv_thr;
+    hs->max_dist = max_dist;
+    hs->status = TC_OK;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, hs, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
+    // order the source by the target cell of its initially transformed position
+    if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &ctx->tgt_index.geom, (const IcpState *)ctx->state.p)) return s;
+    out.l = plan_launch(ns);
+    if (tc_status s = ensure(ctx, ctx->partials, (size_t)kMaxPartialBlocks * TC_ICP_SUMS_STRIDE * sizeof(double))) return s;
+    if (tc_status s = ensure(ctx, ctx->corr, 2 * ns * sizeof(uint32_t))) return s;
+    out.tv = view_of(ctx->tgt_index);
+    return TC_OK;
+}
+
+tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
+                  const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
+                  float conv_thr, tc_icp_result *res, bool corr_on_device) {
+    IcpSetup su;
+    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su)) return s;
+    hipStream_t st = ctx->stream;
+    IcpState *dstate = (IcpState *)ctx->state.p;
+    uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns;
+    double *partials = (double *)ctx->partials.p;
+    const float4 *src = (const float4 *)ctx->src_index.pts.p;
+    const float4 *nrm = (const float4 *)ctx->tgt_index.normals.p;
+
+    // iterations are enqueued in chunks; the `done` flag of chunk c is polled (pinned copy +
+    // event) before chunk c+2 is enqueued, so the stream never drains while running.
+    constexpr size_t kChunk = 8;
+    const size_t nchunks = (max_iters + kChunk - 1) / kChunk;
+    int32_t *flags = (int32_t *)((char *)ctx->pinned + 1024);
+    const size_t max_flags = (ctx->pinned_cap - 1024) / sizeof(int32_t);
+    std::vector<hipEvent_t> evs;
+    size_t it = 0;
+    bool stopped = false;
+    for (size_t c = 0; c < nchunks && !stopped; ++c) {
+        if (c >= 2 && c - 2 < max_flags) {
+            TC_HIP_TRY(ctx, hipEventSynchronize(evs[c - 2]));
+            if (flags[c - 2]) { stopped = true; break; }
+        }
+        for (size_t k = 0; k < kChunk && it < max_iters; ++k, ++it)
+            launch_iteration(ctx, p2plane, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr, corr_pos, partials, true, true, true);
+        if (c < max_flags) {
+            flags[c] = 0;
+            TC_HIP_TRY(ctx, hipMemcpyAsync(&flags[c], &dstate->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        }
+        hipEvent_t ev;
+        TC_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        TC_HIP_TRY(ctx, hipEventRecord(ev, st));
+        evs.push_back(ev);
+    }
+    if (!p2plane) {
+        ProfScope ps(ctx, "icp_final_mse");
+        hipLaunchKernelGGL(icp_final_mse_kernel, dim3(su.l.nblocks), dim3(kIcpBlock), 0, st, su.tv, src, (uint32_t)ns, su.l.chunk,
+                           dstate, corr_pos, partials);
+    }
+    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, su.l.nblocks, p2plane ? 1 : 0);
+    IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
+    if (res->corr_target) {
+        TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, ns * sizeof(uint32_t),
+                                       corr_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    }
+    TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+    TC_HIP_TRY(ctx, hipGetLastError());
+    if (hs->status != TC_OK) {
+        return fail(ctx, (tc_status)hs->status,
+                    p2plane ? "Insufficient correspondences for point-to-plane ICP (need >= 6) or ill-conditioned system"
+                            : "Insufficient correspondences found");
+    }
+    for (int i = 0; i < 4; ++i) res->transformation[i] = hs->q[i];
+    for (int i = 0; i < 3; ++i) res->transformation[4 + i] = hs->t[i];
+    res->mse = hs->mse;
+    res->iterations = hs->converged ? hs->iterations : max_iters;
+    res->converged = hs->converged;
+    res->n_correspondences = hs->n_corr;
+    return TC_OK;
+}
+
+}  // namespace tc
+
+// ---- sharded building blocks (C ABI) ---------------------------------------------------------
+struct tc_icp_shard {
+    tc_context *ctx;
+    bool p2plane;
+    size_t ns;
+    tc::IcpSetup su;
+};
+
+extern "C" {
+
+tc_status tc_icp_shard_create(tc_context *ctx, int point_to_plane, const float *d_source_slice, size_t n_source_slice,
+                              const float *d_target, size_t n_target, const float *d_target_normals, size_t normal_stride,
+                              const float init[7], float max_correspondence_distance, float convergence_threshold,
+                              tc_icp_shard **out) {
+    if (!ctx || !out) return TC_INVALID_DATA;
+    if (n_source_slice == 0 || n_target == 0) return tc::fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");
+    tc_icp_shard *s = new tc_icp_shard{ctx, point_to_plane != 0, n_source_slice, {}};
+    tc_status rc = tc::icp_setup(ctx, s->p2plane, d_source_slice, n_source_slice, d_target, n_target, d_target_normals,
+                                 normal_stride, init, max_correspondence_distance, convergence_threshold, s->su);
+    if (rc != TC_OK) { delete s; return rc; }
+    *out = s;
+    return TC_OK;
+}
+
+double *tc_icp_shard_sums(tc_icp_shard *s) { return ((tc::IcpState *)s->ctx->state.p)->sums; }
+
+tc_status tc_icp_shard_reduce(tc_icp_shard *s) {
+    tc_context *ctx = s->ctx;
+    uint32_t *corr = (uint32_t *)ctx->corr.p;
+    tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
+                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr, corr + s->ns, (double *)ctx->partials.p,
+                         true, false, true);
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
+tc_status tc_icp_shard_apply(tc_icp_shard *s) {
+    tc_context *ctx = s->ctx;
+    uint32_t *corr = (uint32_t *)ctx->corr.p;
+    tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
+                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr, corr + s->ns, (double *)ctx->partials.p,
+                         false, true, false);
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
+tc_status tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *res) {
+    tc_context *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    tc::IcpState *dstate = (tc::IcpState *)ctx->state.p;
+    // point-to-point's post-loop mse recompute needs a cross-rank sum: the host driver does it
+    // (threecrate_amd.distributed); here the p2plane rule (mse = previous_mse) is applied.
+    hipLaunchKernelGGL(tc::icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, (const double *)ctx->partials.p, 0u, 1);
+    tc::IcpState *hs = (tc::IcpState *)((char *)ctx->pinned + 256);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(tc::IcpState), hipMemcpyDeviceToHost, st));
+    if (res->corr_target)
+        TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, ctx->corr.p, s->ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (hs->status != TC_OK) return tc::fail(ctx, (tc_status)hs->status, "ICP failed (insufficient correspondences / singular system)");
+    for (int i = 0; i < 4; ++i) res->transformation[i] = hs->q[i];
+    for (int i = 0; i < 3; ++i) res->transformation[4 + i] = hs->t[i];
+    res->mse = hs->mse;
+    res->iterations = hs->converged ? hs->iterations : max_iters;
+    res->converged = hs->converged;
+    res->n_correspondences = hs->n_corr;
+    return TC_OK;
+}
+
+void tc_icp_shard_destroy(tc_icp_shard *s) { delete s; }
+
+}  // extern "C"

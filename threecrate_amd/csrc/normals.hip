@@ -1,0 +1,320 @@
+// normals.hip -- HK2 normals_knn_pca: fused exact grid k-NN -> covariance -> 3x3 eigenvector
+// -> viewpoint orientation.  One lane per point, points visited in cell-sorted order.
+//
+// Reference semantics (threecrate-algorithms/src/normals.rs):
+//   neighbours = kNN(k+1) minus self, first k, ascending distance (:147-153); self appended
+//   last (:338-340); f32 centroid and covariance in that order (:164-177); eigenvector of the
+//   smallest eigenvalue (:181-194); renormalise (:197-202); flip towards viewpoint (:208-222).
+//
+// Device algorithm per point (no neighbour list ever reaches HBM):
+//   phase 1  scan the (2R+1)^3 cell block as (2R+1)^2 contiguous spans of the cell-sorted
+//            record array; keep the L smallest squared distances in a sorted REGISTER list.
+//            Insertion into the sorted list is branch-free: new[t] = med3(old[t-1], v, old[t]),
+//            one v_med3_f32 per slot, all slots independent.
+//   exactness tau = (k+1)-th smallest d2 is final iff tau <= (R*h + m)^2, m = distance from
+//            the query to the nearest face of its own cell (every unscanned point is at least
+//            R*h + m away).  Lanes that fail go to an overflow list handled by a second
+//            launch that grows R (keeps the main launch free of per-lane ring loops).
+//   phase 2  rescan, append the record positions with d2 <= tau to a per-lane LDS list
+//            (ties at tau: lowest cell-sorted position first), rank them against the register
+//            list -> neighbours in ascending-distance order, exactly the reference's order.
+//   epilogue f32 centroid / covariance in the reference's operation order (bit-identical to
+//            the oracle for identical neighbour sets), smallest eigenvector in f64
+//            (trigonometric estimate + monotone Newton polish + largest cross product).
+//
+// Algorithmic HBM bytes per point: 12 (query) + 12*k (neighbours) + 24 (out).
+#include "tc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace tc {
+
+struct NormalParams {
+    uint32_t k;             // k_neighbors
+    int      orient;        // consistent_orientation
+    float    vx, vy, vz;    // viewpoint
+    int      R0;            // ring count of the main launch
+    int      has_radius;
+    float    radius;
+};
+
+// ---- smallest-eigenvalue eigenvector of a symmetric 3x3 (f64) -------------------------------
+__device__ __forceinline__ void smallest_eigvec_sym3(double a00, double a01, double a02, double a11, double a12,
+                                                     double a22, double &nx, double &ny, double &nz) {
+    double scale = fmax(fmax(fmax(fabs(a00), fabs(a01)), fmax(fabs(a02), fabs(a11))), fmax(fabs(a12), fabs(a22)));
+    if (!(scale > 0.0)) { nx = 1.0; ny = 0.0; nz = 0.0; return; }   // zero matrix: reference's Q = I, column 0
+    double inv = 1.0 / scale;
+    a00 *= inv; a01 *= inv; a02 *= inv; a11 *= inv; a12 *= inv; a22 *= inv;
+    double q = (a00 + a11 + a22) * (1.0 / 3.0);
+    double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12);
+    double p = sqrt(p2 * (1.0 / 6.0));
+    if (!(p > 1e-150)) { nx = 1.0; ny = 0.0; nz = 0.0; return; }    // multiple of the identity
+    // f32 trigonometric estimate of the smallest root
+    double ip = 1.0 / p;
+    double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+    double detB = c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02);
+    float r = (float)(0.5 * detB);
+    r = fminf(1.0f, fmaxf(-1.0f, r));
+    float phi = acosf(r) * (1.0f / 3.0f);
+    double lam = q + 2.0 * p * (double)cosf(phi + 2.0943951023931953f);
+    // characteristic polynomial det(A - x I) = -x^3 + c2 x^2 - c1 x + c0
+    double c2 = a00 + a11 + a22;
+    double c1 = (a00 * a11 - a01 * a01) + (a00 * a22 - a02 * a02) + (a11 * a22 - a12 * a12);
+    double c0 = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
+    // start strictly below the smallest root: det(A - xI) is positive, decreasing and convex
+    // there, so Newton converges monotonically from the left.
+    lam -= 4e-6 * (p + fabs(q));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        double f = ((-lam + c2) * lam - c1) * lam + c0;
+        double df = (-3.0 * lam + 2.0 * c2) * lam - c1;
+        if (df < 0.0) lam -= f / df;
+    }
+    double m00 = a00 - lam, m11 = a11 - lam, m22 = a22 - lam;
+    // cross products of the rows of (A - lam I)
+    double x0 = a01 * a12 - a02 * m11, y0 = a02 * a01 - m00 * a12, z0 = m00 * m11 - a01 * a01;      // r0 x r1
+    double x1 = a01 * m22 - a02 * a12, y1 = a02 * a02 - m00 * m22, z1 = m00 * a12 - a01 * a02;      // r0 x r2
+    double x2 = m11 * m22 - a12 * a12, y2 = a12 * a02 - a01 * m22, z2 = a01 * a12 - m11 * a02;      // r1 x r2
+    double n0 = x0 * x0 + y0 * y0 + z0 * z0, n1 = x1 * x1 + y1 * y1 + z1 * z1, n2 = x2 * x2 + y2 * y2 + z2 * z2;
+    double bx = x0, by = y0, bz = z0, bn = n0;
+    if (n1 > bn) { bx = x1; by = y1; bz = z1; bn = n1; }
+    if (n2 > bn) { bx = x2; by = y2; bz = z2; bn = n2; }
+    if (bn > 1e-28) {
+        double s = 1.0 / sqrt(bn);
+        nx = bx * s; ny = by * s; nz = bz * s;
+        return;
+    }
+    // rank <= 1 (two smallest eigenvalues coincide): any unit vector orthogonal to the dominant row
+    double r0n = m00 * m00 + a01 * a01 + a02 * a02, r1n = a01 * a01 + m11 * m11 + a12 * a12,
+           r2n = a02 * a02 + a12 * a12 + m22 * m22;
+    double ux = m00, uy = a01, uz = a02, un = r0n;
+    if (r1n > un) { ux = a01; uy = m11; uz = a12; un = r1n; }
+    if (r2n > un) { ux = a02; uy = a12; uz = m22; un = r2n; }
+    if (!(un > 0.0)) { nx = 1.0; ny = 0.0; nz = 0.0; return; }
+    // pick the coordinate axis least aligned with u and orthogonalise
+    double ax = fabs(ux), ay = fabs(uy), az = fabs(uz);
+    double ex = (ax <= ay && ax <= az) ? 1.0 : 0.0, ey = (ex == 0.0 && ay <= az) ? 1.0 : 0.0;
+    double ez = (ex == 0.0 && ey == 0.0) ? 1.0 : 0.0;
+    double vx = uy * ez - uz * ey, vy = uz * ex - ux * ez, vz = ux * ey - uy * ex;
+    double s = 1.0 / sqrt(vx * vx + vy * vy + vz * vz);
+    nx = vx * s; ny = vy * s; nz = vz * s;
+}
+
+// ---- sorted register list -------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ void list_insert(float (&d)[L], float v) {
+#pragma unroll
+    for (int t = L - 1; t >= 1; --t) d[t] = __builtin_amdgcn_fmed3f(d[t - 1], v, d[t]);
+    d[0] = fminf(d[0], v);
+}
+
+// visit every record of the Chebyshev ring block [c-R, c+R]^3 (clamped to the grid)
+template <typename F>
+__device__ __forceinline__ void scan_block(const GridView &gv, int cx, int cy, int cz, int R, F &&f) {
+    const GridGeom &g = gv.g;
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
+    const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
+    const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
+    for (int z = z0; z <= z1; ++z) {
+        for (int y = y0; y <= y1; ++y) {
+            const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
+            const uint32_t s = gv.cell_start[row + x0], e = gv.cell_start[row + x1 + 1];
+            for (uint32_t j = s; j < e; ++j) f(j, gv.pts[j]);
+        }
+    }
+}
+
+template <int L, int BLOCK>
+__device__ __forceinline__ void normals_point(const GridView &gv, const NormalParams &prm, uint32_t p, bool grow,
+                                              uint32_t *__restrict__ overflow, float *__restrict__ out6,
+                                              uint32_t *ldsA, uint32_t *ldsB) {
+    const GridGeom &g = gv.g;
+    const float4 q = gv.pts[p];
+    const uint32_t orig = __float_as_uint(q.w);
+    const uint32_t K1 = prm.k + 1;
+    const int cx = cell_coord(q.x, g.minx, g.inv_h, g.gx);
+    const int cy = cell_coord(q.y, g.miny, g.inv_h, g.gy);
+    const int cz = cell_coord(q.z, g.minz, g.inv_h, g.gz);
+    // distance from the query to the nearest face of its own cell
+    float fx = (q.x - g.minx) * g.inv_h - (float)cx, fy = (q.y - g.miny) * g.inv_h - (float)cy,
+          fz = (q.z - g.minz) * g.inv_h - (float)cz;
+    float mf = fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz));
+    mf = fmaxf(mf, 0.0f);
+
+    float d[L];
+    float tau = INFINITY;
+    int R = prm.R0;
+    for (;;) {
+#pragma unroll
+        for (int t = 0; t < L; ++t) d[t] = INFINITY;
+        scan_block(gv, cx, cy, cz, R, [&](uint32_t, const float4 &c) {
+            list_insert<L>(d, d2_nc(c.x, c.y, c.z, q.x, q.y, q.z));
+        });
+        tau = d[0];
+#pragma unroll
+        for (int t = 1; t < L; ++t) tau = ((uint32_t)t == prm.k) ? d[t] : tau;
+        const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
+                            (cz - R <= 0) && (cz + R >= g.gz - 1);
+        const float bound = ((float)R + mf - 2e-3f) * g.h;
+        if (covers || tau <= bound * bound) break;
+        if (!grow) {
+            uint32_t slot = atomicAdd(&overflow[0], 1u);
+            overflow[1 + slot] = p;
+            return;
+        }
+        ++R;
+    }
+
+    // phase 2: collect the positions of the K1 nearest records
+    uint32_t n_lt = 0;
+#pragma unroll
+    for (int t = 0; t < L; ++t) n_lt += (d[t] < tau) ? 1u : 0u;
+    const uint32_t quota = K1 - min(n_lt, K1);
+    uint32_t cnt = 0, ties = 0;
+    scan_block(gv, cx, cy, cz, R, [&](uint32_t j, const float4 &c) {
+        float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+        bool take = v < tau;
+        if (!take && v == tau && ties < quota) { take = true; ++ties; }
+        if (take && cnt < K1) { ldsA[cnt * BLOCK] = j; ++cnt; }
+    });
+
+    // rank -> ascending-distance order (ties keep scan order)
+    unsigned long long taken_lo = 0ull, taken_hi = 0ull;   // bitset over ranks 0..127
+    auto is_taken = [&](uint32_t r) { return r < 64 ? ((taken_lo >> r) & 1ull) : ((taken_hi >> (r - 64)) & 1ull); };
+    int self_r = -1;
+    for (uint32_t e = 0; e < cnt; ++e) {
+        const uint32_t j = ldsA[e * BLOCK];
+        const float4 c = gv.pts[j];
+        const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+        uint32_t r = 0;
+#pragma unroll
+        for (int t = 0; t < L; ++t) r += (d[t] < v) ? 1u : 0u;
+        while (is_taken(r)) ++r;
+        if (r < 64) taken_lo |= 1ull << r; else taken_hi |= 1ull << (r - 64);
+        ldsB[r * BLOCK] = j;
+        if (j == p) self_r = (int)r;
+    }
+    // normals.rs:147-153: drop self from the k+1 list (or the last entry when self is not in it)
+    const int drop_r = (self_r >= 0) ? self_r : (int)cnt - 1;
+    const uint32_t npts = cnt;   // (cnt - 1) neighbours + self
+    float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
+    if (npts >= 3) {
+        // centroid (normals.rs:165-169): sequential f32 adds, neighbours ascending then self
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (uint32_t r = 0; r < cnt; ++r) {
+            if ((int)r == drop_r) continue;
+            const float4 c = gv.pts[ldsB[r * BLOCK]];
+            sx += c.x; sy += c.y; sz += c.z;
+        }
+        sx += q.x; sy += q.y; sz += q.z;
+        const float nf = (float)npts;
+        const float mx = sx / nf, my = sy / nf, mz = sz / nf;
+        // covariance (normals.rs:172-177)
+        float cxx = 0.0f, cxy = 0.0f, cxz = 0.0f, cyy = 0.0f, cyz = 0.0f, czz = 0.0f;
+        for (uint32_t r = 0; r < cnt; ++r) {
+            if ((int)r == drop_r) continue;
+            const float4 c = gv.pts[ldsB[r * BLOCK]];
+            const float dx = c.x - mx, dy = c.y - my, dz = c.z - mz;
+            cxx += dx * dx; cxy += dx * dy; cxz += dx * dz; cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
+        }
+        {
+            const float dx = q.x - mx, dy = q.y - my, dz = q.z - mz;
+            cxx += dx * dx; cxy += dx * dy; cxz += dx * dz; cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
+        }
+        cxx /= nf; cxy /= nf; cxz /= nf; cyy /= nf; cyz /= nf; czz /= nf;
+        double ex, ey, ez;
+        smallest_eigvec_sym3((double)cxx, (double)cxy, (double)cxz, (double)cyy, (double)cyz, (double)czz, ex, ey, ez);
+        float vx = (float)ex, vy = (float)ey, vz = (float)ez;
+        const float mag = sqrtf(vx * vx + vy * vy + vz * vz);          // normals.rs:197-202
+        if (mag > 1e-6f) { nrm_x = vx / mag; nrm_y = vy / mag; nrm_z = vz / mag; }
+    }
+    if (prm.orient) {   // normals.rs:208-222
+        const float tx = prm.vx - q.x, ty = prm.vy - q.y, tz = prm.vz - q.z;
+        const float tn = sqrtf(tx * tx + ty * ty + tz * tz);
+        const float ux = tx / tn, uy = ty / tn, uz = tz / tn;
+        const float dp = nrm_x * ux + nrm_y * uy + nrm_z * uz;
+        if (dp < 0.0f) { nrm_x = -nrm_x; nrm_y = -nrm_y; nrm_z = -nrm_z; }
+    }
+    float *o = out6 + 6 * (size_t)orig;
+    o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = nrm_x; o[4] = nrm_y; o[5] = nrm_z;
+}
+
+// XCD-aware block remap: hardware deals blocks round-robin over the 8 XCDs, so give each XCD
+// one contiguous eighth of the cell-sorted array (its L2 then holds a contiguous slab + halo).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
+    const uint32_t per = (nb + 7) / 8;
+    const uint32_t lb = (b & 7u) * per + (b >> 3);
+    return lb;
+}
+
+template <int L, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, NormalParams prm,
+                                                                uint32_t *__restrict__ overflow,
+                                                                float *__restrict__ out6) {
+    __shared__ uint32_t ldsA[L * BLOCK];
+    __shared__ uint32_t ldsB[L * BLOCK];
+    const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t p = lb * BLOCK + threadIdx.x;
+    if (p >= gv.g.n) return;
+    normals_point<L, BLOCK>(gv, prm, p, false, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+}
+
+template <int L, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) normals_overflow_kernel(GridView gv, NormalParams prm,
+                                                                 uint32_t *__restrict__ overflow,
+                                                                 float *__restrict__ out6) {
+    __shared__ uint32_t ldsA[L * BLOCK];
+    __shared__ uint32_t ldsB[L * BLOCK];
+    const uint32_t count = overflow[0];
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        NormalParams p2 = prm;
+        p2.R0 = prm.R0 + 1;
+        normals_point<L, BLOCK>(gv, p2, overflow[1 + i], true, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+    }
+}
+
+template <int L, int BLOCK>
+static void launch_variant(hipStream_t st, const GridView &gv, const NormalParams &prm, uint32_t *overflow, float *out6,
+                           tc_context *ctx) {
+    const uint32_t n = gv.g.n;
+    uint32_t nb = (n + BLOCK - 1) / BLOCK;
+    nb = (nb + 7) / 8 * 8;   // xcd_remap needs a multiple of 8
+    {
+        ProfScope ps(ctx, "normals_knn_pca");
+        hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
+    }
+    {
+        ProfScope ps(ctx, "normals_overflow");
+        hipLaunchKernelGGL((normals_overflow_kernel<L, BLOCK>), dim3(256), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
+    }
+}
+
+tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg, const float vp[3],
+                         float *d_out6) {
+    const size_t n = ix.geom.n;
+    if (cfg.has_radius) return fail(ctx, TC_UNSUPPORTED, "radius-based normal estimation is not built yet");
+    if (cfg.k_neighbors + 1 > 65) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 64 is not supported by the HIP backend");
+    if (tc_status s = ensure(ctx, ctx->overflow, (n + 1) * sizeof(uint32_t))) return s;
+    TC_HIP_TRY(ctx, hipMemsetAsync(ctx->overflow.p, 0, sizeof(uint32_t), ctx->stream));
+    NormalParams prm;
+    prm.k = (uint32_t)cfg.k_neighbors;
+    prm.orient = cfg.consistent_orientation ? 1 : 0;
+    prm.vx = vp[0]; prm.vy = vp[1]; prm.vz = vp[2];
+    prm.R0 = 2;
+    prm.has_radius = 0; prm.radius = 0.0f;
+    const GridView gv = view_of(ix);
+    uint32_t *ov = (uint32_t *)ctx->overflow.p;
+    const uint32_t K1 = prm.k + 1;
+    if (K1 <= 9)       launch_variant<9, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
+    else if (K1 <= 11) launch_variant<11, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
+    else if (K1 <= 17) launch_variant<17, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
+    else if (K1 <= 21) launch_variant<21, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
+    else if (K1 <= 33) launch_variant<33, 128>(ctx->stream, gv, prm, ov, d_out6, ctx);
+    else               launch_variant<65, 64>(ctx->stream, gv, prm, ov, d_out6, ctx);
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
+}  // namespace tc

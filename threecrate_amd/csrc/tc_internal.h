@@ -1,0 +1,154 @@
+// tc_internal.h -- shared host/device declarations of libthreecrate_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/threecrate_hip.h"
+
+namespace tc {
+
+// ------------------------------------------------------------------------------------------
+// Uniform-grid spatial index over one cloud (replaces KdTree, nearest_neighbor.rs:29-33).
+// Cells are ordered x-fastest, so a run of cells along x is ONE contiguous range of the
+// cell-sorted point array: a (2R+1)^3 neighbourhood is (2R+1)^2 contiguous spans.
+// ------------------------------------------------------------------------------------------
+struct GridGeom {
+    float minx, miny, minz;     // bbox min (cell origin)
+    float maxx, maxy, maxz;     // bbox max
+    float h, inv_h;             // cell edge and 1/h
+    int   gx, gy, gz;           // cells per axis
+    uint32_t ncell;             // gx*gy*gz
+    uint32_t n;                 // points indexed
+    float cx, cy, cz;           // bbox centre (shift origin for the p2p Kabsch sums)
+};
+
+struct GridView {
+    GridGeom g;
+    const float4   *pts;        // cell-sorted points: x, y, z, w = bit pattern of the original index
+    const uint32_t *cell_start; // ncell + 1 exclusive prefix sums
+};
+
+// device-side ICP state (one per running registration); mirrors the loop variables of
+// registration.rs:278-340 / :533-593.
+struct IcpState {
+    float    q[4];          // current_transform rotation (i j k w)
+    float    t[3];          // current_transform translation
+    float    prev_mse;      // previous_mse (starts +inf)
+    float    mse;           // mse of the last executed iteration
+    uint32_t iterations;    // executed iterations
+    int32_t  converged;
+    int32_t  status;        // tc_status
+    int32_t  done;          // converged or failed: later launches exit immediately
+    uint32_t n_corr;        // valid pairs of the last executed iteration
+    float    conv_thr;
+    float    max_dist;      // < 0 : none
+    double   sums[TC_ICP_SUMS_STRIDE];   // packed, fully reduced sums of the current iteration
+};
+
+constexpr int kIcpBlock = 256;
+constexpr int kMaxPartialBlocks = 2048;
+
+// ---- device helpers -----------------------------------------------------------------------
+#if defined(__HIPCC__)
+__device__ __forceinline__ float d2_nc(float ax, float ay, float az, float bx, float by, float bz) {
+    // nearest_neighbor.rs:162-167: (a - b) per component, dx*dx + dy*dy + dz*dz, left to right,
+    // NO fma contraction (the library is built with -ffp-contract=off).
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return dx * dx + dy * dy + dz * dz;
+}
+__device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int g) {
+    float f = (v - mn) * inv_h;
+    int c = (f >= 0.0f) ? (int)f : 0;          // NaN -> 0
+    return c < g ? c : g - 1;
+}
+#endif
+
+// ---- host side ----------------------------------------------------------------------------
+struct DevBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+};
+
+struct KernelTimer {
+    std::string name;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    uint64_t launches = 0;
+    double   total_ms = 0.0;
+};
+
+// One indexed cloud living in device memory.
+struct DeviceIndex {
+    GridGeom geom{};
+    DevBuf pts;         // float4 * n   (cell-sorted, w = original index bits)
+    DevBuf cell_start;  // u32 * (ncell+1)
+    DevBuf normals;     // float4 * n   (cell-sorted target normals; optional)
+    DevBuf cell_of;     // u32 * n      (scratch: cell id per original point)
+    DevBuf slot;        // u32 * n      (scratch: atomic scatter order)
+    DevBuf fill;        // u32 * ncell  (scratch: histogram / fill counters)
+    DevBuf blocksum;    // u32 * nblocks (scan scratch)
+};
+
+}  // namespace tc
+
+struct tc_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string last_error;
+    bool profiling = false;
+    std::vector<tc::KernelTimer> timers;
+    std::vector<hipEvent_t> event_pool;
+
+    // persistent (grow-only) device buffers, reused across calls
+    tc::DeviceIndex tgt_index;      // target / normals cloud
+    tc::DeviceIndex src_index;      // source ordered by target cell (ICP)
+    tc::DevBuf in_a, in_b, in_c;    // staged host inputs
+    tc::DevBuf out_a;               // staged outputs
+    tc::DevBuf bbox;                // 6 x u32 (ordered-int encoded floats)
+    tc::DevBuf state;               // IcpState
+    tc::DevBuf partials;            // double * kMaxPartialBlocks * TC_ICP_SUMS_STRIDE
+    tc::DevBuf corr;                // u32 * n_source
+    tc::DevBuf overflow;            // u32 * (n + 1)  (normals ring-overflow list, [0] = count)
+    void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
+    size_t pinned_cap = 0;
+};
+
+namespace tc {
+
+// error plumbing
+tc_status fail(tc_context *ctx, tc_status st, const std::string &msg);
+#define TC_HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return tc::fail((ctx), TC_GPU, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes);
+
+// profiling scope: records hipEvents around one kernel launch on ctx->stream
+struct ProfScope {
+    tc_context *ctx; int idx = -1; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(tc_context *c, const char *name);
+    ~ProfScope();
+};
+
+// grid.hip
+tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n,
+                      float cell_factor, const GridGeom *reuse_geom, const IcpState *d_state_transform);
+tc_status gather_normals(tc_context *ctx, DeviceIndex &ix, const float *d_normals, size_t stride);
+GridView view_of(const DeviceIndex &ix);
+
+// normals.hip
+tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg,
+                         const float vp[3], float *d_out6);
+
+// icp.hip
+tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
+                  const float *d_nrm, size_t nstride, const float init[7], size_t max_iters,
+                  float max_dist, float conv_thr, tc_icp_result *res, bool corr_on_device);
+
+}  // namespace tc
