@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X normals + ICP backend (BASELINE.json config [1]).
+
+One "step" = one pass of the hot path over one synthetic 1M-point scan pair:
+    estimate_normals(target, k=16)  +  50-iteration point-to-plane ICP (convergence_threshold 0.0,
+    so exactly 50 iterations run: SURVEY.md 7/H4) of source -> target,
+with all inputs already resident in HBM when the timed region starts.  With --gpus N every rank
+runs its own independent pair (BASELINE config [2], weak scaling, no data-path collective);
+the only collective is the max-over-ranks of the wall time.
+
+Prints ONE JSON line (rank 0).  `value` = whole-job ICP iterations / second =
+50 * steps * n_gpus / wall, where wall covers normals + ICP of every step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_POINTS = 1_000_000
+K_NORMALS = 16
+ICP_ITERS = 50
+ALG_BYTES_ICP = 40          # B / source point / iteration: 12 src + 12 tgt + 12 normal + 4 index
+ALG_BYTES_NORMALS = 12 + 12 * K_NORMALS + 24   # = 228 B / point
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(n_points, tgt, src):
+    """The oracle (CPU restatement of threecrate-algorithms, kind="port") timed on this box's host
+    cores on a bounded sample of the same workload: full k=16 normals on the 1M cloud + the kd-tree
+    build + 3 of the 50 p2plane iterations, extrapolated to the 50-iteration job."""
+    from oracle import oracle as O
+    cores = O.num_threads()
+    t0 = time.perf_counter()
+    nrm = O.estimate_normals(tgt, K_NORMALS)
+    t_norm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.icp_point_to_plane_detailed(src, tgt, nrm[:, 3:], None, 1, None, 0.0)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.icp_point_to_plane_detailed(src, tgt, nrm[:, 3:], None, 4, None, 0.0)
+    t4 = time.perf_counter() - t0
+    t_iter = max((t4 - t1) / 3.0, 1e-9)
+    t_build = max(t1 - t_iter, 0.0)
+    job = t_norm + t_build + ICP_ITERS * t_iter
+    return {
+        "value": ICP_ITERS / job, "unit": "ICP it/s (whole job: normals + 50 it)", "cores": cores, "kind": "port",
+        "sample": f"oracle on {n_points} pts: full k={K_NORMALS} normals ({t_norm:.2f} s) + kd-tree build ({t_build:.2f} s) + "
+                  f"3 timed p2plane iterations ({t_iter:.3f} s/it) extrapolated to {ICP_ITERS}",
+        "normals_mpts_per_s": n_points / t_norm / 1e6,
+        "icp_it_per_s_steady": 1.0 / t_iter,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import threecrate_amd as tc
+    from threecrate_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n = args.points
+    # every rank owns an independent scan pair (seed differs per rank)
+    src_h, tgt_h, _ = synth.registration_pair(n, seed=1 + rank, transform=synth.harness_transform())
+    src, tgt = torch.from_numpy(src_h).to(dev), torch.from_numpy(tgt_h).to(dev)
+    ctx = tc.GpuContext(local_rank)
+    ctx.profile_enable(True)
+
+    def step():
+        t0 = time.perf_counter()
+        nrm = ctx.estimate_normals(tgt, K_NORMALS)                       # (n, 6) NormalPoint3f, stays in HBM
+        t1 = time.perf_counter()
+        r = ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, ICP_ITERS, None, 0.0, correspondences=False)
+        t2 = time.perf_counter()
+        assert r.iterations == ICP_ITERS
+        return t1 - t0, t2 - t1, r
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_reset()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_start = time.perf_counter()
+    tn = ti = 0.0
+    last = None
+    for _ in range(args.steps):
+        a, b, last = step()
+        tn += a
+        ti += b
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t_start
+    stats = ctx.profile_read()
+    if world > 1:
+        tw = torch.tensor([wall, tn, ti], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall, tn, ti = [float(v) for v in tw.tolist()]
+
+    if rank == 0:
+        k = "icp_correspond_reduce_p2plane"
+        launches, total_ms = stats.get(k, (0, 0.0))
+        avg_s = (total_ms / max(launches, 1)) * 1e-3
+        achieved = ALG_BYTES_ICP * n / max(avg_s, 1e-12) / 1e9
+        kn_l, kn_ms = stats.get("normals_knn_pca", (0, 0.0))
+        ko_l, ko_ms = stats.get("normals_overflow", (0, 0.0))
+        n_avg_s = ((kn_ms + ko_ms) / max(kn_l, 1)) * 1e-3
+        out = {
+            "metric": "ICP iterations/sec (whole job: k=16 normals + 50-iter point-to-plane ICP per 1M-pt pair)",
+            "value": ICP_ITERS * args.steps * world / wall,
+            "unit": "it/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n}-pt uniform-random cloud, k={K_NORMALS} normals + {ICP_ITERS}-iter point-to-plane ICP "
+                                   "(BASELINE configs[1]; one independent pair per GPU)",
+                       "points": n, "k": K_NORMALS, "icp_iterations": ICP_ITERS, "parallelism": f"pairs{world}"},
+            "normals_mpts_per_s": n * args.steps * world / tn / 1e6,
+            "icp_only_it_per_s": ICP_ITERS * args.steps * world / ti,
+            "roofline": {"bound": "hbm", "kernel": k, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": ALG_BYTES_ICP * n, "avg_launch_us": avg_s * 1e6, "launches": launches},
+            "roofline_normals": {"bound": "hbm", "kernel": "normals_knn_pca(+overflow)",
+                                 "achieved": ALG_BYTES_NORMALS * n / max(n_avg_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": ALG_BYTES_NORMALS * n / max(n_avg_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                                 "alg_bytes_per_launch": ALG_BYTES_NORMALS * n, "avg_launch_us": n_avg_s * 1e6},
+            "kernels_us_avg": {kk: round(1e3 * ms / max(c, 1), 2) for kk, (c, ms) in stats.items()},
+            "final_mse": last.mse,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, tgt_h, src_h)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,25 @@ EXPORTS = [
 _lib = None
 
 
+def _preload_hip_runtime():
+    """If PyTorch-ROCm is installed it bundles its own libamdhip64.so (SONAME libamdhip64.so.7).
+    Two HIP runtimes in one process cannot both open the GPU, so bind to torch's copy first:
+    our NEEDED libamdhip64.so.7 then resolves to it and torch tensors / streams can be handed
+    across the C ABI.  Without torch the system ROCm runtime (/opt/rocm/lib) is used."""
+    if os.environ.get("TC_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load the HIP library; raises (never falls back) when it is absent."""
     global _lib
@@ -63,6 +82,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  threecrate_amd has no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, f32p, sz, f, i = C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_int
     ctxpp = C.POINTER(C.c_void_p)

@@ -17,18 +17,6 @@
 
 namespace tc {
 
-// ---- ordered-int encoding of floats for atomicMin / atomicMax ------------------------------
-__device__ __forceinline__ uint32_t f2ord(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-static inline float ord2f(uint32_t u) {
-    uint32_t v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
-    float f;
-    std::memcpy(&f, &v, 4);
-    return f;
-}
-
 __device__ __forceinline__ void isometry_apply(const float q[4], const float t[3], float x, float y, float z,
                                                float &ox, float &oy, float &oz) {
     // nalgebra UnitQuaternion * Point3: t2 = 2 (qv x p); p' = t2*w + qv x t2 + p; then + translation
@@ -43,8 +31,13 @@ __device__ __forceinline__ void isometry_apply(const float q[4], const float t[3
     oz = ((tz * q[3] + cz) + z) + t[2];
 }
 
-__global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, uint32_t *__restrict__ box) {
+// per-block bounding box partials (6 floats per block); the host folds the <= 256 rows
+// (min / max are order independent, so the result equals the reference's sequential fold).
+constexpr int kBboxBlocks = 256;
+__global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, float *__restrict__ box) {
+    __shared__ float sm[4][6];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    // each thread reads whole points; consecutive lanes read consecutive 12-B records
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
         mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);   // fminf ignores NaN
@@ -60,10 +53,13 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
     }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            atomicMin(&box[c], f2ord(mn[c]));
-            atomicMax(&box[3 + c], f2ord(mx[c]));
-        }
+        for (int c = 0; c < 3; ++c) { sm[threadIdx.x >> 6][c] = mn[c]; sm[threadIdx.x >> 6][3 + c] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
+        box[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
 
@@ -268,18 +264,18 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         ix.geom = *reuse_geom;
         ix.geom.n = n32;
     } else {
-        if (tc_status s = ensure(ctx, ctx->bbox, 6 * sizeof(uint32_t))) return s;
-        TC_HIP_TRY(ctx, hipMemsetAsync(ctx->bbox.p, 0xFF, 3 * sizeof(uint32_t), st));
-        TC_HIP_TRY(ctx, hipMemsetAsync((uint32_t *)ctx->bbox.p + 3, 0x00, 3 * sizeof(uint32_t), st));
+        const int bb = std::min(nb, kBboxBlocks);
+        if (tc_status s = ensure(ctx, ctx->bbox, (size_t)kBboxBlocks * 6 * sizeof(float))) return s;
         {
             ProfScope ps(ctx, "bbox");
-            hipLaunchKernelGGL(bbox_kernel, dim3(std::min(nb, 1024)), dim3(256), 0, st, d_xyz, n32, (uint32_t *)ctx->bbox.p);
+            hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, n32, (float *)ctx->bbox.p);
         }
-        uint32_t *hb = (uint32_t *)ctx->pinned;
-        TC_HIP_TRY(ctx, hipMemcpyAsync(hb, ctx->bbox.p, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        float *hb = (float *)((char *)ctx->pinned + 2048);
+        TC_HIP_TRY(ctx, hipMemcpyAsync(hb, ctx->bbox.p, (size_t)bb * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
         TC_HIP_TRY(ctx, hipStreamSynchronize(st));
-        float mn[3], mx[3];
-        for (int c = 0; c < 3; ++c) { mn[c] = ord2f(hb[c]); mx[c] = ord2f(hb[3 + c]); }
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int b = 0; b < bb; ++b)
+            for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hb[6 * b + c]); mx[c] = std::fmax(mx[c], hb[6 * b + 3 + c]); }
         for (int c = 0; c < 3; ++c)
             if (!(mn[c] <= mx[c]) || !std::isfinite(mn[c]) || !std::isfinite(mx[c])) { mn[c] = 0.0f; mx[c] = 0.0f; }
         derive_geom(ix.geom, mn, mx, n, cell_factor);

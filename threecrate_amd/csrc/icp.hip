@@ -376,20 +376,29 @@ __device__ void finish_iteration(IcpState *st, float mse, uint32_t n) {
 }
 
 template <bool P2PLANE>
-__global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
-                                                          IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply) {
+__global__ void __launch_bounds__(1024) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
+                                                           IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply) {
     if (st->done) return;
-    __shared__ double sm[8][TC_ICP_SUMS_STRIDE];
+    __shared__ double sm[32][TC_ICP_SUMS_STRIDE];
     if (do_sum) {
+        // 32 row groups x 32 columns; every group folds its rows in a fixed order with
+        // 4 independent loads in flight, then column t folds the 32 groups in order.
         const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-        double s = 0.0;
-        for (uint32_t b = grp; b < nblocks; b += 8) s += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
-        sm[grp][col] = s;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        uint32_t b = grp;
+        for (; b + 96 < nblocks; b += 128) {
+            s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
+            s1 += partials[(size_t)(b + 32) * TC_ICP_SUMS_STRIDE + col];
+            s2 += partials[(size_t)(b + 64) * TC_ICP_SUMS_STRIDE + col];
+            s3 += partials[(size_t)(b + 96) * TC_ICP_SUMS_STRIDE + col];
+        }
+        for (; b < nblocks; b += 32) s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
+        sm[grp][col] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
             double tot = 0.0;
 #pragma unroll
-            for (int gi = 0; gi < 8; ++gi) tot += sm[gi][threadIdx.x];
+            for (int gi = 0; gi < 32; ++gi) tot += sm[gi][threadIdx.x];
             st->sums[threadIdx.x] = tot;
         }
         __syncthreads();
@@ -479,10 +488,10 @@ static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, 
     if (do_sum || do_apply) {
         ProfScope ps(ctx, "icp_finalize");
         if (p2plane)
-            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(256), 0, s, partials, l.nblocks, st, tv.g, do_sum ? 1 : 0,
+            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(1024), 0, s, partials, l.nblocks, st, tv.g, do_sum ? 1 : 0,
                                do_apply ? 1 : 0);
         else
-            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(256), 0, s, partials, l.nblocks, st, tv.g, do_sum ? 1 : 0,
+            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(1024), 0, s, partials, l.nblocks, st, tv.g, do_sum ? 1 : 0,
                                do_apply ? 1 : 0);
     }
 }

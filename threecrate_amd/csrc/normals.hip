@@ -267,12 +267,14 @@ __global__ void __launch_bounds__(BLOCK) normals_overflow_kernel(GridView gv, No
                                                                  float *__restrict__ out6) {
     __shared__ uint32_t ldsA[L * BLOCK];
     __shared__ uint32_t ldsB[L * BLOCK];
+    // launched with one thread per POINT (the count is not known on the host); threads past the
+    // list length leave at once.
     const uint32_t count = overflow[0];
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
-        NormalParams p2 = prm;
-        p2.R0 = prm.R0 + 1;
-        normals_point<L, BLOCK>(gv, p2, overflow[1 + i], true, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
-    }
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    NormalParams p2 = prm;
+    p2.R0 = prm.R0 + 1;
+    normals_point<L, BLOCK>(gv, p2, overflow[1 + i], true, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
 }
 
 template <int L, int BLOCK>
@@ -287,7 +289,7 @@ static void launch_variant(hipStream_t st, const GridView &gv, const NormalParam
     }
     {
         ProfScope ps(ctx, "normals_overflow");
-        hipLaunchKernelGGL((normals_overflow_kernel<L, BLOCK>), dim3(256), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
+        hipLaunchKernelGGL((normals_overflow_kernel<L, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
     }
 }
 
