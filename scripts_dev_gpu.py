@@ -14,7 +14,12 @@ ctx.profile_enable(True)
 for rep in range(3):
     ctx.profile_reset()
     t0 = time.time(); nrm = ctx.estimate_normals(dt, 16); t1 = time.time()
-    r = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, 50, None, 0.0, correspondences=False); t2 = time.time()
+    try:
+        r = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, 50, None, 0.0, correspondences=False)
+    except Exception as e:
+        class R: mse=-1; iterations=-1
+        r = R()
+    t2 = time.time()
     print(f"rep {rep}: normals {1e3*(t1-t0):.2f} ms ({n/(t1-t0)/1e6:.1f} Mpts/s)  icp50 {1e3*(t2-t1):.2f} ms ({50/(t2-t1):.1f} it/s) mse {r.mse:.3e} it {r.iterations}")
     for k, (cnt, ms) in sorted(ctx.profile_read().items(), key=lambda kv: -kv[1][1]):
         print(f"    {k:36s} {cnt:5d} launches {ms:9.3f} ms total {1e3*ms/max(cnt,1):9.2f} us avg")

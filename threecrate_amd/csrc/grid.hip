@@ -1,7 +1,7 @@
 // grid.hip -- device-built uniform-grid index (replaces KdTree::new, nearest_neighbor.rs:37-159).
 //
 // Pipeline (all on ctx->stream):
-//   bbox_kernel      : min/max of the cloud (order-independent atomics on ordered-int floats)
+//   bbox_kernel      : per-block min/max partials, folded on the host (order independent)
 //   cell_hist_kernel : cell id per point + histogram
 //   scan_*           : exclusive prefix sum of the histogram -> cell_start
 //   scatter_kernel   : counting-sort scatter (atomic slot order, not yet deterministic)
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
 // cell id per point (+ histogram).  With `st` != null the point is first moved by the
 // isometry in *st (ICP source ordering by target cell); the stored record keeps the raw point.
 __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g,
-                                                       const IcpState *__restrict__ st,
+                                                       const IcpState *__restrict__ st, TileGeom tg, int tile_major,
                                                        uint32_t *__restrict__ cell_of, uint32_t *__restrict__ hist) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict_
     int ix = cell_coord(x, g.minx, g.inv_h, g.gx);
     int iy = cell_coord(y, g.miny, g.inv_h, g.gy);
     int iz = cell_coord(z, g.minz, g.inv_h, g.gz);
-    uint32_t c = ((uint32_t)iz * g.gy + iy) * g.gx + ix;
+    uint32_t c = tile_major ? tile_major_id(tg, ix, iy, iz) : ((uint32_t)iz * g.gy + iy) * g.gx + ix;
     cell_of[i] = c;
     atomicAdd(&hist[c], 1u);
 }
@@ -253,8 +253,17 @@ static void derive_geom(GridGeom &g, const float mn[3], const float mx[3], size_
     g.n = (uint32_t)n;
 }
 
+TileGeom make_tiles(const GridGeom &g, int tx, int ty, int tz) {
+    TileGeom t;
+    t.tx = std::max(tx, 1); t.ty = std::max(ty, 1); t.tz = std::max(tz, 1);
+    t.ntx = (g.gx + t.tx - 1) / t.tx; t.nty = (g.gy + t.ty - 1) / t.ty; t.ntz = (g.gz + t.tz - 1) / t.tz;
+    t.cpt = (uint32_t)(t.tx * t.ty * t.tz);
+    t.ntiles = (uint32_t)t.ntx * (uint32_t)t.nty * (uint32_t)t.ntz;
+    return t;
+}
+
 tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n, float cell_factor,
-                      const GridGeom *reuse_geom, const IcpState *d_state_transform) {
+                      const GridGeom *reuse_geom, const IcpState *d_state_transform, const TileGeom *tile_major) {
     if (n == 0 || n >= 0xFFFFFFF0ull) return fail(ctx, TC_INVALID_DATA, "build_index: bad point count");
     hipStream_t st = ctx->stream;
     const uint32_t n32 = (uint32_t)n;
@@ -281,30 +290,39 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         derive_geom(ix.geom, mn, mx, n, cell_factor);
     }
     const GridGeom g = ix.geom;
+    TileGeom tg{};
+    uint32_t nkeys = g.ncell;          // number of counting-sort keys
+    if (tile_major) {
+        tg = *tile_major;
+        ix.tile = tg;
+        const uint64_t nk = (uint64_t)tg.ntiles * tg.cpt;
+        if (nk >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "tile-major key space too large");
+        nkeys = (uint32_t)nk;
+    }
 
     if (tc_status s = ensure(ctx, ix.pts, n * sizeof(float4))) return s;
     if (tc_status s = ensure(ctx, ix.cell_of, n * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, ix.slot, n * sizeof(uint32_t))) return s;
-    if (tc_status s = ensure(ctx, ix.fill, (size_t)g.ncell * sizeof(uint32_t))) return s;
-    if (tc_status s = ensure(ctx, ix.cell_start, ((size_t)g.ncell + 1) * sizeof(uint32_t))) return s;
-    const uint32_t nscan = (g.ncell + kScanTile - 1) / kScanTile;
+    if (tc_status s = ensure(ctx, ix.fill, (size_t)nkeys * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.cell_start, ((size_t)nkeys + 1) * sizeof(uint32_t))) return s;
+    const uint32_t nscan = (nkeys + kScanTile - 1) / kScanTile;
     if (tc_status s = ensure(ctx, ix.blocksum, (size_t)nscan * sizeof(uint32_t))) return s;
 
-    TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)g.ncell * sizeof(uint32_t), st));
+    TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)nkeys * sizeof(uint32_t), st));
     {
         ProfScope ps(ctx, "cell_hist");
-        hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform,
+        hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0,
                            (uint32_t *)ix.cell_of.p, (uint32_t *)ix.fill.p);
     }
     {
         ProfScope ps(ctx, "cell_scan");
-        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nscan), dim3(kScanBlock), 0, st, (const uint32_t *)ix.fill.p, g.ncell,
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nscan), dim3(kScanBlock), 0, st, (const uint32_t *)ix.fill.p, nkeys,
                            (uint32_t *)ix.blocksum.p);
         hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, (uint32_t *)ix.blocksum.p, nscan);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, (const uint32_t *)ix.fill.p, g.ncell,
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, (const uint32_t *)ix.fill.p, nkeys,
                            (const uint32_t *)ix.blocksum.p, (uint32_t *)ix.cell_start.p);
     }
-    TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)g.ncell * sizeof(uint32_t), st));
+    TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)nkeys * sizeof(uint32_t), st));
     {
         ProfScope ps(ctx, "cell_scatter");
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)ix.cell_of.p, n32,

@@ -25,6 +25,17 @@ struct GridGeom {
     float cx, cy, cz;           // bbox centre (shift origin for the p2p Kabsch sums)
 };
 
+// Tiles of TX x TY x TZ cells.  A workgroup owns one tile of QUERIES and stages the tile +
+// halo region of the cell-sorted target records into LDS.  The ICP source cloud is sorted by
+// the tile-major id (tile index * cells_per_tile + x-fastest local cell) so that the queries of
+// one tile are one contiguous range.
+struct TileGeom {
+    int tx, ty, tz;             // cells per tile along each axis
+    int ntx, nty, ntz;          // tiles per axis (grid dims rounded up)
+    uint32_t cpt;               // cells per tile
+    uint32_t ntiles;
+};
+
 struct GridView {
     GridGeom g;
     const float4   *pts;        // cell-sorted points: x, y, z, w = bit pattern of the original index
@@ -53,6 +64,12 @@ constexpr int kMaxPartialBlocks = 2048;
 
 // ---- device helpers -----------------------------------------------------------------------
 #if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t tile_major_id(const TileGeom &t, int cx, int cy, int cz) {
+    const int ax = cx / t.tx, ay = cy / t.ty, az = cz / t.tz;
+    const int lx = cx - ax * t.tx, ly = cy - ay * t.ty, lz = cz - az * t.tz;
+    const uint32_t tile = ((uint32_t)az * t.nty + ay) * t.ntx + ax;
+    return tile * t.cpt + ((uint32_t)lz * t.ty + ly) * t.tx + lx;
+}
 __device__ __forceinline__ float d2_nc(float ax, float ay, float az, float bx, float by, float bz) {
     // nearest_neighbor.rs:162-167: (a - b) per component, dx*dx + dy*dy + dz*dz, left to right,
     // NO fma contraction (the library is built with -ffp-contract=off).
@@ -82,6 +99,7 @@ struct KernelTimer {
 // One indexed cloud living in device memory.
 struct DeviceIndex {
     GridGeom geom{};
+    TileGeom tile{};    // only meaningful for a tile-major (query-side) ordering
     DevBuf pts;         // float4 * n   (cell-sorted, w = original index bits)
     DevBuf cell_start;  // u32 * (ncell+1)
     DevBuf normals;     // float4 * n   (cell-sorted target normals; optional)
@@ -138,7 +156,9 @@ struct ProfScope {
 
 // grid.hip
 tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n,
-                      float cell_factor, const GridGeom *reuse_geom, const IcpState *d_state_transform);
+                      float cell_factor, const GridGeom *reuse_geom, const IcpState *d_state_transform,
+                      const TileGeom *tile_major = nullptr);
+TileGeom make_tiles(const GridGeom &g, int tx, int ty, int tz);
 tc_status gather_normals(tc_context *ctx, DeviceIndex &ix, const float *d_normals, size_t stride);
 GridView view_of(const DeviceIndex &ix);
 
