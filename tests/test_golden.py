@@ -1,0 +1,84 @@
+"""Golden fixtures (tests/golden/, made by tests/golden/make_golden.py with the oracle in the build
+container): the oracle must keep reproducing them (CPU), and the HIP path must match them (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.golden.make_golden import corr_digest
+from tests.helpers import cos_abs, sphere_cloud
+from threecrate_amd import synth
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ICP = json.load(open(os.path.join(G, "icp_u10k.json")))
+
+
+def _mat(T):
+    return O.isometry_to_matrix(np.asarray(T, np.float32)).astype(np.float64)
+
+
+def _check_icp(r, key, exact_corr=True):
+    g = ICP[key]
+    assert r.iterations == g["iterations"] and r.converged == g["converged"]
+    assert np.linalg.norm(_mat(r.transformation) - _mat(g["transformation"])) <= 1e-5
+    assert abs(r.mse - g["mse"]) <= 1e-9 + 1e-3 * abs(g["mse"])
+    assert len(r.correspondences) == g["n_correspondences"]
+    if exact_corr:
+        assert corr_digest(r.correspondences) == g["correspondences_sha256"]
+
+
+class _Cases:
+    """One definition of the golden cases; `b` is any object with the reference's function names."""
+
+    @staticmethod
+    def normals(b, k):
+        pts = synth.uniform_cloud(10000, seed=1)
+        got = np.asarray(b.estimate_normals(pts, k))[:, 3:]
+        ref = np.load(os.path.join(G, f"normals_u10k_k{k}.npy"))
+        c = cos_abs(got, ref)
+        assert c.min() >= 1 - 1e-4, f"worst 1-|cos| = {1 - c.min():.3e}"
+        assert (np.sum(got * ref, axis=1) > 0).all()
+
+    @staticmethod
+    def icp(b):
+        src, tgt, T = synth.registration_pair(10000, seed=1)
+        assert np.allclose(T, ICP["T_true"])
+        _check_icp(b.icp_detailed(src, tgt, None, 20, None, 0.0), "icp_p2p_u10k_20it")
+        _check_icp(b.icp_detailed(src, tgt, None, 50, None, 1e-6), "icp_p2p_u10k_default")
+        _check_icp(b.icp_detailed(src, tgt, None, 10, 0.02, 1e-9), "icp_p2p_u10k_maxdist")
+        n16 = np.load(os.path.join(G, "normals_u10k_k16.npy"))
+        _check_icp(b.icp_point_to_plane_detailed(src, tgt, n16, None, 20, None, 0.0), "icp_p2pl_u10k_20it")
+        _check_icp(b.icp_point_to_plane(src, tgt, n16, None, 50), "icp_p2pl_u10k_default")
+        s, nn = sphere_cloud(100)
+        _check_icp(b.icp_point_to_plane(s, s + np.array([0.15, 0, 0], np.float32), nn, None, 50),
+                   "icp_p2pl_sphere100_shift", exact_corr=False)
+
+
+@pytest.mark.parametrize("k", [10, 16])
+def test_oracle_reproduces_golden_normals(k):
+    _Cases.normals(O, k)
+
+
+def test_oracle_reproduces_golden_icp():
+    _Cases.icp(O)
+
+
+def test_oracle_reproduces_golden_knn_and_voxel():
+    pts = synth.uniform_cloud(10000, seed=1)
+    idx, dist, cnt = O.knn_batch(pts, pts[:1000], 17)
+    assert np.array_equal(np.sort(idx, axis=1).astype(np.uint32), np.load(os.path.join(G, "knn_u10k_k17_q1k_idx.npy")))
+    assert np.array_equal(dist, np.load(os.path.join(G, "knn_u10k_k17_q1k_dist.npy")))
+    assert np.array_equal(O.voxel_grid_filter(pts, 0.1), np.load(os.path.join(G, "voxel_u10k_0p1.npy")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [10, 16])
+def test_hip_matches_golden_normals(ctx, k):
+    _Cases.normals(ctx, k)
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_icp(ctx):
+    _Cases.icp(ctx)

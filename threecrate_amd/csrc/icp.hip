@@ -121,12 +121,23 @@ __device__ __forceinline__ void nn_refine_wave(const GridView &gv, bool need, fl
         float wb = __shfl(best, l);
         uint32_t wj = __shfl(bestj, l);
         for (int R = 2;; ++R) {
-            const int W = 2 * R + 1, W3 = W * W * W;
+            // enumerate ONLY the shell cells of ring R: two full z faces, two y faces without the z
+            // rims, two x faces without the y / z rims: 24 R^2 + 2 cells
+            const int W = 2 * R + 1, V = W - 2;
+            const int nz = 2 * W * W, ny = 2 * W * V, nx = 2 * V * V, nshell = nz + ny + nx;
             float lb = INFINITY; uint32_t lj = 0xFFFFFFFFu;
-            for (int idx = lane; idx < W3; idx += 64) {
-                const int dz = idx / (W * W), rem = idx - dz * W * W, dy = rem / W, dx = rem - dy * W;
-                const int ox = dx - R, oy = dy - R, oz = dz - R;
-                if (max(max(abs(ox), abs(oy)), abs(oz)) != R) continue;          // interior: already scanned
+            for (int idx = lane; idx < nshell; idx += 64) {
+                int ox, oy, oz;
+                if (idx < nz) {
+                    const int f = idx / (W * W), r = idx - f * W * W;
+                    oz = f ? R : -R; oy = r / W - R; ox = r - (r / W) * W - R;
+                } else if (idx < nz + ny) {
+                    const int i2 = idx - nz, f = i2 / (W * V), r = i2 - f * W * V;
+                    oy = f ? R : -R; oz = r / W - (R - 1); ox = r - (r / W) * W - R;
+                } else {
+                    const int i3 = idx - nz - ny, f = i3 / (V * V), r = i3 - f * V * V;
+                    ox = f ? R : -R; oz = r / V - (R - 1); oy = r - (r / V) * V - (R - 1);
+                }
                 const int ccx = qcx + ox, ccy = qcy + oy, ccz = qcz + oz;
                 if (ccx < 0 || ccx >= g.gx || ccy < 0 || ccy >= g.gy || ccz < 0 || ccz >= g.gz) continue;
                 const uint32_t c = ((uint32_t)ccz * g.gy + ccy) * g.gx + ccx;
@@ -143,7 +154,7 @@ __device__ __forceinline__ void nn_refine_wave(const GridView &gv, bool need, fl
                 const uint32_t oj = __shfl_xor(lj, o);
                 if (ob < lb || (ob == lb && oj < lj)) { lb = ob; lj = oj; }
             }
-            if (lb < wb) { wb = lb; wj = lj; }
+            if (lb < wb || (lb == wb && lj < wj)) { wb = lb; wj = lj; }
             const bool covers = (qcx - R <= 0) && (qcx + R >= g.gx - 1) && (qcy - R <= 0) && (qcy + R >= g.gy - 1) &&
                                 (qcz - R <= 0) && (qcz + R >= g.gz - 1);
             const float bound = ((float)R + qmf - 2e-3f) * g.h;
@@ -176,232 +187,217 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *
     }
 }
 
-// ---- LDS-staged target region -----------------------------------------------------------------
-// A workgroup owns one TILE of source points (contiguous in the tile-major source order).  Every
-// iteration it computes the bounding box of its queries' CURRENT target cells (the tile moves
-// rigidly with the transform), adds a one-cell halo and stages that block of the cell-sorted
-// target into LDS: one contiguous, coalesced span of records per (y, z) row.  Lanes then scan
-// their 3x3 rows out of LDS with one flattened loop (candidates and row changes interleaved, so
-// lanes with short spans do not wait for lanes with long ones).
-constexpr int kNRMax = 96;    // (y, z) rows of a staged region
-constexpr int kLW = 24;       // row stride of the cell table: staged width in cells <= kLW - 1
-constexpr int kCap = 1792;    // staged records (28 KiB)
+// ---- correspondence search + reduction ---------------------------------------------------------
+// One lane per source point, points visited in target-cell (tile-major) order so that the lanes
+// of a wave read neighbouring rows of the cell-sorted target (L1 / L2 hits, merged requests).
+//
+// Warm start (exact): the previous iteration's match p of a source point is a real target point,
+// so ub = |T s - p|^2 bounds the new nearest-neighbour distance from above.  Only the rows / cells
+// of the 3x3x3 block that intersect that ball can hold the answer; everything else is skipped.
+// In steady state that leaves ~1-3 short spans (~5 candidates) per query instead of 9 (~40).
+//
+// Candidate loop: the surviving spans live in registers; one flattened, software-pipelined loop
+// walks them (the record of step i+1 is requested before step i is evaluated) so that a lane
+// with few candidates does not wait on a row-by-row schedule.  The running best is the minimum
+// of the 64-bit key (d2 bits, position): independent of visiting order, ties -> lowest position.
+//
+// Sums: per-pair terms and products are f32 exactly as the reference forms them
+// (registration.rs:417-427); a lane adds its handful of pairs in f32, then wave shuffles -> LDS
+// -> per-block partial rows in f64, folded in a fixed order by icp_finalize_kernel.
 
-struct RegionLds {
-    float4   pts[kCap];                 // staged records; the first kNRMax*kLW words double as the raw cell_start table
-    uint32_t row_g0[kNRMax];            // cell-sorted position of the first staged record of a row
-    uint32_t row_off[kNRMax + 1];       // LDS offset of a row (exclusive prefix of row lengths)
-    uint16_t cell[kNRMax * kLW];        // LDS index of the first record of cell (row, i)
-    int      box[kIcpBlock / 64][6];    // per-wave min / max of the query cells
+struct Span9 {
+    uint32_t s[9], e[9];
 };
+
+__device__ __forceinline__ void span_select(const Span9 &sp, int k, uint32_t &s, uint32_t &e) {
+    s = sp.s[0]; e = sp.e[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        s = (k == i) ? sp.s[i] : s;
+        e = (k == i) ? sp.e[i] : e;
+    }
+}
+
+// exact 1-NN of (x, y, z); ub2 = a valid upper bound of the squared NN distance (or +inf)
+__device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, float y, float z, float ub2,
+                                                 float &best, uint32_t &bestj, bool &refine, int &cx, int &cy,
+                                                 int &cz, float &mf, float &out2, float max_dist) {
+    const GridGeom &g = gv.g;
+    const float qx = fminf(fmaxf(x, g.minx), g.maxx), qy = fminf(fmaxf(y, g.miny), g.maxy),
+                qz = fminf(fmaxf(z, g.minz), g.maxz);
+    cx = cell_coord(qx, g.minx, g.inv_h, g.gx);
+    cy = cell_coord(qy, g.miny, g.inv_h, g.gy);
+    cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
+    const float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy,
+                fz = (qz - g.minz) * g.inv_h - (float)cz;
+    mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
+    out2 = outside_d2(x, y, z, qx, qy, qz);
+    // squared distance (shaved by the cell-assignment fuzz) from q' to the neighbouring slabs
+    const float lo_x = fmaxf(fx - 2e-3f, 0.0f) * g.h, hi_x = fmaxf(1.0f - fx - 2e-3f, 0.0f) * g.h;
+    const float lo_y = fmaxf(fy - 2e-3f, 0.0f) * g.h, hi_y = fmaxf(1.0f - fy - 2e-3f, 0.0f) * g.h;
+    const float lo_z = fmaxf(fz - 2e-3f, 0.0f) * g.h, hi_z = fmaxf(1.0f - fz - 2e-3f, 0.0f) * g.h;
+    const float ax2[3] = {lo_x * lo_x, 0.0f, hi_x * hi_x};
+    const float ay2[3] = {lo_y * lo_y, 0.0f, hi_y * hi_y};
+    const float az2[3] = {lo_z * lo_z, 0.0f, hi_z * hi_z};
+    const float ub = ub2 - out2;     // budget left inside the box (|p-q|^2 >= |p-q'|^2 + |q-q'|^2)
+    Span9 sp;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int dz = k / 3 - 1, dy = k % 3 - 1;
+        const int yy = cy + dy, zz = cz + dz;
+        const float r2 = ay2[dy + 1] + az2[dz + 1];
+        bool on = (yy >= 0) && (yy < g.gy) && (zz >= 0) && (zz < g.gz) && !(r2 > ub);
+        // x window: the left / right cell only if the ball reaches it
+        const int xa = (cx > 0 && !(r2 + ax2[0] > ub)) ? cx - 1 : cx;
+        const int xb = (cx < g.gx - 1 && !(r2 + ax2[2] > ub)) ? cx + 1 : cx;
+        uint32_t s0 = 0, e0 = 0;
+        if (on) {
+            const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
+            s0 = gv.cell_start[row + xa];
+            e0 = gv.cell_start[row + xb + 1];
+        }
+        sp.s[k] = s0; sp.e[k] = e0;
+        if (on) mask |= 1u << k;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        if (sp.s[k] == sp.e[k]) mask &= ~(1u << k);     // empty spans
+    // flattened, software-pipelined walk over the surviving spans
+    unsigned long long bestkey = ~0ull;                 // (d2 bits << 32) | position
+    uint32_t j = 0, e = 0;
+    bool have = false;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mask) {
+        const int k = __ffs(mask) - 1;
+        mask &= mask - 1;
+        span_select(sp, k, j, e);
+        c = gv.pts[j];
+        have = true;
+    }
+    while (have) {
+        // position of the next candidate (this span, else the next surviving span)
+        uint32_t nj = j + 1, ne = e;
+        bool nhave = true;
+        if (nj == e) {
+            if (mask) {
+                const int k = __ffs(mask) - 1;
+                mask &= mask - 1;
+                span_select(sp, k, nj, ne);
+            } else {
+                nhave = false;
+            }
+        }
+        float4 cn = c;
+        if (nhave) cn = gv.pts[nj];
+        const float v = d2_nc(c.x, c.y, c.z, x, y, z);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | j;
+        bestkey = (key < bestkey) ? key : bestkey;
+        c = cn; j = nj; e = ne; have = nhave;
+    }
+    best = __uint_as_float((uint32_t)(bestkey >> 32));
+    bestj = (uint32_t)bestkey;
+    if (bestkey == ~0ull) { best = INFINITY; bestj = 0xFFFFFFFFu; }
+    const bool covers = (cx - 1 <= 0) && (cx + 1 >= g.gx - 1) && (cy - 1 <= 0) && (cy + 1 >= g.gy - 1) &&
+                        (cz - 1 <= 0) && (cz + 1 >= g.gz - 1);
+    const float bound = (1.0f + mf - 2e-3f) * g.h;
+    refine = !(covers || best <= bound * bound + out2 || (max_dist >= 0.0f && bound > max_dist));
+}
 
 template <bool P2PLANE>
 __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
-    GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src,
-    const uint32_t *__restrict__ src_key_start, TileGeom tg, uint32_t tiles_per_block,
-    const IcpState *__restrict__ st, uint32_t *__restrict__ corr, uint32_t *__restrict__ corr_pos,
-    double *__restrict__ partials, int dbg) {
+    GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
+    const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, double *__restrict__ partials, int dbg) {
     constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
     if (st->done) return;
-    __shared__ RegionLds L;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
     const GridGeom &g = tgt.g;
     const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
     const float t[3] = {st->t[0], st->t[1], st->t[2]};
     const float max_dist = st->max_dist;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double acc[NACC];
+    const bool warm = st->iterations > 0 && !(dbg & 1);
+    float acc[NACC];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
 
     const uint32_t lb = xcd_remap_icp(blockIdx.x, gridDim.x);
-    const uint32_t tile0 = lb * tiles_per_block;
-    const uint32_t tile1 = min(tile0 + tiles_per_block, tg.ntiles);
-    for (uint32_t tile = tile0; tile < tile1; ++tile) {
-        const uint32_t qbeg = src_key_start[(size_t)tile * tg.cpt], qend = src_key_start[(size_t)(tile + 1) * tg.cpt];
-        for (uint32_t cb = qbeg; cb < qend; cb += kIcpBlock) {
-            const uint32_t j = cb + tid;
-            const bool active = j < qend;
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            float x = 0.f, y = 0.f, z = 0.f;
-            int cx = 0, cy = 0, cz = 0;
-            float mf = 0.f, out2 = 0.f;
-            if (active) {
-                s = src[j];
-                iso_apply(q, t, s.x, s.y, s.z, x, y, z);
-                const float qx = fminf(fmaxf(x, g.minx), g.maxx), qy = fminf(fmaxf(y, g.miny), g.maxy),
-                            qz = fminf(fmaxf(z, g.minz), g.maxz);
-                cx = cell_coord(qx, g.minx, g.inv_h, g.gx);
-                cy = cell_coord(qy, g.miny, g.inv_h, g.gy);
-                cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
-                const float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy,
-                            fz = (qz - g.minz) * g.inv_h - (float)cz;
-                mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
-                out2 = outside_d2(x, y, z, qx, qy, qz);
-            }
-            // ---- bounding box of the query cells (wave shuffles -> LDS -> every thread folds 4 rows)
-            int bmn[3] = {active ? cx : 0x7fffffff, active ? cy : 0x7fffffff, active ? cz : 0x7fffffff};
-            int bmx[3] = {active ? cx : -1, active ? cy : -1, active ? cz : -1};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    bmn[c] = min(bmn[c], __shfl_xor(bmn[c], o));
-                    bmx[c] = max(bmx[c], __shfl_xor(bmx[c], o));
+    const uint32_t beg = lb * chunk;
+    const uint32_t end = min(beg + chunk, ns);
+    for (uint32_t jb = beg; jb < end; jb += kIcpBlock) {
+        const uint32_t j = jb + threadIdx.x;
+        const bool active = j < end;
+        float x = 0.f, y = 0.f, z = 0.f, best = INFINITY, mf = 0.f, out2 = 0.f;
+        uint32_t bestg = 0xFFFFFFFFu;
+        int cx = 0, cy = 0, cz = 0;
+        bool refine = false;
+        if (active) {
+            const float4 s = src[j];
+            iso_apply(q, t, s.x, s.y, s.z, x, y, z);
+            float ub2 = INFINITY;
+            if (warm) {
+                const uint32_t pj = corr_pos[j];
+                if (pj != 0xFFFFFFFFu) {
+                    const float4 p = tgt.pts[pj];
+                    ub2 = d2_nc(p.x, p.y, p.z, x, y, z);
                 }
             }
-            if (lane == 0) {
+            if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f);   // farther matches are rejected anyway
+            nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, cx, cy, cz, mf, out2, max_dist);
+        }
+        nn_refine_wave(tgt, refine, x, y, z, cx, cy, cz, mf, out2, max_dist, best, bestg);
+        if (active) {
+            bool valid = bestg != 0xFFFFFFFFu;
+            if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
+            corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
+            if (valid) {
+                const float4 c = tgt.pts[bestg];
+                if (P2PLANE) {
+                    const float4 n = tgt_nrm[bestg];
+                    // registration.rs:417-427 in f32: c = s x n ; a = [c, n] ; b = n . (d - s)
+                    const float a[6] = {y * n.z - z * n.y, z * n.x - x * n.z, x * n.y - y * n.x, n.x, n.y, n.z};
+                    const float dx = c.x - x, dy = c.y - y, dz = c.z - z;
+                    const float b = n.x * dx + n.y * dy + n.z * dz;
+                    int o = 0;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { L.box[wave][c] = bmn[c]; L.box[wave][3 + c] = bmx[c]; }
-            }
-            __syncthreads();
+                    for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                bmn[c] = min(min(L.box[0][c], L.box[1][c]), min(L.box[2][c], L.box[3][c]));
-                bmx[c] = max(max(L.box[0][3 + c], L.box[1][3 + c]), max(L.box[2][3 + c], L.box[3][3 + c]));
-            }
-            const int X0 = max(bmn[0] - 1, 0), X1 = min(bmx[0] + 1, g.gx - 1);
-            const int Y0 = max(bmn[1] - 1, 0), Y1 = min(bmx[1] + 1, g.gy - 1);
-            const int Z0 = max(bmn[2] - 1, 0), Z1 = min(bmx[2] + 1, g.gz - 1);
-            const int WX = X1 - X0 + 1, RY = Y1 - Y0 + 1, RZ = Z1 - Z0 + 1, NR = RY * RZ;
-            bool staged = (WX <= kLW - 1) && (NR <= kNRMax) && !(dbg & 1);      // wave-uniform
-            if (staged) {
-                // A: raw cell_start table of the region (aliases the record buffer); thread = (row lane, column)
-                uint32_t *raw = reinterpret_cast<uint32_t *>(L.pts);
-                const int col = tid & 31, rl = tid >> 5;
-                const float inv_ry = 1.0f / (float)RY;
-                if (col <= WX) {
-                    for (int r = rl; r < NR; r += kIcpBlock / 32) {
-                        const int rz = (int)(((float)r + 0.5f) * inv_ry), ry = r - rz * RY;
-                        raw[r * kLW + col] = tgt.cell_start[((uint32_t)(Z0 + rz) * g.gy + (Y0 + ry)) * g.gx + X0 + col];
-                    }
-                }
-                __syncthreads();
-                // B: row lengths -> exclusive prefix (wave 0, two rows per lane)
-                if (wave == 0) {
-                    const int r0 = lane, r1 = lane + 64;
-                    const uint32_t g0a = (r0 < NR) ? raw[r0 * kLW] : 0u, g0b = (r1 < NR) ? raw[r1 * kLW] : 0u;
-                    const uint32_t la = (r0 < NR) ? raw[r0 * kLW + WX] - g0a : 0u;
-                    const uint32_t lb2 = (r1 < NR) ? raw[r1 * kLW + WX] - g0b : 0u;
-                    uint32_t ia = la, ib = lb2;
+                        for (int cc = r; cc < 6; ++cc) { acc[o] += a[r] * a[cc]; ++o; }
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const uint32_t ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
-                        if (lane >= o) { ia += ta; ib += tb; }
-                    }
-                    const uint32_t tot_a = __shfl(ia, 63), tot_b = __shfl(ib, 63);
-                    if (r0 < NR) { L.row_g0[r0] = g0a; L.row_off[r0] = ia - la; }
-                    if (r1 < NR) { L.row_g0[r1] = g0b; L.row_off[r1] = tot_a + ib - lb2; }
-                    if (lane == 0) L.row_off[NR] = tot_a + tot_b;
-                }
-                __syncthreads();
-                staged = L.row_off[NR] <= (uint32_t)kCap;
-                if (staged) {
-                    // C: cell table -> LDS indices
-                    uint16_t cv[kNRMax / (kIcpBlock / 32)];
-                    if (col <= WX) {
-                        int ne = 0;
-                        for (int r = rl; r < NR; r += kIcpBlock / 32, ++ne)
-                            cv[ne] = (uint16_t)(raw[r * kLW + col] - L.row_g0[r] + L.row_off[r]);
-                    }
-                    __syncthreads();      // all raw reads done before the records overwrite them
-                    if (col <= WX) {
-                        int ne = 0;
-                        for (int r = rl; r < NR; r += kIcpBlock / 32, ++ne) L.cell[r * kLW + col] = cv[ne];
-                    }
-                    // D: stage the records, 16 lanes per row -> contiguous 256-B pieces
-                    const int sub = tid >> 4, k16 = tid & 15;
-                    if (!(dbg & 8)) for (int r = sub; r < NR; r += kIcpBlock / 16) {
-                        const uint32_t g0 = L.row_g0[r], o = L.row_off[r], len = L.row_off[r + 1] - o;
-                        for (uint32_t kk = k16; kk < len; kk += 16) L.pts[o + kk] = tgt.pts[g0 + kk];
-                    }
-                }
-                __syncthreads();
-            }
-            // ---- search
-            float best = INFINITY;
-            uint32_t bestg = 0xFFFFFFFFu;
-            bool refine = false;
-            if (active && !(dbg & 2)) {
-                if (staged) {
-                    const int lx = cx - X0, ly = cy - Y0, lz = cz - Z0;
-                    const int xa = max(lx - 1, 0), xb = min(lx + 1, WX - 1);
-                    uint32_t jj = 0, ee = 0, bestl = 0;
-                    int k = 0, lr = 0, bestlr = -1;
-                    for (;;) {
-                        while (jj == ee && k < 9) {      // next (dy, dz) row of the 3x3 block
-                            const int dz = (k >= 6) ? 1 : (k >= 3 ? 0 : -1), dy = k - (dz + 1) * 3 - 1;
-                            ++k;
-                            const int yy = ly + dy, zz = lz + dz;
-                            if (yy < 0 || yy >= RY || zz < 0 || zz >= RZ) continue;
-                            lr = zz * RY + yy;
-                            jj = L.cell[lr * kLW + xa];
-                            ee = L.cell[lr * kLW + xb + 1];
-                        }
-                        if (jj == ee) break;
-                        const float4 c = L.pts[jj];
-                        const float v = d2_nc(c.x, c.y, c.z, x, y, z);
-                        if (v < best) { best = v; bestl = jj; bestlr = lr; }
-                        ++jj;
-                    }
-                    if (bestlr >= 0) bestg = L.row_g0[bestlr] + (bestl - L.row_off[bestlr]);
-                    // exactness of ring 1 (same rule as the global path)
-                    const bool covers = (cx - 1 <= 0) && (cx + 1 >= g.gx - 1) && (cy - 1 <= 0) && (cy + 1 >= g.gy - 1) &&
-                                        (cz - 1 <= 0) && (cz + 1 >= g.gz - 1);
-                    const float bound = (1.0f + mf - 2e-3f) * g.h;
-                    refine = !(covers || best <= bound * bound + out2 || (max_dist >= 0.0f && bound > max_dist));
+                    for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * b;
+                    acc[27] += b * b;
+                    acc[28] += 1.0f;
                 } else {
-                    nn_search_global(tgt, x, y, z, max_dist, 1, best, bestg);
+                    // shifted by the target bbox centre so that H = sum s q^T - n ms mq^T does not cancel
+                    const float sx = x - g.cx, sy = y - g.cy, sz = z - g.cz;
+                    const float tx = c.x - g.cx, ty = c.y - g.cy, tz = c.z - g.cz;
+                    acc[0] += sx; acc[1] += sy; acc[2] += sz;
+                    acc[3] += tx; acc[4] += ty; acc[5] += tz;
+                    acc[6] += sx * tx;  acc[7] += sx * ty;  acc[8] += sx * tz;
+                    acc[9] += sy * tx;  acc[10] += sy * ty; acc[11] += sy * tz;
+                    acc[12] += sz * tx; acc[13] += sz * ty; acc[14] += sz * tz;
+                    const float ex = x - c.x, ey = y - c.y, ez = z - c.z;          // registration.rs:214
+                    acc[15] += ex * ex + ey * ey + ez * ez;
+                    acc[16] += 1.0f;
                 }
             }
-            if (!(dbg & 16)) nn_refine_wave(tgt, refine, x, y, z, cx, cy, cz, mf, out2, max_dist, best, bestg);
-            if (active && !(dbg & 4)) {
-                bool valid = bestg != 0xFFFFFFFFu;
-                if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
-                const uint32_t so = __float_as_uint(s.w);
-                if (!valid) {
-                    corr[so] = 0xFFFFFFFFu;
-                    if (!P2PLANE) corr_pos[j] = 0xFFFFFFFFu;
-                } else {
-                    const float4 c = tgt.pts[bestg];
-                    corr[so] = __float_as_uint(c.w);
-                    if (P2PLANE) {
-                        const float4 n = tgt_nrm[bestg];
-                        // registration.rs:417-427 in f32: c = s x n ; a = [c, n] ; b = n . (d - s)
-                        const float a0 = y * n.z - z * n.y, a1 = z * n.x - x * n.z, a2 = x * n.y - y * n.x;
-                        const float dx = c.x - x, dy = c.y - y, dz = c.z - z;
-                        const float b = n.x * dx + n.y * dy + n.z * dz;
-                        const double a[6] = {(double)a0, (double)a1, (double)a2, (double)n.x, (double)n.y, (double)n.z};
-                        const double bd = (double)b;
-                        int o = 0;
-#pragma unroll
-                        for (int r = 0; r < 6; ++r)
-#pragma unroll
-                            for (int cc = r; cc < 6; ++cc) { acc[o] = fma(a[r], a[cc], acc[o]); ++o; }
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) acc[21 + r] = fma(a[r], bd, acc[21 + r]);
-                        acc[27] = fma(bd, bd, acc[27]);
-                        acc[28] += 1.0;
-                    } else {
-                        corr_pos[j] = bestg;
-                        // shifted by the target bbox centre so that H = sum s q^T - n ms mq^T does not cancel
-                        const double sx = (double)x - (double)g.cx, sy = (double)y - (double)g.cy, sz = (double)z - (double)g.cz;
-                        const double qx = (double)c.x - (double)g.cx, qy = (double)c.y - (double)g.cy, qz = (double)c.z - (double)g.cz;
-                        acc[0] += sx; acc[1] += sy; acc[2] += sz;
-                        acc[3] += qx; acc[4] += qy; acc[5] += qz;
-                        acc[6] = fma(sx, qx, acc[6]);   acc[7] = fma(sx, qy, acc[7]);   acc[8] = fma(sx, qz, acc[8]);
-                        acc[9] = fma(sy, qx, acc[9]);   acc[10] = fma(sy, qy, acc[10]); acc[11] = fma(sy, qz, acc[11]);
-                        acc[12] = fma(sz, qx, acc[12]); acc[13] = fma(sz, qy, acc[13]); acc[14] = fma(sz, qz, acc[14]);
-                        const float ex = x - c.x, ey = y - c.y, ez = z - c.z;          // registration.rs:214
-                        acc[15] += (double)(ex * ex + ey * ey + ez * ez);
-                        acc[16] += 1.0;
-                    }
-                }
-            }
-            __syncthreads();   // the next chunk restages L
         }
     }
-    block_reduce_store<NACC>(acc, partials + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE, red);
+    double dacc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) dacc[i] = (double)acc[i];
+    block_reduce_store<NACC>(dacc, partials + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE, red);
+}
+
+// ICPResult.correspondences (registration.rs:22-23): matched ORIGINAL target index per ORIGINAL
+// source index of the last executed iteration; written once, after the loop.
+__global__ void __launch_bounds__(256) icp_write_corr_kernel(GridView tgt, const float4 *__restrict__ src, uint32_t ns,
+                                                            const uint32_t *__restrict__ corr_pos,
+                                                            uint32_t *__restrict__ corr) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ns) return;
+    const uint32_t so = __float_as_uint(src[j].w);
+    const uint32_t pj = corr_pos[j];
+    corr[so] = (pj == 0xFFFFFFFFu) ? 0xFFFFFFFFu : __float_as_uint(tgt.pts[pj].w);
 }
 
 // mse of the last correspondences under the final transform (registration.rs:343-361)
@@ -682,30 +678,26 @@ __global__ void icp_finish_kernel(IcpState *__restrict__ st, const double *__res
 
 // ---- host orchestration ---------------------------------------------------------------------
 struct IcpLaunch {
-    uint32_t nblocks = 0;          // correspond_reduce grid (= rows of partials)
-    uint32_t tiles_per_block = 0;
+    uint32_t nblocks = 0, chunk = 0;          // correspond_reduce grid (= rows of partials) and points per block
     uint32_t mse_blocks = 0, mse_chunk = 0;   // final-mse grid (p2p)
 };
-static IcpLaunch plan_launch(size_t ns, const TileGeom &tg) {
+static IcpLaunch plan_launch(size_t ns) {
     IcpLaunch l;
-    uint32_t nb = std::min<uint32_t>(tg.ntiles, 1024u);
+    uint32_t nb = (uint32_t)std::min<size_t>((ns + kIcpBlock - 1) / kIcpBlock, (size_t)kMaxPartialBlocks);
     nb = std::max<uint32_t>((nb + 7) / 8 * 8, 8);
-    l.nblocks = nb;
-    l.tiles_per_block = (tg.ntiles + nb - 1) / nb;
-    uint32_t mb = (uint32_t)std::min<size_t>((ns + kIcpBlock - 1) / kIcpBlock, 1024);
-    mb = std::max<uint32_t>(mb, 1);
-    uint32_t chunk = (uint32_t)((ns + mb - 1) / mb);
+    uint32_t chunk = (uint32_t)((ns + nb - 1) / nb);
     chunk = (chunk + kIcpBlock - 1) / kIcpBlock * kIcpBlock;
-    l.mse_blocks = mb; l.mse_chunk = chunk;
+    l.nblocks = nb; l.chunk = chunk;
+    l.mse_blocks = nb; l.mse_chunk = chunk;
     return l;
 }
 
-// tile dims so that a tile holds ~0.88 * 256 source points (one full workgroup pass)
+// tile dims for the source ordering: compact blocks of ~256 source points
 static TileGeom plan_tiles(const GridGeom &g, size_t ns) {
     const double rho = (double)ns / std::max<double>(g.ncell, 1.0);
-    const double want = 0.88 * kIcpBlock / std::max(rho, 1e-6);      // cells per tile
+    const double want = 256.0 / std::max(rho, 1e-6);      // cells per tile
     static const int cand[][3] = {{8, 2, 2}, {8, 3, 2}, {8, 3, 3}, {8, 4, 3}, {8, 4, 4}, {8, 5, 4}, {8, 5, 5}, {8, 6, 5},
-                                  {8, 6, 6}, {10, 6, 6}, {12, 6, 6}, {16, 6, 6}, {20, 6, 6}, {4, 2, 2}, {4, 2, 1}, {2, 2, 1}};
+                                  {8, 6, 6}, {10, 6, 6}, {12, 6, 6}, {16, 6, 6}, {16, 8, 8}, {4, 2, 2}, {4, 2, 1}, {2, 2, 1}};
     int best = 0; double bd = 1e300;
     for (int i = 0; i < (int)(sizeof(cand) / sizeof(cand[0])); ++i) {
         const double c = (double)cand[i][0] * cand[i][1] * cand[i][2];
@@ -716,18 +708,18 @@ static TileGeom plan_tiles(const GridGeom &g, size_t ns) {
 }
 
 static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, const float4 *nrm, const float4 *src,
-                             const uint32_t *src_key_start, const TileGeom &tg, const IcpLaunch &l, IcpState *st,
-                             uint32_t *corr, uint32_t *corr_pos, double *partials, bool do_sum, bool do_apply, bool do_reduce) {
+                             uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr_pos, double *partials,
+                             bool do_sum, bool do_apply, bool do_reduce) {
     hipStream_t s = ctx->stream;
     static const int dbg = getenv("TC_DEBUG") ? atoi(getenv("TC_DEBUG")) : 0;
     if (do_reduce) {
         ProfScope ps(ctx, p2plane ? "icp_correspond_reduce_p2plane" : "icp_correspond_reduce_p2p");
         if (p2plane)
-            hipLaunchKernelGGL(icp_correspond_reduce_kernel<true>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src,
-                               src_key_start, tg, l.tiles_per_block, st, corr, corr_pos, partials, dbg);
+            hipLaunchKernelGGL(icp_correspond_reduce_kernel<true>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
+                               l.chunk, st, corr_pos, partials, dbg);
         else
-            hipLaunchKernelGGL(icp_correspond_reduce_kernel<false>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src,
-                               src_key_start, tg, l.tiles_per_block, st, corr, corr_pos, partials, dbg);
+            hipLaunchKernelGGL(icp_correspond_reduce_kernel<false>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
+                               l.chunk, st, corr_pos, partials, dbg);
     }
     if (do_sum || do_apply) {
         ProfScope ps(ctx, "icp_finalize");
@@ -767,7 +759,7 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     // order the source by the (tile-major) target cell of its initially transformed position
     out.tg = plan_tiles(ctx->tgt_index.geom, ns);
     if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &ctx->tgt_index.geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
-    out.l = plan_launch(ns, out.tg);
+    out.l = plan_launch(ns);
     if (tc_status s = ensure(ctx, ctx->partials, (size_t)kMaxPartialBlocks * TC_ICP_SUMS_STRIDE * sizeof(double))) return s;
     if (tc_status s = ensure(ctx, ctx->corr, 2 * ns * sizeof(uint32_t))) return s;
     out.tv = view_of(ctx->tgt_index);
@@ -801,8 +793,7 @@ tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, 
             if (flags[c - 2]) { stopped = true; break; }
         }
         for (size_t k = 0; k < kChunk && it < max_iters; ++k, ++it)
-            launch_iteration(ctx, p2plane, su.tv, nrm, src, (const uint32_t *)ctx->src_index.cell_start.p, su.tg, su.l, dstate, corr,
-                             corr_pos, partials, true, true, true);
+            launch_iteration(ctx, p2plane, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, partials, true, true, true);
         if (c < max_flags) {
             flags[c] = 0;
             TC_HIP_TRY(ctx, hipMemcpyAsync(&flags[c], &dstate->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -821,6 +812,8 @@ tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, 
     IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
     TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
     if (res->corr_target) {
+        hipLaunchKernelGGL(icp_write_corr_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, su.tv, src, (uint32_t)ns,
+                           corr_pos, corr);
         TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, ns * sizeof(uint32_t),
                                        corr_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     }
@@ -873,8 +866,8 @@ tc_status tc_icp_shard_reduce(tc_icp_shard *s) {
     tc_context *ctx = s->ctx;
     uint32_t *corr = (uint32_t *)ctx->corr.p;
     tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
-                         (const uint32_t *)ctx->src_index.cell_start.p, s->su.tg, s->su.l, (tc::IcpState *)ctx->state.p, corr,
-                         corr + s->ns, (double *)ctx->partials.p, true, false, true);
+                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr + s->ns, (double *)ctx->partials.p, true, false,
+                         true);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
 }
@@ -883,8 +876,8 @@ tc_status tc_icp_shard_apply(tc_icp_shard *s) {
     tc_context *ctx = s->ctx;
     uint32_t *corr = (uint32_t *)ctx->corr.p;
     tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
-                         (const uint32_t *)ctx->src_index.cell_start.p, s->su.tg, s->su.l, (tc::IcpState *)ctx->state.p, corr,
-                         corr + s->ns, (double *)ctx->partials.p, false, true, false);
+                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr + s->ns, (double *)ctx->partials.p, false, true,
+                         false);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
 }
@@ -898,8 +891,12 @@ tc_status tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *
     hipLaunchKernelGGL(tc::icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, (const double *)ctx->partials.p, 0u, 1);
     tc::IcpState *hs = (tc::IcpState *)((char *)ctx->pinned + 256);
     TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(tc::IcpState), hipMemcpyDeviceToHost, st));
-    if (res->corr_target)
-        TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, ctx->corr.p, s->ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    if (res->corr_target) {
+        uint32_t *corr = (uint32_t *)ctx->corr.p;
+        hipLaunchKernelGGL(tc::icp_write_corr_kernel, dim3((unsigned)((s->ns + 255) / 256)), dim3(256), 0, st, s->su.tv,
+                           (const float4 *)ctx->src_index.pts.p, (uint32_t)s->ns, corr + s->ns, corr);
+        TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, s->ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    }
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
     if (hs->status != TC_OK) return tc::fail(ctx, (tc_status)hs->status, "ICP failed (insufficient correspondences / singular system)");
     for (int i = 0; i < 4; ++i) res->transformation[i] = hs->q[i];

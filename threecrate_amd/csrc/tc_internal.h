@@ -60,7 +60,7 @@ struct IcpState {
 };
 
 constexpr int kIcpBlock = 256;
-constexpr int kMaxPartialBlocks = 2048;
+constexpr int kMaxPartialBlocks = 1024;
 
 // ---- device helpers -----------------------------------------------------------------------
 #if defined(__HIPCC__)
