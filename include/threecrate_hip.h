@@ -187,6 +187,12 @@ tc_status tc_icp_shard_create(tc_context *ctx, int point_to_plane,
 /* device pointer to TC_ICP_SUMS_STRIDE doubles: this rank's packed sums (all-reduce in place) */
 double     *tc_icp_shard_sums(tc_icp_shard *s);
 tc_status   tc_icp_shard_reduce(tc_icp_shard *s);              /* correspondences + local sums */
+/* async device-to-device copies of the TC_ICP_SUMS_STRIDE packed sums on the context's stream,
+   for callers that all-reduce in their own buffer (e.g. a torch tensor) */
+tc_status   tc_icp_shard_get_sums(tc_icp_shard *s, double *d_out);
+tc_status   tc_icp_shard_set_sums(tc_icp_shard *s, const double *d_in);
+/* blocking: *done = 1 once the loop has converged or failed (identical on every rank) */
+tc_status   tc_icp_shard_done(tc_icp_shard *s, int *done);
 tc_status   tc_icp_shard_apply(tc_icp_shard *s);               /* solve + compose + convergence (device) */
 tc_status   tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *result);
 void        tc_icp_shard_destroy(tc_icp_shard *s);

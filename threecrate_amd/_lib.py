@@ -47,7 +47,8 @@ EXPORTS = [
     "tc_estimate_normals", "tc_estimate_normals_device", "tc_icp_detailed", "tc_icp_detailed_device",
     "tc_icp_point_to_point", "tc_icp", "tc_icp_point_to_plane_detailed",
     "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
-    "tc_icp_shard_reduce", "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
+    "tc_icp_shard_reduce", "tc_icp_shard_get_sums", "tc_icp_shard_set_sums", "tc_icp_shard_done",
+    "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
     "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
 ]
 
@@ -111,6 +112,9 @@ def load():
     L.tc_icp_shard_sums.argtypes = [vp]
     L.tc_icp_shard_sums.restype = C.c_void_p
     L.tc_icp_shard_reduce.argtypes = [vp]
+    L.tc_icp_shard_get_sums.argtypes = [vp, vp]
+    L.tc_icp_shard_set_sums.argtypes = [vp, vp]
+    L.tc_icp_shard_done.argtypes = [vp, C.POINTER(C.c_int)]
     L.tc_icp_shard_apply.argtypes = [vp]
     L.tc_icp_shard_finish.argtypes = [vp, sz, resp]
     L.tc_icp_shard_destroy.argtypes = [vp]

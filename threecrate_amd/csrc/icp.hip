@@ -862,6 +862,29 @@ tc_status tc_icp_shard_create(tc_context *ctx, int point_to_plane, const float *
 
 double *tc_icp_shard_sums(tc_icp_shard *s) { return ((tc::IcpState *)s->ctx->state.p)->sums; }
 
+tc_status tc_icp_shard_get_sums(tc_icp_shard *s, double *d_out) {
+    tc_context *ctx = s->ctx;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(d_out, ((tc::IcpState *)ctx->state.p)->sums, TC_ICP_SUMS_STRIDE * sizeof(double),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    return TC_OK;
+}
+
+tc_status tc_icp_shard_set_sums(tc_icp_shard *s, const double *d_in) {
+    tc_context *ctx = s->ctx;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(((tc::IcpState *)ctx->state.p)->sums, d_in, TC_ICP_SUMS_STRIDE * sizeof(double),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    return TC_OK;
+}
+
+tc_status tc_icp_shard_done(tc_icp_shard *s, int *done) {
+    tc_context *ctx = s->ctx;
+    int32_t *h = (int32_t *)((char *)ctx->pinned + 1024);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(h, &((tc::IcpState *)ctx->state.p)->done, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *done = *h;
+    return TC_OK;
+}
+
 tc_status tc_icp_shard_reduce(tc_icp_shard *s) {
     tc_context *ctx = s->ctx;
     uint32_t *corr = (uint32_t *)ctx->corr.p;

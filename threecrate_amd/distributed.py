@@ -1,0 +1,139 @@
+"""Multi-GPU host logic, one process per GPU over torch.distributed.
+
+Two ways the path shards:
+  * independent scan pairs / batch ICP (BASELINE config [2]): rank r runs jobs r, r+W, ... on its
+    own GPU; there is NO data-path collective (run_independent_jobs only gathers the results).
+  * one big cloud (BASELINE config [3]): the SOURCE points are sharded, the target (+ normals +
+    grid) is replicated; every iteration each rank reduces its shard to the packed normal
+    equations (29 f64 words for point-to-plane) and ONE all-reduce(sum) of that 232-byte vector
+    (RCCL over xGMI when the backend is "nccl") makes them global.  Every rank then applies the
+    identical reduced buffer, so all ranks hold the same transform without a broadcast.
+
+The per-shard work is done by a backend object: HipShardBackend calls the C ABI
+(tc_icp_shard_*); the CPU tests (gloo, world_size 2) plug in a checker backend instead, so that
+the sharding / collective / control flow is exercised without a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .api import ICPResult, Unsupported, _ERR, Error
+
+SUMS = _lib.SUMS_STRIDE
+
+
+def shard_range(n, rank, world):
+    """Contiguous, balanced source range of `rank`."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class HipShardBackend:
+    """Per-rank shard session on one GPU (tc_icp_shard_*).  `sums` is a torch CUDA f64 tensor that
+    the caller all-reduces in place."""
+
+    def __init__(self, ctx, source_slice, target, target_normals, init, max_correspondence_distance, convergence_threshold):
+        import torch
+        self.torch, self.ctx, self.L = torch, ctx, _lib.load()
+        self.s = source_slice.detach().to(torch.float32).contiguous().reshape(-1, 3)
+        self.t = target.detach().to(torch.float32).contiguous().reshape(-1, 3)
+        n = target_normals.detach().to(torch.float32).contiguous()
+        self.stride = 6 if (n.dim() == 2 and n.shape[1] == 6) else 3
+        self.n = n
+        if (n.shape[0] if n.dim() == 2 else n.numel() // 3) != self.t.shape[0]:
+            from .api import InvalidData
+            raise InvalidData("target_normals length must equal the number of target points")
+        i7 = np.ascontiguousarray(np.asarray(init, np.float32).reshape(7))
+        md = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance)
+        h = C.c_void_p()
+        rc = self.L.tc_icp_shard_create(ctx._h, 1, self.s.data_ptr(), self.s.shape[0], self.t.data_ptr(), self.t.shape[0],
+                                        n.data_ptr() + (12 if self.stride == 6 else 0), self.stride, i7.ctypes.data, md,
+                                        convergence_threshold, C.byref(h))
+        ctx._check(rc)
+        self.h = h
+        self.sums = torch.zeros(SUMS, dtype=torch.float64, device=self.s.device)
+
+    def reduce(self):
+        self.ctx._check(self.L.tc_icp_shard_reduce(self.h))
+        self.ctx._check(self.L.tc_icp_shard_get_sums(self.h, self.sums.data_ptr()))
+        self.ctx._check(self.L.tc_synchronize(self.ctx._h))     # the collective runs on torch's stream
+        return self.sums
+
+    def apply(self, sums):
+        self.torch.cuda.current_stream().synchronize()
+        self.ctx._check(self.L.tc_icp_shard_set_sums(self.h, sums.data_ptr()))
+        self.ctx._check(self.L.tc_icp_shard_apply(self.h))
+
+    def done(self):
+        d = C.c_int(0)
+        self.ctx._check(self.L.tc_icp_shard_done(self.h, C.byref(d)))
+        return bool(d.value)
+
+    def finish(self, max_iters):
+        r = _lib.IcpResultC()
+        rc = self.L.tc_icp_shard_finish(self.h, max_iters, C.byref(r))
+        self.L.tc_icp_shard_destroy(self.h)
+        self.h = None
+        self.ctx._check(rc)
+        return ICPResult(np.array(list(r.transformation), np.float32), float(r.mse), int(r.iterations), bool(r.converged))
+
+
+def sharded_icp_loop(backend, max_iters, group=None, poll_every=4):
+    """Drives `max_iters` iterations of a sharded ICP: reduce -> all_reduce(sum) -> apply.
+    Returns the backend's result (identical on every rank)."""
+    import torch.distributed as dist
+    use = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    it = 0
+    while it < max_iters:
+        sums = backend.reduce()
+        if use:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        backend.apply(sums)
+        it += 1
+        if it % poll_every == 0 and it < max_iters and backend.done():
+            break
+    return backend.finish(max_iters)
+
+
+def sharded_icp_point_to_plane(ctx, source, target, target_normals, init=None, max_iters=50,
+                               max_correspondence_distance=None, convergence_threshold=1e-6, group=None,
+                               source_is_local_slice=False):
+    """icp_point_to_plane_detailed (registration.rs:508-602) over all ranks of `group`:
+    `source` is the full source cloud (every rank takes its shard_range) or, with
+    source_is_local_slice=True, already this rank's slice; target / normals are replicated
+    torch CUDA tensors."""
+    import torch.distributed as dist
+    from .api import IDENTITY, InvalidData
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    if source.shape[0] == 0 or target.shape[0] == 0:
+        raise InvalidData("Source or target point cloud is empty")
+    if max_iters == 0:
+        raise InvalidData("Max iterations must be positive")
+    sl = source
+    if not source_is_local_slice:
+        lo, hi = shard_range(source.shape[0], rank, world)
+        sl = source[lo:hi]
+    be = HipShardBackend(ctx, sl, target, target_normals, IDENTITY if init is None else init,
+                         max_correspondence_distance, convergence_threshold)
+    return sharded_icp_loop(be, max_iters, group)
+
+
+def run_independent_jobs(jobs, run_one, group=None):
+    """Independent scan pairs: rank r runs jobs[r::world] with `run_one(job)`; results are
+    gathered to every rank in job order.  No data-path collective."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    mine = [(i, run_one(jobs[i])) for i in range(rank, len(jobs), world)]
+    if world == 1:
+        return [r for _, r in mine]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine, group=group)
+    out = [None] * len(jobs)
+    for part in gathered:
+        for i, r in part:
+            out[i] = r
+    return out
