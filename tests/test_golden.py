@@ -51,9 +51,18 @@ class _Cases:
         n16 = np.load(os.path.join(G, "normals_u10k_k16.npy"))
         _check_icp(b.icp_point_to_plane_detailed(src, tgt, n16, None, 20, None, 0.0), "icp_p2pl_u10k_20it")
         _check_icp(b.icp_point_to_plane(src, tgt, n16, None, 50), "icp_p2pl_u10k_default")
+        # Fibonacci sphere (registration.rs:1148-1196): the 6x6 system is rank deficient in rotation
+        # (a sphere is invariant under rotations about its centre), so the iterates are decided by
+        # rounding noise -- f32 sequential sums (reference / oracle) vs f64 tree sums (HIP) take
+        # different paths (5 vs 8 iterations) to the same fixed point.  Only the answer is pinned.
         s, nn = sphere_cloud(100)
-        _check_icp(b.icp_point_to_plane(s, s + np.array([0.15, 0, 0], np.float32), nn, None, 50),
-                   "icp_p2pl_sphere100_shift", exact_corr=False)
+        shift = np.array([0.15, 0, 0], np.float32)
+        r = b.icp_point_to_plane(s, s + shift, nn, None, 50)
+        g = ICP["icp_p2pl_sphere100_shift"]
+        assert r.converged and g["converged"]
+        assert np.linalg.norm(np.asarray(r.transformation[4:]) - shift) < 1e-3
+        assert np.linalg.norm(np.asarray(g["transformation"][4:]) - shift) < 1e-3
+        assert r.mse < 1e-6 and g["mse"] < 1e-6
 
 
 @pytest.mark.parametrize("k", [10, 16])
