@@ -263,37 +263,31 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
 #pragma unroll
     for (int k = 0; k < 9; ++k)
         if (sp.s[k] == sp.e[k]) mask &= ~(1u << k);     // empty spans
-    // flattened, software-pipelined walk over the surviving spans
+    // flattened walk over the surviving spans, four records per step (four independent gathers in
+    // flight per lane); a lane switches to its next span as soon as the current one is exhausted
     unsigned long long bestkey = ~0ull;                 // (d2 bits << 32) | position
     uint32_t j = 0, e = 0;
-    bool have = false;
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (mask) {
-        const int k = __ffs(mask) - 1;
-        mask &= mask - 1;
-        span_select(sp, k, j, e);
-        c = gv.pts[j];
-        have = true;
-    }
-    while (have) {
-        // position of the next candidate (this span, else the next surviving span)
-        uint32_t nj = j + 1, ne = e;
-        bool nhave = true;
-        if (nj == e) {
-            if (mask) {
-                const int k = __ffs(mask) - 1;
-                mask &= mask - 1;
-                span_select(sp, k, nj, ne);
-            } else {
-                nhave = false;
-            }
+    while (true) {
+        if (j >= e) {
+            if (!mask) break;
+            const int k = __ffs(mask) - 1;
+            mask &= mask - 1;
+            span_select(sp, k, j, e);
         }
-        float4 cn = c;
-        if (nhave) cn = gv.pts[nj];
-        const float v = d2_nc(c.x, c.y, c.z, x, y, z);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | j;
-        bestkey = (key < bestkey) ? key : bestkey;
-        c = cn; j = nj; e = ne; have = nhave;
+        const uint32_t last = e - 1;
+        const uint32_t j0 = j, j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
+        const float4 c0 = gv.pts[j0], c1 = gv.pts[j1], c2 = gv.pts[j2], c3 = gv.pts[j3];
+        const float v0 = d2_nc(c0.x, c0.y, c0.z, x, y, z), v1 = d2_nc(c1.x, c1.y, c1.z, x, y, z);
+        const float v2 = d2_nc(c2.x, c2.y, c2.z, x, y, z), v3 = d2_nc(c3.x, c3.y, c3.z, x, y, z);
+        // duplicates (clamped positions) produce identical keys: harmless
+        const unsigned long long k0 = ((unsigned long long)__float_as_uint(v0) << 32) | j0;
+        const unsigned long long k1 = ((unsigned long long)__float_as_uint(v1) << 32) | j1;
+        const unsigned long long k2 = ((unsigned long long)__float_as_uint(v2) << 32) | j2;
+        const unsigned long long k3 = ((unsigned long long)__float_as_uint(v3) << 32) | j3;
+        const unsigned long long ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
+        const unsigned long long kc = ka < kb ? ka : kb;
+        bestkey = kc < bestkey ? kc : bestkey;
+        j += 4;
     }
     best = __uint_as_float((uint32_t)(bestkey >> 32));
     bestj = (uint32_t)bestkey;
