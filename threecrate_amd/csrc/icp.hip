@@ -75,7 +75,7 @@ __device__ __forceinline__ void nn_search_global(const GridView &gv, float x, fl
         for (uint32_t j = s; j < e; ++j) {
             const float4 c = gv.pts[j];
             const float v = d2_nc(c.x, c.y, c.z, x, y, z);
-            if (v < best) { best = v; bestj = j; }
+            if (v < best || (v == best && j < bestj)) { best = v; bestj = j; }   // ties: lowest position
         }
     };
     for (;; ++R) {
@@ -338,7 +338,13 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
             if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f);   // farther matches are rejected anyway
             nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, cx, cy, cz, mf, out2, max_dist);
         }
-        nn_refine_wave(tgt, refine, x, y, z, cx, cy, cz, mf, out2, max_dist, best, bestg);
+        // ring >= 2 continuation: a few lanes -> served one by one by the whole wave; many lanes
+        // (e.g. a wave of queries outside the target's bounding box) -> every lane walks its own shell
+        if (__popcll(__ballot(refine)) > 6) {
+            if (refine) nn_search_global(tgt, x, y, z, max_dist, 2, best, bestg);
+        } else {
+            nn_refine_wave(tgt, refine, x, y, z, cx, cy, cz, mf, out2, max_dist, best, bestg);
+        }
         if (active) {
             bool valid = bestg != 0xFFFFFFFFu;
             if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
