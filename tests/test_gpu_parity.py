@@ -182,3 +182,28 @@ def test_large_cloud_properties(ctx):
         if (w[1] - w[0]) > 0.02 * w[2] and 1 - abs(float(g[row] @ v[:, 0])) > 1e-4:
             bad += 1
     assert bad == 0
+
+
+@pytest.mark.parametrize("radius", [0.06, 0.035, 0.01, 0.15])
+def test_normals_radius_mode_matches_oracle(ctx, radius):
+    """estimate_normals_radius (normals.rs:368-380): radius set when it has >= 10 members, k-NN fallback
+    otherwise.  The HIP path sums the radius set in f64 (order independent), the reference in f32 in
+    ascending-distance order: same neighbour sets, rounding-level difference."""
+    pts = synth.uniform_cloud(12000, seed=7)
+    gpu = ctx.estimate_normals_radius(pts, radius, True)
+    ref = O.estimate_normals_radius(pts, radius, True)
+    c = cos_abs(gpu[:, 3:], ref[:, 3:])
+    assert (c < 1 - COS_TOL).sum() == 0, f"{(c < 1 - COS_TOL).sum()} beyond 1e-4, worst {1 - c.min():.3e}"
+    gpu = ctx.estimate_normals_with_config(pts, __import__("threecrate_amd").NormalEstimationConfig(
+        k_neighbors=5, radius=radius, consistent_orientation=False))
+    ref = O.estimate_normals(pts, 5, radius=radius, consistent_orientation=False)
+    c = cos_abs(gpu[:, 3:], ref[:, 3:])
+    assert (c < 1 - COS_TOL).sum() == 0
+
+
+def test_normals_radius_nonpositive_is_knn(ctx):
+    pts = synth.uniform_cloud(5000, seed=9)
+    a = ctx.estimate_normals_radius(pts, 0.0, True)
+    b = ctx.estimate_normals(pts, 10)
+    assert np.array_equal(a, b)
+    assert np.array_equal(O.estimate_normals_radius(pts, -1.0, True), O.estimate_normals(pts, 10))

@@ -70,7 +70,9 @@ static float normals_cell_factor(size_t k) {
 }
 
 static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, float *d_out) {
-    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(cfg->k_neighbors), nullptr, nullptr)) return s;
+    // radius mode: ring 2 must cover the radius ball, so the cell edge is at least radius / 2
+    const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(cfg->k_neighbors), nullptr, nullptr, nullptr, min_h)) return s;
     float vp[3];
     if (cfg->has_viewpoint) {
         vp[0] = cfg->viewpoint[0]; vp[1] = cfg->viewpoint[1]; vp[2] = cfg->viewpoint[2];

@@ -220,7 +220,7 @@ GridView view_of(const DeviceIndex &ix) {
 }
 
 // Cell edge from the bounding box: h = f * (measure / n)^(1/d) over the non-degenerate axes.
-static void derive_geom(GridGeom &g, const float mn[3], const float mx[3], size_t n, float f) {
+static void derive_geom(GridGeom &g, const float mn[3], const float mx[3], size_t n, float f, float min_h) {
     g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
     g.maxx = mx[0]; g.maxy = mx[1]; g.maxz = mx[2];
     g.cx = 0.5f * (mn[0] + mx[0]); g.cy = 0.5f * (mn[1] + mx[1]); g.cz = 0.5f * (mn[2] + mx[2]);
@@ -238,6 +238,7 @@ static void derive_geom(GridGeom &g, const float mn[3], const float mx[3], size_
         if (!(h > 0.0) || !std::isfinite(h)) h = emax;
         h = std::max(h, emax * 1e-4);   // at most 10^4 cells per axis
     }
+    if (min_h > 0.0f && std::isfinite(min_h)) h = std::max(h, (double)min_h);
     const double max_cells = std::max<double>(8.0 * (double)n, 4096.0);
     for (int guard = 0; guard < 200; ++guard) {
         double gx = std::floor(e[0] / h) + 1.0, gy = std::floor(e[1] / h) + 1.0, gz = std::floor(e[2] / h) + 1.0;
@@ -263,7 +264,8 @@ TileGeom make_tiles(const GridGeom &g, int tx, int ty, int tz) {
 }
 
 tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n, float cell_factor,
-                      const GridGeom *reuse_geom, const IcpState *d_state_transform, const TileGeom *tile_major) {
+                      const GridGeom *reuse_geom, const IcpState *d_state_transform, const TileGeom *tile_major,
+                      float min_cell_edge) {
     if (n == 0 || n >= 0xFFFFFFF0ull) return fail(ctx, TC_INVALID_DATA, "build_index: bad point count");
     hipStream_t st = ctx->stream;
     const uint32_t n32 = (uint32_t)n;
@@ -287,7 +289,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
             for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hb[6 * b + c]); mx[c] = std::fmax(mx[c], hb[6 * b + 3 + c]); }
         for (int c = 0; c < 3; ++c)
             if (!(mn[c] <= mx[c]) || !std::isfinite(mn[c]) || !std::isfinite(mx[c])) { mn[c] = 0.0f; mx[c] = 0.0f; }
-        derive_geom(ix.geom, mn, mx, n, cell_factor);
+        derive_geom(ix.geom, mn, mx, n, cell_factor, min_cell_edge);
     }
     const GridGeom g = ix.geom;
     TileGeom tg{};

@@ -126,7 +126,7 @@ __device__ __forceinline__ void scan_block(const GridView &gv, int cx, int cy, i
     }
 }
 
-template <int L, int BLOCK>
+template <int L, int BLOCK, bool RADIUS>
 __device__ __forceinline__ void normals_point(const GridView &gv, const NormalParams &prm, uint32_t p, bool grow,
                                               uint32_t *__restrict__ overflow, float *__restrict__ out6,
                                               uint32_t *ldsA, uint32_t *ldsB) {
@@ -146,11 +146,27 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     float d[L];
     float tau = INFINITY;
     int R = prm.R0;
+    // radius mode (normals.rs:141-146): neighbours = every record within `radius` except the query
+    // itself; their moments about the query are accumulated in f64 during the same scan
+    // (order independent; the reference's f32 sums in ascending-distance order differ by rounding only)
+    const float r2 = prm.radius * prm.radius;
+    uint32_t cnt_r = 0;
+    double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    bool use_radius = false;
     for (;;) {
 #pragma unroll
         for (int t = 0; t < L; ++t) d[t] = INFINITY;
-        scan_block(gv, cx, cy, cz, R, [&](uint32_t, const float4 &c) {
-            list_insert<L>(d, d2_nc(c.x, c.y, c.z, q.x, q.y, q.z));
+        if (RADIUS) { cnt_r = 0; s1x = s1y = s1z = sxx = sxy = sxz = syy = syz = szz = 0.0; }
+        scan_block(gv, cx, cy, cz, R, [&](uint32_t j, const float4 &c) {
+            const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+            list_insert<L>(d, v);
+            if (RADIUS && j != p && v <= r2) {
+                const double dx = (double)c.x - (double)q.x, dy = (double)c.y - (double)q.y, dz = (double)c.z - (double)q.z;
+                ++cnt_r;
+                s1x += dx; s1y += dy; s1z += dz;
+                sxx = fma(dx, dx, sxx); sxy = fma(dx, dy, sxy); sxz = fma(dx, dz, sxz);
+                syy = fma(dy, dy, syy); syz = fma(dy, dz, syz); szz = fma(dz, dz, szz);
+            }
         });
         tau = d[0];
 #pragma unroll
@@ -158,7 +174,11 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
                             (cz - R <= 0) && (cz + R >= g.gz - 1);
         const float bound = ((float)R + mf - 2e-3f) * g.h;
-        if (covers || tau <= bound * bound) break;
+        // enough radius neighbours (normals.rs:315): the radius set is used, and it is complete iff
+        // the ring covers the radius ball; otherwise the k-NN fallback needs the usual tau rule
+        use_radius = RADIUS && cnt_r >= prm.k;
+        const bool exact = use_radius ? (prm.radius <= bound) : (tau <= bound * bound);
+        if (covers || exact) break;
         if (!grow) {
             uint32_t slot = atomicAdd(&overflow[0], 1u);
             overflow[1 + slot] = p;
@@ -167,6 +187,17 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         ++R;
     }
 
+    float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
+    if (RADIUS && use_radius) {
+        const double nn = (double)cnt_r + 1.0;                     // + the query itself (normals.rs:338-340)
+        const double mx = s1x / nn, my = s1y / nn, mz = s1z / nn;
+        double ex, ey, ez;
+        smallest_eigvec_sym3(sxx / nn - mx * mx, sxy / nn - mx * my, sxz / nn - mx * mz, syy / nn - my * my,
+                             syz / nn - my * mz, szz / nn - mz * mz, ex, ey, ez);
+        const float vx = (float)ex, vy = (float)ey, vz = (float)ez;
+        const float mag = sqrtf(vx * vx + vy * vy + vz * vz);
+        if (mag > 1e-6f) { nrm_x = vx / mag; nrm_y = vy / mag; nrm_z = vz / mag; }
+    } else {
     // phase 2: collect the positions of the K1 nearest records
     uint32_t n_lt = 0;
 #pragma unroll
@@ -199,7 +230,6 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     // normals.rs:147-153: drop self from the k+1 list (or the last entry when self is not in it)
     const int drop_r = (self_r >= 0) ? self_r : (int)cnt - 1;
     const uint32_t npts = cnt;   // (cnt - 1) neighbours + self
-    float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
     if (npts >= 3) {
         // centroid (normals.rs:165-169): sequential f32 adds, neighbours ascending then self
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
@@ -230,6 +260,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         const float mag = sqrtf(vx * vx + vy * vy + vz * vz);          // normals.rs:197-202
         if (mag > 1e-6f) { nrm_x = vx / mag; nrm_y = vy / mag; nrm_z = vz / mag; }
     }
+    }   // k-NN path
     if (prm.orient) {   // normals.rs:208-222
         const float tx = prm.vx - q.x, ty = prm.vy - q.y, tz = prm.vz - q.z;
         const float tn = sqrtf(tx * tx + ty * ty + tz * tz);
@@ -249,7 +280,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
     return lb;
 }
 
-template <int L, int BLOCK>
+template <int L, int BLOCK, bool RADIUS>
 __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, NormalParams prm,
                                                                 uint32_t *__restrict__ overflow,
                                                                 float *__restrict__ out6) {
@@ -258,10 +289,10 @@ __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, Nor
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t p = lb * BLOCK + threadIdx.x;
     if (p >= gv.g.n) return;
-    normals_point<L, BLOCK>(gv, prm, p, false, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+    normals_point<L, BLOCK, RADIUS>(gv, prm, p, false, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
 }
 
-template <int L, int BLOCK>
+template <int L, int BLOCK, bool RADIUS>
 __global__ void __launch_bounds__(BLOCK) normals_overflow_kernel(GridView gv, NormalParams prm,
                                                                  uint32_t *__restrict__ overflow,
                                                                  float *__restrict__ out6) {
@@ -274,10 +305,10 @@ __global__ void __launch_bounds__(BLOCK) normals_overflow_kernel(GridView gv, No
     if (i >= count) return;
     NormalParams p2 = prm;
     p2.R0 = prm.R0 + 1;
-    normals_point<L, BLOCK>(gv, p2, overflow[1 + i], true, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+    normals_point<L, BLOCK, RADIUS>(gv, p2, overflow[1 + i], true, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
 }
 
-template <int L, int BLOCK>
+template <int L, int BLOCK, bool RADIUS = false>
 static void launch_variant(hipStream_t st, const GridView &gv, const NormalParams &prm, uint32_t *overflow, float *out6,
                            tc_context *ctx) {
     const uint32_t n = gv.g.n;
@@ -285,18 +316,17 @@ static void launch_variant(hipStream_t st, const GridView &gv, const NormalParam
     nb = (nb + 7) / 8 * 8;   // xcd_remap needs a multiple of 8
     {
         ProfScope ps(ctx, "normals_knn_pca");
-        hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
+        hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
     }
     {
         ProfScope ps(ctx, "normals_overflow");
-        hipLaunchKernelGGL((normals_overflow_kernel<L, BLOCK>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
+        hipLaunchKernelGGL((normals_overflow_kernel<L, BLOCK, RADIUS>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
     }
 }
 
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg, const float vp[3],
                          float *d_out6) {
     const size_t n = ix.geom.n;
-    if (cfg.has_radius) return fail(ctx, TC_UNSUPPORTED, "radius-based normal estimation is not built yet");
     if (cfg.k_neighbors + 1 > 65) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 64 is not supported by the HIP backend");
     if (tc_status s = ensure(ctx, ctx->overflow, (n + 1) * sizeof(uint32_t))) return s;
     TC_HIP_TRY(ctx, hipMemsetAsync(ctx->overflow.p, 0, sizeof(uint32_t), ctx->stream));
@@ -305,10 +335,19 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal
     prm.orient = cfg.consistent_orientation ? 1 : 0;
     prm.vx = vp[0]; prm.vy = vp[1]; prm.vz = vp[2];
     prm.R0 = 2;
-    prm.has_radius = 0; prm.radius = 0.0f;
+    prm.has_radius = (cfg.has_radius && cfg.radius > 0.0f) ? 1 : 0;
+    prm.radius = prm.has_radius ? cfg.radius : 0.0f;
     const GridView gv = view_of(ix);
     uint32_t *ov = (uint32_t *)ctx->overflow.p;
     const uint32_t K1 = prm.k + 1;
+    if (cfg.has_radius && cfg.radius > 0.0f) {   // radius <= 0 finds nothing (nearest_neighbor.rs:255): pure k-NN fallback
+        if (K1 <= 11)      launch_variant<11, 256, true>(ctx->stream, gv, prm, ov, d_out6, ctx);
+        else if (K1 <= 17) launch_variant<17, 256, true>(ctx->stream, gv, prm, ov, d_out6, ctx);
+        else if (K1 <= 33) launch_variant<33, 128, true>(ctx->stream, gv, prm, ov, d_out6, ctx);
+        else               launch_variant<65, 64, true>(ctx->stream, gv, prm, ov, d_out6, ctx);
+        TC_HIP_TRY(ctx, hipGetLastError());
+        return TC_OK;
+    }
     if (K1 <= 9)       launch_variant<9, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
     else if (K1 <= 11) launch_variant<11, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
     else if (K1 <= 17) launch_variant<17, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
