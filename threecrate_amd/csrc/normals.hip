@@ -27,6 +27,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 namespace tc {
 
@@ -126,7 +128,31 @@ __device__ __forceinline__ void scan_block(const GridView &gv, int cx, int cy, i
     }
 }
 
-template <int L, int BLOCK, bool RADIUS>
+// same visit order, four records per step (four independent gathers in flight per lane).  Used by the
+// overflow pass: it runs few waves, so it is bound by dependent-load latency, not by VALU issue;
+// slots past the end of a span re-read its last record (re-inserting a value that is already in the
+// list would duplicate it, so those slots are fed +inf / skipped by the callback's `valid` flag).
+template <typename F>
+__device__ __forceinline__ void scan_block_wide(const GridView &gv, int cx, int cy, int cz, int R, F &&f) {
+    const GridGeom &g = gv.g;
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
+    const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
+    const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
+    for (int z = z0; z <= z1; ++z) {
+        for (int y = y0; y <= y1; ++y) {
+            const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
+            const uint32_t s = gv.cell_start[row + x0], e = gv.cell_start[row + x1 + 1];
+            for (uint32_t j = s; j < e; j += 4) {
+                const uint32_t last = e - 1;
+                const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
+                const float4 c0 = gv.pts[j], c1 = gv.pts[j1], c2 = gv.pts[j2], c3 = gv.pts[j3];
+                f(j, c0, true); f(j + 1, c1, j + 1 < e); f(j + 2, c2, j + 2 < e); f(j + 3, c3, j + 3 < e);
+            }
+        }
+    }
+}
+
+template <int L, int BLOCK, bool RADIUS, bool WIDE = false>
 __device__ __forceinline__ void normals_point(const GridView &gv, const NormalParams &prm, uint32_t p, bool grow,
                                               uint32_t *__restrict__ overflow, float *__restrict__ out6,
                                               uint32_t *ldsA, uint32_t *ldsB) {
@@ -157,17 +183,19 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
 #pragma unroll
         for (int t = 0; t < L; ++t) d[t] = INFINITY;
         if (RADIUS) { cnt_r = 0; s1x = s1y = s1z = sxx = sxy = sxz = syy = syz = szz = 0.0; }
-        scan_block(gv, cx, cy, cz, R, [&](uint32_t j, const float4 &c) {
-            const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+        auto visit1 = [&](uint32_t j, const float4 &c, bool valid) {
+            const float v = valid ? d2_nc(c.x, c.y, c.z, q.x, q.y, q.z) : INFINITY;
             list_insert<L>(d, v);
-            if (RADIUS && j != p && v <= r2) {
+            if (RADIUS && valid && j != p && v <= r2) {
                 const double dx = (double)c.x - (double)q.x, dy = (double)c.y - (double)q.y, dz = (double)c.z - (double)q.z;
                 ++cnt_r;
                 s1x += dx; s1y += dy; s1z += dz;
                 sxx = fma(dx, dx, sxx); sxy = fma(dx, dy, sxy); sxz = fma(dx, dz, sxz);
                 syy = fma(dy, dy, syy); syz = fma(dy, dz, syz); szz = fma(dz, dz, szz);
             }
-        });
+        };
+        if (WIDE) scan_block_wide(gv, cx, cy, cz, R, visit1);
+        else scan_block(gv, cx, cy, cz, R, [&](uint32_t j, const float4 &c) { visit1(j, c, true); });
         tau = d[0];
 #pragma unroll
         for (int t = 1; t < L; ++t) tau = ((uint32_t)t == prm.k) ? d[t] : tau;
@@ -204,12 +232,14 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     for (int t = 0; t < L; ++t) n_lt += (d[t] < tau) ? 1u : 0u;
     const uint32_t quota = K1 - min(n_lt, K1);
     uint32_t cnt = 0, ties = 0;
-    scan_block(gv, cx, cy, cz, R, [&](uint32_t j, const float4 &c) {
+    auto visit2 = [&](uint32_t j, const float4 &c, bool valid) {
         float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
-        bool take = v < tau;
-        if (!take && v == tau && ties < quota) { take = true; ++ties; }
+        bool take = valid && v < tau;
+        if (valid && !take && v == tau && ties < quota) { take = true; ++ties; }
         if (take && cnt < K1) { ldsA[cnt * BLOCK] = j; ++cnt; }
-    });
+    };
+    if (WIDE) scan_block_wide(gv, cx, cy, cz, R, visit2);
+    else scan_block(gv, cx, cy, cz, R, [&](uint32_t j, const float4 &c) { visit2(j, c, true); });
 
     // rank -> ascending-distance order (ties keep scan order)
     unsigned long long taken_lo = 0ull, taken_hi = 0ull;   // bitset over ranks 0..127
@@ -305,7 +335,7 @@ __global__ void __launch_bounds__(BLOCK) normals_overflow_kernel(GridView gv, No
     if (i >= count) return;
     NormalParams p2 = prm;
     p2.R0 = prm.R0 + 1;
-    normals_point<L, BLOCK, RADIUS>(gv, p2, overflow[1 + i], true, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+    normals_point<L, BLOCK, RADIUS, true>(gv, p2, overflow[1 + i], true, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
 }
 
 template <int L, int BLOCK, bool RADIUS = false>
@@ -355,6 +385,12 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal
     else if (K1 <= 33) launch_variant<33, 128>(ctx->stream, gv, prm, ov, d_out6, ctx);
     else               launch_variant<65, 64>(ctx->stream, gv, prm, ov, d_out6, ctx);
     TC_HIP_TRY(ctx, hipGetLastError());
+    if (getenv("TC_DEBUG_OVERFLOW")) {
+        uint32_t cnt = 0;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(&cnt, ctx->overflow.p, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[tc] normals overflow list: %u of %zu points (h=%g, grid %dx%dx%d)\n", cnt, n, ix.geom.h, ix.geom.gx, ix.geom.gy, ix.geom.gz);
+    }
     return TC_OK;
 }
 
