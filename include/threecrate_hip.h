@@ -198,6 +198,8 @@ tc_status   tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result
 void        tc_icp_shard_destroy(tc_icp_shard *s);
 
 /* ---- profiling ---- */
+/* on: 0 = off, 1 = hipEvents around every kernel, 2 = only around every 4th launch of the dominant
+   kernel (icp_correspond_reduce): ~1 % overhead, used inside bench.py's timed region */
 void   tc_profile_enable(tc_context *ctx, int on);
 void   tc_profile_reset(tc_context *ctx);
 size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap);

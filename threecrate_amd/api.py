@@ -126,7 +126,8 @@ class GpuContext:
 
     # ---- profiling ----
     def profile_enable(self, on=True):
-        self._L.tc_profile_enable(self._h, 1 if on else 0)
+        """False/0 off, True/1 every kernel, 2 = sampled events on the dominant kernel only."""
+        self._L.tc_profile_enable(self._h, int(on))
 
     def profile_reset(self):
         self._L.tc_profile_reset(self._h)

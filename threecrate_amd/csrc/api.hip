@@ -34,8 +34,9 @@ tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes) {
     return TC_OK;
 }
 
-ProfScope::ProfScope(tc_context *c, const char *name) : ctx(c) {
+ProfScope::ProfScope(tc_context *c, const char *name, bool dominant) : ctx(c) {
     if (!ctx->profiling) return;
+    if (ctx->profiling == 2 && (!dominant || (ctx->prof_tick++ & 3u) != 0)) return;
     for (size_t i = 0; i < ctx->timers.size(); ++i)
         if (ctx->timers[i].name == name) { idx = (int)i; break; }
     if (idx < 0) { ctx->timers.push_back(KernelTimer{name, {}, 0, 0.0}); idx = (int)ctx->timers.size() - 1; }
@@ -305,7 +306,7 @@ tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp
 }
 
 // ---- profiling ------------------------------------------------------------------------------
-void tc_profile_enable(tc_context *ctx, int on) { if (ctx) ctx->profiling = on != 0; }
+void tc_profile_enable(tc_context *ctx, int on) { if (ctx) { ctx->profiling = on; ctx->prof_tick = 0; } }
 
 static void profile_collect(tc_context *ctx) {
     (void)hipStreamSynchronize(ctx->stream);

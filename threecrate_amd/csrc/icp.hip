@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 
 namespace tc {
 
@@ -49,6 +50,13 @@ __device__ __forceinline__ uint32_t xcd_remap_icp(uint32_t b, uint32_t nb) {
 __device__ __forceinline__ float outside_d2(float x, float y, float z, float qx, float qy, float qz) {
     const float ex = x - qx, ey = y - qy, ez = z - qz;
     return (ex * ex + ey * ey + ez * ez) * 0.9999f;
+}
+
+// squared distance from q to the box of cell index c along one axis, shaved by the cell-assignment
+// fuzz (conservative: never larger than the true gap)
+__device__ __forceinline__ float axis_gap(float q, float mn, float h, int c) {
+    const float lo = mn + (float)c * h, hi = lo + h;
+    return fmaxf(fmaxf(lo - q, q - hi) - 2e-3f * h, 0.0f);
 }
 
 // exact nearest record of the target grid to (x, y, z) straight from HBM/L2 (no staging);
@@ -82,90 +90,47 @@ __device__ __forceinline__ void nn_search_global(const GridView &gv, float x, fl
         const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
         const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
         const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
+        // ball pruning: only cells whose box is within sqrt(best) of the query can improve the match.
+        // The ball intersected with the grid box is convex and contains clamp(q), so once a whole
+        // shell misses it every farther shell does too.
+        bool touched = (R == 1);
         for (int zz = z0; zz <= z1; ++zz) {
+            const float gz = axis_gap(z, g.minz, g.h, zz);
             for (int yy = y0; yy <= y1; ++yy) {
+                const float gy = axis_gap(y, g.miny, g.h, yy);
+                const float rg = gy * gy + gz * gz;
+                if (R > 1 && rg > best) continue;
                 const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
                 const bool edge = (zz == cz - R) || (zz == cz + R) || (yy == cy - R) || (yy == cy + R);
-                if (R == 1 || edge) {
+                if (R == 1) {
                     span(row, x0, x1);
+                } else if (edge) {
+                    // tighten the x window to the cells the ball can reach
+                    int xa = x0, xb = x1;
+                    while (xa <= xb && rg + axis_gap(x, g.minx, g.h, xa) * axis_gap(x, g.minx, g.h, xa) > best) ++xa;
+                    while (xb >= xa && rg + axis_gap(x, g.minx, g.h, xb) * axis_gap(x, g.minx, g.h, xb) > best) --xb;
+                    if (xa <= xb) { touched = true; span(row, xa, xb); }
                 } else {   // interior rows of a shell: only the two end cells are new
-                    if (cx - R >= 0) span(row, cx - R, cx - R);
-                    if (cx + R <= g.gx - 1) span(row, cx + R, cx + R);
+                    if (cx - R >= 0) {
+                        const float gx = axis_gap(x, g.minx, g.h, cx - R);
+                        if (rg + gx * gx <= best) { touched = true; span(row, cx - R, cx - R); }
+                    }
+                    if (cx + R <= g.gx - 1) {
+                        const float gx = axis_gap(x, g.minx, g.h, cx + R);
+                        if (rg + gx * gx <= best) { touched = true; span(row, cx + R, cx + R); }
+                    }
                 }
             }
         }
         const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
                             (cz - R <= 0) && (cz + R >= g.gz - 1);
         const float bound = ((float)R + mf - 2e-3f) * g.h;
-        if (covers || best <= bound * bound + out2) break;
+        if (covers || !touched || best <= bound * bound + out2) break;
         if (max_dist >= 0.0f && bound > max_dist) break;   // everything unscanned would be rejected
     }
 }
 
-// Wave-cooperative continuation for the (rare) lanes whose ring-1 answer is not provably exact:
-// the lanes are served one after the other, and for each of them all 64 lanes scan the cells of
-// the ring-R shell in parallel (one cell per lane and step), then fold (d2, position) with a
-// wave min.  ~3 dependent memory round trips per ring instead of one per row and candidate.
-// Tie rule = the sequential scan's: an earlier ring wins, inside a shell the lowest cell-sorted
-// position wins.
-__device__ __forceinline__ void nn_refine_wave(const GridView &gv, bool need, float x, float y, float z, int cx, int cy,
-                                               int cz, float mf, float out2, float max_dist, float &best, uint32_t &bestj) {
-    const GridGeom &g = gv.g;
-    const int lane = threadIdx.x & 63;
-    unsigned long long mask = __ballot(need);
-    while (mask) {
-        const int l = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const float qx = __shfl(x, l), qy = __shfl(y, l), qz = __shfl(z, l), qmf = __shfl(mf, l), qo2 = __shfl(out2, l);
-        const int qcx = __shfl(cx, l), qcy = __shfl(cy, l), qcz = __shfl(cz, l);
-        float wb = __shfl(best, l);
-        uint32_t wj = __shfl(bestj, l);
-        for (int R = 2;; ++R) {
-            // enumerate ONLY the shell cells of ring R: two full z faces, two y faces without the z
-            // rims, two x faces without the y / z rims: 24 R^2 + 2 cells
-            const int W = 2 * R + 1, V = W - 2;
-            const int nz = 2 * W * W, ny = 2 * W * V, nx = 2 * V * V, nshell = nz + ny + nx;
-            float lb = INFINITY; uint32_t lj = 0xFFFFFFFFu;
-            for (int idx = lane; idx < nshell; idx += 64) {
-                int ox, oy, oz;
-                if (idx < nz) {
-                    const int f = idx / (W * W), r = idx - f * W * W;
-                    oz = f ? R : -R; oy = r / W - R; ox = r - (r / W) * W - R;
-                } else if (idx < nz + ny) {
-                    const int i2 = idx - nz, f = i2 / (W * V), r = i2 - f * W * V;
-                    oy = f ? R : -R; oz = r / W - (R - 1); ox = r - (r / W) * W - R;
-                } else {
-                    const int i3 = idx - nz - ny, f = i3 / (V * V), r = i3 - f * V * V;
-                    ox = f ? R : -R; oz = r / V - (R - 1); oy = r - (r / V) * V - (R - 1);
-                }
-                const int ccx = qcx + ox, ccy = qcy + oy, ccz = qcz + oz;
-                if (ccx < 0 || ccx >= g.gx || ccy < 0 || ccy >= g.gy || ccz < 0 || ccz >= g.gz) continue;
-                const uint32_t c = ((uint32_t)ccz * g.gy + ccy) * g.gx + ccx;
-                const uint32_t s0 = gv.cell_start[c], e0 = gv.cell_start[c + 1];
-                for (uint32_t j = s0; j < e0; ++j) {
-                    const float4 p = gv.pts[j];
-                    const float v = d2_nc(p.x, p.y, p.z, qx, qy, qz);
-                    if (v < lb || (v == lb && j < lj)) { lb = v; lj = j; }
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(lb, o);
-                const uint32_t oj = __shfl_xor(lj, o);
-                if (ob < lb || (ob == lb && oj < lj)) { lb = ob; lj = oj; }
-            }
-            if (lb < wb || (lb == wb && lj < wj)) { wb = lb; wj = lj; }
-            const bool covers = (qcx - R <= 0) && (qcx + R >= g.gx - 1) && (qcy - R <= 0) && (qcy + R >= g.gy - 1) &&
-                                (qcz - R <= 0) && (qcz + R >= g.gz - 1);
-            const float bound = ((float)R + qmf - 2e-3f) * g.h;
-            if (covers || wb <= bound * bound + qo2) break;
-            if (max_dist >= 0.0f && bound > max_dist) break;
-        }
-        if (lane == l) { best = wb; bestj = wj; }
-    }
-}
-
-template <int NACC>
+template <int NACC, int NW = kIcpBlock / 64>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *__restrict__ out_row, double (*sm)[TC_ICP_SUMS_STRIDE]) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
@@ -182,7 +147,10 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *
     __syncthreads();
     if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
         double s = 0.0;
-        if (threadIdx.x < NACC) s = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+        if (threadIdx.x < NACC) {
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) s += sm[w2][threadIdx.x];
+        }
         out_row[threadIdx.x] = s;
     }
 }
@@ -298,10 +266,48 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     refine = !(covers || best <= bound * bound + out2 || (max_dist >= 0.0f && bound > max_dist));
 }
 
+// per-pair terms -> per-lane f32 accumulators (shared by the main and the refine kernel)
+template <bool P2PLANE, int NACC>
+__device__ __forceinline__ void accumulate_pair(const GridGeom &g, float (&acc)[NACC], float x, float y, float z,
+                                                const float4 &c, const float4 &n) {
+    if (P2PLANE) {
+        // registration.rs:417-427 in f32: c = s x n ; a = [c, n] ; b = n . (d - s)
+        const float a[6] = {y * n.z - z * n.y, z * n.x - x * n.z, x * n.y - y * n.x, n.x, n.y, n.z};
+        const float dx = c.x - x, dy = c.y - y, dz = c.z - z;
+        const float b = n.x * dx + n.y * dy + n.z * dz;
+        int o = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = r; cc < 6; ++cc) { acc[o] += a[r] * a[cc]; ++o; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * b;
+        acc[27] += b * b;
+        acc[28] += 1.0f;
+    } else {
+        // shifted by the target bbox centre so that H = sum s q^T - n ms mq^T does not cancel
+        const float sx = x - g.cx, sy = y - g.cy, sz = z - g.cz;
+        const float tx = c.x - g.cx, ty = c.y - g.cy, tz = c.z - g.cz;
+        acc[0] += sx; acc[1] += sy; acc[2] += sz;
+        acc[3] += tx; acc[4] += ty; acc[5] += tz;
+        acc[6] += sx * tx;  acc[7] += sx * ty;  acc[8] += sx * tz;
+        acc[9] += sy * tx;  acc[10] += sy * ty; acc[11] += sy * tz;
+        acc[12] += sz * tx; acc[13] += sz * ty; acc[14] += sz * tz;
+        const float ex = x - c.x, ey = y - c.y, ez = z - c.z;          // registration.rs:214
+        acc[15] += ex * ex + ey * ey + ez * ez;
+        acc[16] += 1.0f;
+    }
+}
+
+// Main pass: ring-1 search (warm-start pruned).  Lanes whose ring-1 answer is not provably exact
+// (Poisson tail, queries outside the target's box) are NOT finished here: they go to a list served
+// by icp_refine_kernel in dense waves.  Keeping the ring>=2 code out of this kernel keeps its
+// register count (=> waves per SIMD) low; the kernel is bound by loads in flight.
 template <bool P2PLANE>
 __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
-    const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, double *__restrict__ partials, int dbg) {
+    const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
+    double *__restrict__ partials, int dbg) {
     constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
     if (st->done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
@@ -319,73 +325,176 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     const uint32_t end = min(beg + chunk, ns);
     for (uint32_t jb = beg; jb < end; jb += kIcpBlock) {
         const uint32_t j = jb + threadIdx.x;
-        const bool active = j < end;
-        float x = 0.f, y = 0.f, z = 0.f, best = INFINITY, mf = 0.f, out2 = 0.f;
-        uint32_t bestg = 0xFFFFFFFFu;
-        int cx = 0, cy = 0, cz = 0;
-        bool refine = false;
-        if (active) {
-            const float4 s = src[j];
-            iso_apply(q, t, s.x, s.y, s.z, x, y, z);
-            float ub2 = INFINITY;
-            if (warm) {
-                const uint32_t pj = corr_pos[j];
-                if (pj != 0xFFFFFFFFu) {
-                    const float4 p = tgt.pts[pj];
-                    ub2 = d2_nc(p.x, p.y, p.z, x, y, z);
-                }
+        if (j >= end) continue;
+        const float4 s = src[j];
+        float x, y, z;
+        iso_apply(q, t, s.x, s.y, s.z, x, y, z);
+        float ub2 = INFINITY;
+        if (warm) {
+            const uint32_t pj = corr_pos[j];
+            if (pj != 0xFFFFFFFFu) {
+                const float4 p = tgt.pts[pj];
+                ub2 = d2_nc(p.x, p.y, p.z, x, y, z);
             }
-            if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f);   // farther matches are rejected anyway
-            nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, cx, cy, cz, mf, out2, max_dist);
         }
-        // ring >= 2 continuation: a few lanes -> served one by one by the whole wave; many lanes
-        // (e.g. a wave of queries outside the target's bounding box) -> every lane walks its own shell
-        if (__popcll(__ballot(refine)) > 6) {
-            if (refine) nn_search_global(tgt, x, y, z, max_dist, 2, best, bestg);
-        } else {
-            nn_refine_wave(tgt, refine, x, y, z, cx, cy, cz, mf, out2, max_dist, best, bestg);
+        if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f);   // farther matches are rejected anyway
+        float best, mf, out2;
+        uint32_t bestg;
+        int cx, cy, cz;
+        bool refine;
+        nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, cx, cy, cz, mf, out2, max_dist);
+        if (refine) {
+            const uint32_t slot = atomicAdd(&rlist[0], 1u);
+            rlist[1 + slot] = j;
+            continue;
         }
-        if (active) {
-            bool valid = bestg != 0xFFFFFFFFu;
-            if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
-            corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
-            if (valid) {
-                const float4 c = tgt.pts[bestg];
-                if (P2PLANE) {
-                    const float4 n = tgt_nrm[bestg];
-                    // registration.rs:417-427 in f32: c = s x n ; a = [c, n] ; b = n . (d - s)
-                    const float a[6] = {y * n.z - z * n.y, z * n.x - x * n.z, x * n.y - y * n.x, n.x, n.y, n.z};
-                    const float dx = c.x - x, dy = c.y - y, dz = c.z - z;
-                    const float b = n.x * dx + n.y * dy + n.z * dz;
-                    int o = 0;
-#pragma unroll
-                    for (int r = 0; r < 6; ++r)
-#pragma unroll
-                        for (int cc = r; cc < 6; ++cc) { acc[o] += a[r] * a[cc]; ++o; }
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * b;
-                    acc[27] += b * b;
-                    acc[28] += 1.0f;
-                } else {
-                    // shifted by the target bbox centre so that H = sum s q^T - n ms mq^T does not cancel
-                    const float sx = x - g.cx, sy = y - g.cy, sz = z - g.cz;
-                    const float tx = c.x - g.cx, ty = c.y - g.cy, tz = c.z - g.cz;
-                    acc[0] += sx; acc[1] += sy; acc[2] += sz;
-                    acc[3] += tx; acc[4] += ty; acc[5] += tz;
-                    acc[6] += sx * tx;  acc[7] += sx * ty;  acc[8] += sx * tz;
-                    acc[9] += sy * tx;  acc[10] += sy * ty; acc[11] += sy * tz;
-                    acc[12] += sz * tx; acc[13] += sz * ty; acc[14] += sz * tz;
-                    const float ex = x - c.x, ey = y - c.y, ez = z - c.z;          // registration.rs:214
-                    acc[15] += ex * ex + ey * ey + ez * ez;
-                    acc[16] += 1.0f;
-                }
-            }
+        bool valid = bestg != 0xFFFFFFFFu;
+        if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
+        corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
+        if (valid) {
+            const float4 c = tgt.pts[bestg];
+            float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P2PLANE) n = tgt_nrm[bestg];
+            accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, c, n);
         }
     }
     double dacc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) dacc[i] = (double)acc[i];
     block_reduce_store<NACC>(dacc, partials + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE, red);
+}
+
+// Refine pass: the listed queries get the full ring search, kRG lanes per query: ring 1 = one cell
+// per lane, farther rings = the shell cells that the ball |p - q| <= best can reach (ball pruning,
+// stop as soon as a whole shell misses the ball).  ~2-3 dependent memory round trips per ring and
+// query instead of one per row, and thousands of waves in flight.  Per-block sums go to the
+// partial rows after the main pass's rows.
+constexpr int kRefineBlocks = 128;
+constexpr int kRefineThreads = 1024;
+constexpr int kRG = 32;                     // lanes per query
+
+__device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = kRG / 2; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+template <bool P2PLANE>
+__global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
+    GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src,
+    const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, const uint32_t *__restrict__ rlist,
+    double *__restrict__ partial_rows) {
+    constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
+    if (st->done) return;
+    __shared__ double red[kRefineThreads / 64][TC_ICP_SUMS_STRIDE];
+    const GridGeom &g = tgt.g;
+    const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
+    const float t[3] = {st->t[0], st->t[1], st->t[2]};
+    const float max_dist = st->max_dist;
+    const bool warm = st->iterations > 0;
+    const uint32_t count = rlist[0];
+    if ((uint32_t)blockIdx.x * (kRefineThreads / kRG) >= count) {      // no query for this block: zero row, done
+        if (threadIdx.x < TC_ICP_SUMS_STRIDE) partial_rows[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = 0.0;
+        return;
+    }
+    const int lg = threadIdx.x & (kRG - 1);
+    const uint32_t group = (blockIdx.x * kRefineThreads + threadIdx.x) / kRG, ngroups = gridDim.x * kRefineThreads / kRG;
+    const unsigned long long gmask = (kRG == 64) ? ~0ull : (((1ull << kRG) - 1ull) << ((threadIdx.x & 63) & ~(kRG - 1)));
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+    for (uint32_t i = group; i < count; i += ngroups) {
+        const uint32_t j = rlist[1 + i];
+        const float4 s = src[j];
+        float x, y, z;
+        iso_apply(q, t, s.x, s.y, s.z, x, y, z);
+        const float qx = fminf(fmaxf(x, g.minx), g.maxx), qy = fminf(fmaxf(y, g.miny), g.maxy),
+                    qz = fminf(fmaxf(z, g.minz), g.maxz);
+        const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx), cy = cell_coord(qy, g.miny, g.inv_h, g.gy),
+                  cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
+        const float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy,
+                    fz = (qz - g.minz) * g.inv_h - (float)cz;
+        const float mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
+        const float out2 = outside_d2(x, y, z, qx, qy, qz);
+        // warm start: the previous match is a real candidate
+        unsigned long long bestkey = ~0ull;
+        if (warm) {
+            const uint32_t pj = corr_pos[j];
+            if (pj != 0xFFFFFFFFu) {
+                const float4 p = tgt.pts[pj];
+                bestkey = ((unsigned long long)__float_as_uint(d2_nc(p.x, p.y, p.z, x, y, z)) << 32) | pj;
+            }
+        }
+        for (int R = 1;; ++R) {
+            const int W = 2 * R + 1, V = W - 2;
+            const int nz = 2 * W * W, ny = 2 * W * V, nx = 2 * V * V;
+            const int ncell = (R == 1) ? 27 : nz + ny + nx;
+            const float bestd = __uint_as_float((uint32_t)(bestkey >> 32));     // +inf / NaN pattern when empty
+            const bool have = bestkey != ~0ull;
+            unsigned long long lk = ~0ull;
+            bool touched = false;
+            for (int idx = lg; idx < ncell; idx += kRG) {
+                int ox, oy, oz;
+                if (R == 1) {
+                    oz = idx / 9 - 1; oy = (idx - (idx / 9) * 9) / 3 - 1; ox = idx - (idx / 3) * 3 - 1;
+                } else if (idx < nz) {
+                    const int f = idx / (W * W), r = idx - f * W * W;
+                    oz = f ? R : -R; oy = r / W - R; ox = r - (r / W) * W - R;
+                } else if (idx < nz + ny) {
+                    const int i2 = idx - nz, f = i2 / (W * V), r = i2 - f * W * V;
+                    oy = f ? R : -R; oz = r / W - (R - 1); ox = r - (r / W) * W - R;
+                } else {
+                    const int i3 = idx - nz - ny, f = i3 / (V * V), r = i3 - f * V * V;
+                    ox = f ? R : -R; oz = r / V - (R - 1); oy = r - (r / V) * V - (R - 1);
+                }
+                const int ccx = cx + ox, ccy = cy + oy, ccz = cz + oz;
+                if (ccx < 0 || ccx >= g.gx || ccy < 0 || ccy >= g.gy || ccz < 0 || ccz >= g.gz) continue;
+                if (have) {
+                    const float gx = axis_gap(x, g.minx, g.h, ccx), gy = axis_gap(y, g.miny, g.h, ccy),
+                                gz = axis_gap(z, g.minz, g.h, ccz);
+                    if (gx * gx + gy * gy + gz * gz > bestd) continue;       // outside the ball
+                }
+                touched = true;
+                const uint32_t c = ((uint32_t)ccz * g.gy + ccy) * g.gx + ccx;
+                const uint32_t s0 = tgt.cell_start[c], e0 = tgt.cell_start[c + 1];
+                for (uint32_t jj = s0; jj < e0; ++jj) {
+                    const float4 p = tgt.pts[jj];
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d2_nc(p.x, p.y, p.z, x, y, z)) << 32) | jj;
+                    lk = key < lk ? key : lk;
+                }
+            }
+            lk = group_min_u64(lk);
+            bestkey = lk < bestkey ? lk : bestkey;
+            const bool any_touched = (__ballot(touched) & gmask) != 0ull;
+            const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
+                                (cz - R <= 0) && (cz + R >= g.gz - 1);
+            const float bound = ((float)R + mf - 2e-3f) * g.h;
+            const float bd = __uint_as_float((uint32_t)(bestkey >> 32));
+            if (covers || (R > 1 && !any_touched)) break;
+            if (bestkey != ~0ull && bd <= bound * bound + out2) break;
+            if (max_dist >= 0.0f && bound > max_dist) break;   // everything unscanned would be rejected
+        }
+        if (lg == 0) {
+            const float best = __uint_as_float((uint32_t)(bestkey >> 32));
+            const uint32_t bestg = (uint32_t)bestkey;
+            bool valid = bestkey != ~0ull;
+            if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);
+            corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
+            if (valid) {
+                const float4 c = tgt.pts[bestg];
+                float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (P2PLANE) n = tgt_nrm[bestg];
+                accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, c, n);
+            }
+        }
+    }
+    double dacc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) dacc[i] = (double)acc[i];
+    block_reduce_store<NACC, kRefineThreads / 64>(dacc, partial_rows + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE, red);
 }
 
 // ICPResult.correspondences (registration.rs:22-23): matched ORIGINAL target index per ORIGINAL
@@ -595,7 +704,7 @@ __device__ void finish_iteration(IcpState *st, float mse, uint32_t n) {
 
 template <bool P2PLANE>
 __global__ void __launch_bounds__(1024) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
-                                                           IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply) {
+                                                           IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply, uint32_t *__restrict__ rlist) {
     if (st->done) return;
     __shared__ double sm[32][TC_ICP_SUMS_STRIDE];
     if (do_sum) {
@@ -619,6 +728,7 @@ __global__ void __launch_bounds__(1024) icp_finalize_kernel(const double *__rest
             for (int gi = 0; gi < 32; ++gi) tot += sm[gi][threadIdx.x];
             st->sums[threadIdx.x] = tot;
         }
+        if (threadIdx.x == 0 && rlist) rlist[0] = 0;     // refine list consumed: ready for the next iteration
         __syncthreads();
     }
     if (!do_apply || threadIdx.x != 0) return;
@@ -708,27 +818,38 @@ static TileGeom plan_tiles(const GridGeom &g, size_t ns) {
 }
 
 static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, const float4 *nrm, const float4 *src,
-                             uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr_pos, double *partials,
-                             bool do_sum, bool do_apply, bool do_reduce) {
+                             uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr_pos, uint32_t *rlist,
+                             double *partials, bool do_sum, bool do_apply, bool do_reduce) {
     hipStream_t s = ctx->stream;
     static const int dbg = getenv("TC_DEBUG") ? atoi(getenv("TC_DEBUG")) : 0;
+    double *refine_rows = partials + (size_t)l.nblocks * TC_ICP_SUMS_STRIDE;
     if (do_reduce) {
-        ProfScope ps(ctx, p2plane ? "icp_correspond_reduce_p2plane" : "icp_correspond_reduce_p2p");
+        {
+            ProfScope ps(ctx, p2plane ? "icp_correspond_reduce_p2plane" : "icp_correspond_reduce_p2p", true);
+            if (p2plane)
+                hipLaunchKernelGGL(icp_correspond_reduce_kernel<true>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
+                                   l.chunk, st, corr_pos, rlist, partials, dbg);
+            else
+                hipLaunchKernelGGL(icp_correspond_reduce_kernel<false>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
+                                   l.chunk, st, corr_pos, rlist, partials, dbg);
+        }
+        ProfScope ps(ctx, "icp_refine");
         if (p2plane)
-            hipLaunchKernelGGL(icp_correspond_reduce_kernel<true>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
-                               l.chunk, st, corr_pos, partials, dbg);
+            hipLaunchKernelGGL(icp_refine_kernel<true>, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist,
+                               refine_rows);
         else
-            hipLaunchKernelGGL(icp_correspond_reduce_kernel<false>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
-                               l.chunk, st, corr_pos, partials, dbg);
+            hipLaunchKernelGGL(icp_refine_kernel<false>, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist,
+                               refine_rows);
     }
     if (do_sum || do_apply) {
         ProfScope ps(ctx, "icp_finalize");
+        const uint32_t rows = l.nblocks + kRefineBlocks;
         if (p2plane)
-            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(1024), 0, s, partials, l.nblocks, st, tv.g, do_sum ? 1 : 0,
-                               (do_apply && !(dbg & 32)) ? 1 : 0);
+            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(1024), 0, s, partials, rows, st, tv.g, do_sum ? 1 : 0,
+                               (do_apply && !(dbg & 32)) ? 1 : 0, do_sum ? rlist : nullptr);
         else
-            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(1024), 0, s, partials, l.nblocks, st, tv.g, do_sum ? 1 : 0,
-                               (do_apply && !(dbg & 32)) ? 1 : 0);
+            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(1024), 0, s, partials, rows, st, tv.g, do_sum ? 1 : 0,
+                               (do_apply && !(dbg & 32)) ? 1 : 0, do_sum ? rlist : nullptr);
     }
 }
 
@@ -760,8 +881,9 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     out.tg = plan_tiles(ctx->tgt_index.geom, ns);
     if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &ctx->tgt_index.geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
     out.l = plan_launch(ns);
-    if (tc_status s = ensure(ctx, ctx->partials, (size_t)kMaxPartialBlocks * TC_ICP_SUMS_STRIDE * sizeof(double))) return s;
-    if (tc_status s = ensure(ctx, ctx->corr, 2 * ns * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ctx->partials, ((size_t)(kMaxPartialBlocks + kRefineBlocks) * TC_ICP_SUMS_STRIDE + 2) * sizeof(double))) return s;
+    if (tc_status s = ensure(ctx, ctx->corr, (3 * ns + 2) * sizeof(uint32_t))) return s;   // corr | corr_pos | refine list
+    TC_HIP_TRY(ctx, hipMemsetAsync((uint32_t *)ctx->corr.p + 2 * ns, 0, sizeof(uint32_t), ctx->stream));
     out.tv = view_of(ctx->tgt_index);
     return TC_OK;
 }
@@ -793,7 +915,7 @@ tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, 
             if (flags[c - 2]) { stopped = true; break; }
         }
         for (size_t k = 0; k < kChunk && it < max_iters; ++k, ++it)
-            launch_iteration(ctx, p2plane, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, partials, true, true, true);
+            launch_iteration(ctx, p2plane, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true);
         if (c < max_flags) {
             flags[c] = 0;
             TC_HIP_TRY(ctx, hipMemcpyAsync(&flags[c], &dstate->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -889,8 +1011,8 @@ tc_status tc_icp_shard_reduce(tc_icp_shard *s) {
     tc_context *ctx = s->ctx;
     uint32_t *corr = (uint32_t *)ctx->corr.p;
     tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
-                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr + s->ns, (double *)ctx->partials.p, true, false,
-                         true);
+                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr + s->ns, corr + 2 * s->ns,
+                         (double *)ctx->partials.p, true, false, true);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
 }
@@ -899,8 +1021,8 @@ tc_status tc_icp_shard_apply(tc_icp_shard *s) {
     tc_context *ctx = s->ctx;
     uint32_t *corr = (uint32_t *)ctx->corr.p;
     tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
-                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr + s->ns, (double *)ctx->partials.p, false, true,
-                         false);
+                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr + s->ns, corr + 2 * s->ns,
+                         (double *)ctx->partials.p, false, true, false);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
 }

@@ -116,7 +116,8 @@ struct tc_context {
     hipStream_t stream = nullptr;
     bool own_stream = true;
     std::string last_error;
-    bool profiling = false;
+    int profiling = 0;          // 0 off, 1 every kernel, 2 only the dominant kernel, every 4th launch
+    uint32_t prof_tick = 0;
     std::vector<tc::KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
 
@@ -150,7 +151,7 @@ tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes);
 // profiling scope: records hipEvents around one kernel launch on ctx->stream
 struct ProfScope {
     tc_context *ctx; int idx = -1; hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(tc_context *c, const char *name);
+    ProfScope(tc_context *c, const char *name, bool dominant = false);
     ~ProfScope();
 };
 
