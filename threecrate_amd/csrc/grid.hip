@@ -4,7 +4,8 @@
 //   bbox_kernel      : per-block min/max partials, folded on the host (order independent)
 //   cell_hist_kernel : cell id per point + histogram
 //   scan_*           : exclusive prefix sum of the histogram -> cell_start
-//   scatter_kernel   : counting-sort scatter (atomic slot order, not yet deterministic)
+//   scatter_kernel   : counting-sort scatter by the arrival rank the histogram atomics returned
+//                      (atomic arrival order, not yet deterministic)
 //   rank_gather_kernel : stable re-rank inside each cell by original index -> deterministic
 //                      cell-sorted float4 {x, y, z, original-index bits}
 // HBM traffic per point: 12 B read (AoS xyz) + 4 B cell id + 16 B sorted record + 4 B slot
@@ -67,7 +68,8 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
 // isometry in *st (ICP source ordering by target cell); the stored record keeps the raw point.
 __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g,
                                                        const IcpState *__restrict__ st, TileGeom tg, int tile_major,
-                                                       uint32_t *__restrict__ cell_of, uint32_t *__restrict__ hist) {
+                                                       uint32_t *__restrict__ cell_of, uint32_t *__restrict__ hist,
+                                                       uint32_t *__restrict__ arrival) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
@@ -82,7 +84,9 @@ __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict_
     int iz = cell_coord(z, g.minz, g.inv_h, g.gz);
     uint32_t c = tile_major ? tile_major_id(tg, ix, iy, iz) : ((uint32_t)iz * g.gy + iy) * g.gx + ix;
     cell_of[i] = c;
-    atomicAdd(&hist[c], 1u);
+    // the returned count is this point's arrival rank inside its cell: the scatter pass then needs
+    // no second round of atomics
+    arrival[i] = atomicAdd(&hist[c], 1u);
 }
 
 constexpr int kScanItems = 8;
@@ -169,12 +173,10 @@ __global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *
 
 __global__ void __launch_bounds__(256) scatter_kernel(const uint32_t *__restrict__ cell_of, uint32_t n,
                                                      const uint32_t *__restrict__ cell_start,
-                                                     uint32_t *__restrict__ fill, uint32_t *__restrict__ slot) {
+                                                     const uint32_t *__restrict__ arrival, uint32_t *__restrict__ slot) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t c = cell_of[i];
-    uint32_t pos = cell_start[c] + atomicAdd(&fill[c], 1u);
-    slot[pos] = i;
+    slot[cell_start[cell_of[i]] + arrival[i]] = i;
 }
 
 // stable re-rank inside the cell (ascending original index) + gather into the sorted record array
@@ -305,6 +307,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     if (tc_status s = ensure(ctx, ix.pts, n * sizeof(float4))) return s;
     if (tc_status s = ensure(ctx, ix.cell_of, n * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, ix.slot, n * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.arrival, n * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, ix.fill, (size_t)nkeys * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, ix.cell_start, ((size_t)nkeys + 1) * sizeof(uint32_t))) return s;
     const uint32_t nscan = (nkeys + kScanTile - 1) / kScanTile;
@@ -314,7 +317,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     {
         ProfScope ps(ctx, "cell_hist");
         hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0,
-                           (uint32_t *)ix.cell_of.p, (uint32_t *)ix.fill.p);
+                           (uint32_t *)ix.cell_of.p, (uint32_t *)ix.fill.p, (uint32_t *)ix.arrival.p);
     }
     {
         ProfScope ps(ctx, "cell_scan");
@@ -324,11 +327,10 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, (const uint32_t *)ix.fill.p, nkeys,
                            (const uint32_t *)ix.blocksum.p, (uint32_t *)ix.cell_start.p);
     }
-    TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)nkeys * sizeof(uint32_t), st));
     {
         ProfScope ps(ctx, "cell_scatter");
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)ix.cell_of.p, n32,
-                           (const uint32_t *)ix.cell_start.p, (uint32_t *)ix.fill.p, (uint32_t *)ix.slot.p);
+                           (const uint32_t *)ix.cell_start.p, (const uint32_t *)ix.arrival.p, (uint32_t *)ix.slot.p);
     }
     {
         ProfScope ps(ctx, "cell_rank_gather");

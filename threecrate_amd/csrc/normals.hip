@@ -13,9 +13,10 @@
 //            one v_med3_f32 per slot, all slots independent.
 //   exactness tau = (k+1)-th smallest d2 is final iff tau <= (R*h + m)^2, m = distance from
 //            the query to the nearest face of its own cell (every unscanned point is at least
-//            R*h + m away).  Lanes that fail go to an overflow list handled by a second
-//            launch that grows R (keeps the main launch free of per-lane ring loops).
-//   phase 2  rescan, append the record positions with d2 <= tau to a per-lane LDS list
+//            R*h + m away).  Lanes that fail (grid-boundary points, Poisson tail: ~1 %) continue
+//            in place with the next shell, ball-pruned: only cells within sqrt(current tau) of the
+//            query are visited, and a shell that misses that ball ends the search.
+//   phase 2  rescan the cells within sqrt(tau), append the record positions with d2 <= tau to a per-lane LDS list
 //            (ties at tau: lowest cell-sorted position first), rank them against the register
 //            list -> neighbours in ascending-distance order, exactly the reference's order.
 //   epilogue f32 centroid / covariance in the reference's operation order (bit-identical to
@@ -128,34 +129,53 @@ __device__ __forceinline__ void scan_block(const GridView &gv, int cx, int cy, i
     }
 }
 
-// same visit order, four records per step (four independent gathers in flight per lane).  Used by the
-// overflow pass: it runs few waves, so it is bound by dependent-load latency, not by VALU issue;
-// slots past the end of a span re-read its last record (re-inserting a value that is already in the
-// list would duplicate it, so those slots are fed +inf / skipped by the callback's `valid` flag).
-template <typename F>
-__device__ __forceinline__ void scan_block_wide(const GridView &gv, int cx, int cy, int cz, int R, F &&f) {
+// distance from q to the box of cell index c along one axis, shaved by the cell-assignment fuzz
+__device__ __forceinline__ float axis_gap_n(float q, float mn, float h, int c) {
+    const float lo = mn + (float)c * h, hi = lo + h;
+    return fmaxf(fmaxf(lo - q, q - hi) - 2e-3f * h, 0.0f);
+}
+
+// visit the records of the cells of block [c-R, c+R]^3 that (a) lie outside block [c-Rin, c+Rin]^3
+// (Rin < 0: none excluded) and (b) whose box is within sqrt(limit2) of q (ball pruning; the limit is
+// re-read per row so it may shrink while scanning).  Returns whether any cell qualified.
+template <typename LIM, typename F>
+__device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q, int cx, int cy, int cz, int Rin, int R,
+                                            LIM &&limit2, F &&f) {
     const GridGeom &g = gv.g;
     const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
     const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
     const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
+    bool touched = false;
     for (int z = z0; z <= z1; ++z) {
+        const float gz = axis_gap_n(q.z, g.minz, g.h, z);
         for (int y = y0; y <= y1; ++y) {
+            const float gy = axis_gap_n(q.y, g.miny, g.h, y);
+            const float rg = gy * gy + gz * gz;
+            const float lim = limit2();
+            if (rg > lim) continue;
+            const bool inner_row = (abs(z - cz) <= Rin) && (abs(y - cy) <= Rin);
+            // x window reachable by the ball
+            int xa = x0, xb = x1;
+            while (xa <= xb) { const float gx = axis_gap_n(q.x, g.minx, g.h, xa); if (rg + gx * gx > lim) ++xa; else break; }
+            while (xb >= xa) { const float gx = axis_gap_n(q.x, g.minx, g.h, xb); if (rg + gx * gx > lim) --xb; else break; }
+            if (xa > xb) continue;
             const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
-            const uint32_t s = gv.cell_start[row + x0], e = gv.cell_start[row + x1 + 1];
-            for (uint32_t j = s; j < e; j += 4) {
-                const uint32_t last = e - 1;
-                const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
-                const float4 c0 = gv.pts[j], c1 = gv.pts[j1], c2 = gv.pts[j2], c3 = gv.pts[j3];
-                f(j, c0, true); f(j + 1, c1, j + 1 < e); f(j + 2, c2, j + 2 < e); f(j + 3, c3, j + 3 < e);
-            }
+            auto span = [&](int a, int b) {
+                if (a > b) return;
+                touched = true;
+                const uint32_t s = gv.cell_start[row + a], e = gv.cell_start[row + b + 1];
+                for (uint32_t j = s; j < e; ++j) f(j, gv.pts[j]);
+            };
+            if (!inner_row) span(xa, xb);
+            else { span(xa, min(xb, cx - Rin - 1)); span(max(xa, cx + Rin + 1), xb); }   // only the cells outside the inner block
         }
     }
+    return touched;
 }
 
-template <int L, int BLOCK, bool RADIUS, bool WIDE = false>
-__device__ __forceinline__ void normals_point(const GridView &gv, const NormalParams &prm, uint32_t p, bool grow,
-                                              uint32_t *__restrict__ overflow, float *__restrict__ out6,
-                                              uint32_t *ldsA, uint32_t *ldsB) {
+template <int L, int BLOCK, bool RADIUS>
+__device__ __forceinline__ void normals_point(const GridView &gv, const NormalParams &prm, uint32_t p,
+                                              float *__restrict__ out6, uint32_t *ldsA, uint32_t *ldsB) {
     const GridGeom &g = gv.g;
     const float4 q = gv.pts[p];
     const uint32_t orig = __float_as_uint(q.w);
@@ -179,26 +199,29 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     uint32_t cnt_r = 0;
     double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     bool use_radius = false;
+#pragma unroll
+    for (int t = 0; t < L; ++t) d[t] = INFINITY;
+    auto visit1 = [&](uint32_t j, const float4 &c) {
+        const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+        list_insert<L>(d, v);
+        if (RADIUS && j != p && v <= r2) {
+            const double dx = (double)c.x - (double)q.x, dy = (double)c.y - (double)q.y, dz = (double)c.z - (double)q.z;
+            ++cnt_r;
+            s1x += dx; s1y += dy; s1z += dz;
+            sxx = fma(dx, dx, sxx); sxy = fma(dx, dy, sxy); sxz = fma(dx, dz, sxz);
+            syy = fma(dy, dy, syy); syz = fma(dy, dz, syz); szz = fma(dz, dz, szz);
+        }
+    };
+    auto kth = [&]() {
+        float tk = d[0];
+#pragma unroll
+        for (int t = 1; t < L; ++t) tk = ((uint32_t)t == prm.k) ? d[t] : tk;
+        return tk;
+    };
+    // ring R0: the whole block (no bound known yet)
+    scan_block(gv, cx, cy, cz, R, visit1);
     for (;;) {
-#pragma unroll
-        for (int t = 0; t < L; ++t) d[t] = INFINITY;
-        if (RADIUS) { cnt_r = 0; s1x = s1y = s1z = sxx = sxy = sxz = syy = syz = szz = 0.0; }
-        auto visit1 = [&](uint32_t j, const float4 &c, bool valid) {
-            const float v = valid ? d2_nc(c.x, c.y, c.z, q.x, q.y, q.z) : INFINITY;
-            list_insert<L>(d, v);
-            if (RADIUS && valid && j != p && v <= r2) {
-                const double dx = (double)c.x - (double)q.x, dy = (double)c.y - (double)q.y, dz = (double)c.z - (double)q.z;
-                ++cnt_r;
-                s1x += dx; s1y += dy; s1z += dz;
-                sxx = fma(dx, dx, sxx); sxy = fma(dx, dy, sxy); sxz = fma(dx, dz, sxz);
-                syy = fma(dy, dy, syy); syz = fma(dy, dz, syz); szz = fma(dz, dz, szz);
-            }
-        };
-        if (WIDE) scan_block_wide(gv, cx, cy, cz, R, visit1);
-        else scan_block(gv, cx, cy, cz, R, [&](uint32_t j, const float4 &c) { visit1(j, c, true); });
-        tau = d[0];
-#pragma unroll
-        for (int t = 1; t < L; ++t) tau = ((uint32_t)t == prm.k) ? d[t] : tau;
+        tau = kth();
         const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
                             (cz - R <= 0) && (cz + R >= g.gz - 1);
         const float bound = ((float)R + mf - 2e-3f) * g.h;
@@ -207,12 +230,13 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         use_radius = RADIUS && cnt_r >= prm.k;
         const bool exact = use_radius ? (prm.radius <= bound) : (tau <= bound * bound);
         if (covers || exact) break;
-        if (!grow) {
-            uint32_t slot = atomicAdd(&overflow[0], 1u);
-            overflow[1 + slot] = p;
-            return;
-        }
+        // not provably exact (grid-boundary points, Poisson tail): continue IN PLACE with the next
+        // shell, visiting only the cells the ball of the current bound can reach.  The ball clipped to
+        // the grid box is convex and contains the query, so a shell that misses it ends the search.
         ++R;
+        const float need2 = RADIUS ? fmaxf(r2, 0.0f) : 0.0f;     // radius mode must also see the whole radius ball
+        const bool touched = scan_pruned(gv, q, cx, cy, cz, R - 1, R, [&]() { return fmaxf(kth(), need2); }, visit1);
+        if (!touched) { tau = kth(); use_radius = RADIUS && cnt_r >= prm.k; break; }
     }
 
     float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
@@ -232,14 +256,13 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     for (int t = 0; t < L; ++t) n_lt += (d[t] < tau) ? 1u : 0u;
     const uint32_t quota = K1 - min(n_lt, K1);
     uint32_t cnt = 0, ties = 0;
-    auto visit2 = [&](uint32_t j, const float4 &c, bool valid) {
-        float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
-        bool take = valid && v < tau;
-        if (valid && !take && v == tau && ties < quota) { take = true; ++ties; }
+    // rescan only the cells within sqrt(tau) of the query (same visiting order as phase 1)
+    scan_pruned(gv, q, cx, cy, cz, -1, R, [&]() { return tau; }, [&](uint32_t j, const float4 &c) {
+        const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+        bool take = v < tau;
+        if (!take && v == tau && ties < quota) { take = true; ++ties; }
         if (take && cnt < K1) { ldsA[cnt * BLOCK] = j; ++cnt; }
-    };
-    if (WIDE) scan_block_wide(gv, cx, cy, cz, R, visit2);
-    else scan_block(gv, cx, cy, cz, R, [&](uint32_t j, const float4 &c) { visit2(j, c, true); });
+    });
 
     // rank -> ascending-distance order (ties keep scan order)
     unsigned long long taken_lo = 0ull, taken_hi = 0ull;   // bitset over ranks 0..127
@@ -311,55 +334,27 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
 }
 
 template <int L, int BLOCK, bool RADIUS>
-__global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, NormalParams prm,
-                                                                uint32_t *__restrict__ overflow,
-                                                                float *__restrict__ out6) {
+__global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
     __shared__ uint32_t ldsA[L * BLOCK];
     __shared__ uint32_t ldsB[L * BLOCK];
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t p = lb * BLOCK + threadIdx.x;
     if (p >= gv.g.n) return;
-    normals_point<L, BLOCK, RADIUS>(gv, prm, p, false, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
-}
-
-template <int L, int BLOCK, bool RADIUS>
-__global__ void __launch_bounds__(BLOCK) normals_overflow_kernel(GridView gv, NormalParams prm,
-                                                                 uint32_t *__restrict__ overflow,
-                                                                 float *__restrict__ out6) {
-    __shared__ uint32_t ldsA[L * BLOCK];
-    __shared__ uint32_t ldsB[L * BLOCK];
-    // launched with one thread per POINT (the count is not known on the host); threads past the
-    // list length leave at once.
-    const uint32_t count = overflow[0];
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= count) return;
-    NormalParams p2 = prm;
-    p2.R0 = prm.R0 + 1;
-    normals_point<L, BLOCK, RADIUS, true>(gv, p2, overflow[1 + i], true, overflow, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+    normals_point<L, BLOCK, RADIUS>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
 }
 
 template <int L, int BLOCK, bool RADIUS = false>
-static void launch_variant(hipStream_t st, const GridView &gv, const NormalParams &prm, uint32_t *overflow, float *out6,
-                           tc_context *ctx) {
+static void launch_variant(hipStream_t st, const GridView &gv, const NormalParams &prm, float *out6, tc_context *ctx) {
     const uint32_t n = gv.g.n;
     uint32_t nb = (n + BLOCK - 1) / BLOCK;
     nb = (nb + 7) / 8 * 8;   // xcd_remap needs a multiple of 8
-    {
-        ProfScope ps(ctx, "normals_knn_pca");
-        hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
-    }
-    {
-        ProfScope ps(ctx, "normals_overflow");
-        hipLaunchKernelGGL((normals_overflow_kernel<L, BLOCK, RADIUS>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, overflow, out6);
-    }
+    ProfScope ps(ctx, "normals_knn_pca");
+    hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
 }
 
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg, const float vp[3],
                          float *d_out6) {
-    const size_t n = ix.geom.n;
     if (cfg.k_neighbors + 1 > 65) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 64 is not supported by the HIP backend");
-    if (tc_status s = ensure(ctx, ctx->overflow, (n + 1) * sizeof(uint32_t))) return s;
-    TC_HIP_TRY(ctx, hipMemsetAsync(ctx->overflow.p, 0, sizeof(uint32_t), ctx->stream));
     NormalParams prm;
     prm.k = (uint32_t)cfg.k_neighbors;
     prm.orient = cfg.consistent_orientation ? 1 : 0;
@@ -368,29 +363,22 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal
     prm.has_radius = (cfg.has_radius && cfg.radius > 0.0f) ? 1 : 0;
     prm.radius = prm.has_radius ? cfg.radius : 0.0f;
     const GridView gv = view_of(ix);
-    uint32_t *ov = (uint32_t *)ctx->overflow.p;
     const uint32_t K1 = prm.k + 1;
     if (cfg.has_radius && cfg.radius > 0.0f) {   // radius <= 0 finds nothing (nearest_neighbor.rs:255): pure k-NN fallback
-        if (K1 <= 11)      launch_variant<11, 256, true>(ctx->stream, gv, prm, ov, d_out6, ctx);
-        else if (K1 <= 17) launch_variant<17, 256, true>(ctx->stream, gv, prm, ov, d_out6, ctx);
-        else if (K1 <= 33) launch_variant<33, 128, true>(ctx->stream, gv, prm, ov, d_out6, ctx);
-        else               launch_variant<65, 64, true>(ctx->stream, gv, prm, ov, d_out6, ctx);
+        if (K1 <= 11)      launch_variant<11, 256, true>(ctx->stream, gv, prm, d_out6, ctx);
+        else if (K1 <= 17) launch_variant<17, 256, true>(ctx->stream, gv, prm, d_out6, ctx);
+        else if (K1 <= 33) launch_variant<33, 128, true>(ctx->stream, gv, prm, d_out6, ctx);
+        else               launch_variant<65, 64, true>(ctx->stream, gv, prm, d_out6, ctx);
         TC_HIP_TRY(ctx, hipGetLastError());
         return TC_OK;
     }
-    if (K1 <= 9)       launch_variant<9, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
-    else if (K1 <= 11) launch_variant<11, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
-    else if (K1 <= 17) launch_variant<17, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
-    else if (K1 <= 21) launch_variant<21, 256>(ctx->stream, gv, prm, ov, d_out6, ctx);
-    else if (K1 <= 33) launch_variant<33, 128>(ctx->stream, gv, prm, ov, d_out6, ctx);
-    else               launch_variant<65, 64>(ctx->stream, gv, prm, ov, d_out6, ctx);
+    if (K1 <= 9)       launch_variant<9, 256>(ctx->stream, gv, prm, d_out6, ctx);
+    else if (K1 <= 11) launch_variant<11, 256>(ctx->stream, gv, prm, d_out6, ctx);
+    else if (K1 <= 17) launch_variant<17, 256>(ctx->stream, gv, prm, d_out6, ctx);
+    else if (K1 <= 21) launch_variant<21, 256>(ctx->stream, gv, prm, d_out6, ctx);
+    else if (K1 <= 33) launch_variant<33, 128>(ctx->stream, gv, prm, d_out6, ctx);
+    else               launch_variant<65, 64>(ctx->stream, gv, prm, d_out6, ctx);
     TC_HIP_TRY(ctx, hipGetLastError());
-    if (getenv("TC_DEBUG_OVERFLOW")) {
-        uint32_t cnt = 0;
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipMemcpy(&cnt, ctx->overflow.p, 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[tc] normals overflow list: %u of %zu points (h=%g, grid %dx%dx%d)\n", cnt, n, ix.geom.h, ix.geom.gx, ix.geom.gy, ix.geom.gz);
-    }
     return TC_OK;
 }
 

@@ -105,6 +105,7 @@ struct DeviceIndex {
     DevBuf normals;     // float4 * n   (cell-sorted target normals; optional)
     DevBuf cell_of;     // u32 * n      (scratch: cell id per original point)
     DevBuf slot;        // u32 * n      (scratch: atomic scatter order)
+    DevBuf arrival;     // u32 * n      (scratch: arrival rank of a point inside its cell)
     DevBuf fill;        // u32 * ncell  (scratch: histogram / fill counters)
     DevBuf blocksum;    // u32 * nblocks (scan scratch)
 };
