@@ -131,7 +131,8 @@ __device__ __forceinline__ void nn_search_global(const GridView &gv, float x, fl
 }
 
 template <int NACC, int NW = kIcpBlock / 64>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *__restrict__ out_row, double (*sm)[TC_ICP_SUMS_STRIDE]) {
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *__restrict__ out_row, double (*sm)[TC_ICP_SUMS_STRIDE],
+                                                   double extra = 0.0) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
         double v = acc[i];
@@ -151,7 +152,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *
 #pragma unroll
             for (int w2 = 0; w2 < NW; ++w2) s += sm[w2][threadIdx.x];
         }
-        out_row[threadIdx.x] = s;
+        out_row[threadIdx.x] = s + extra;
     }
 }
 
@@ -386,18 +387,25 @@ template <bool P2PLANE>
 __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, const uint32_t *__restrict__ rlist,
-    double *__restrict__ partial_rows) {
+    const double *__restrict__ main_rows, uint32_t n_main_rows, double *__restrict__ partial_rows) {
     constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
     if (st->done) return;
     __shared__ double red[kRefineThreads / 64][TC_ICP_SUMS_STRIDE];
+    // every refine block also folds its share of the main pass's per-block rows (written by the
+    // previous launch) into its own row, in a fixed order: icp_finalize then reads kRefineBlocks rows
+    const uint32_t rows_per = (n_main_rows + gridDim.x - 1) / gridDim.x;
+    const uint32_t mr0 = min(blockIdx.x * rows_per, n_main_rows), mr1 = min(mr0 + rows_per, n_main_rows);
+    double folded = 0.0;
+    if (threadIdx.x < TC_ICP_SUMS_STRIDE)
+        for (uint32_t r = mr0; r < mr1; ++r) folded += main_rows[(size_t)r * TC_ICP_SUMS_STRIDE + threadIdx.x];
     const GridGeom &g = tgt.g;
     const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
     const float t[3] = {st->t[0], st->t[1], st->t[2]};
     const float max_dist = st->max_dist;
     const bool warm = st->iterations > 0;
     const uint32_t count = rlist[0];
-    if ((uint32_t)blockIdx.x * (kRefineThreads / kRG) >= count) {      // no query for this block: zero row, done
-        if (threadIdx.x < TC_ICP_SUMS_STRIDE) partial_rows[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = 0.0;
+    if ((uint32_t)blockIdx.x * (kRefineThreads / kRG) >= count) {      // no query for this block: folded rows only
+        if (threadIdx.x < TC_ICP_SUMS_STRIDE) partial_rows[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = folded;
         return;
     }
     const int lg = threadIdx.x & (kRG - 1);
@@ -494,7 +502,7 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     double dacc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) dacc[i] = (double)acc[i];
-    block_reduce_store<NACC, kRefineThreads / 64>(dacc, partial_rows + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE, red);
+    block_reduce_store<NACC, kRefineThreads / 64>(dacc, partial_rows + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE, red, folded);
 }
 
 // ICPResult.correspondences (registration.rs:22-23): matched ORIGINAL target index per ORIGINAL
@@ -836,19 +844,19 @@ static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, 
         ProfScope ps(ctx, "icp_refine");
         if (p2plane)
             hipLaunchKernelGGL(icp_refine_kernel<true>, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist,
-                               refine_rows);
+                               partials, l.nblocks, refine_rows);
         else
             hipLaunchKernelGGL(icp_refine_kernel<false>, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist,
-                               refine_rows);
+                               partials, l.nblocks, refine_rows);
     }
     if (do_sum || do_apply) {
         ProfScope ps(ctx, "icp_finalize");
-        const uint32_t rows = l.nblocks + kRefineBlocks;
+        const uint32_t rows = kRefineBlocks;      // the refine pass folded the main pass's rows into its own
         if (p2plane)
-            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(1024), 0, s, partials, rows, st, tv.g, do_sum ? 1 : 0,
+            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(1024), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
                                (do_apply && !(dbg & 32)) ? 1 : 0, do_sum ? rlist : nullptr);
         else
-            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(1024), 0, s, partials, rows, st, tv.g, do_sum ? 1 : 0,
+            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(1024), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
                                (do_apply && !(dbg & 32)) ? 1 : 0, do_sum ? rlist : nullptr);
     }
 }
