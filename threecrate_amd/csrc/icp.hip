@@ -543,34 +543,49 @@ __global__ void __launch_bounds__(kIcpBlock) icp_final_mse_kernel(GridView tgt, 
 }
 
 // ---- small f64 solvers (one lane) -----------------------------------------------------------
-__device__ bool chol6_solve(const double A[6][6], const double b[6], double x[6]) {
+__device__ __forceinline__ bool chol6_solve(const double A[6][6], const double b[6], double x[6]) {
+    // fully unrolled (static indices only) so that L lives in registers, not scratch
     double L[6][6];
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) L[i][j] = A[i][j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) L[i][j] = A[i][j];
+    bool ok = true;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
+#pragma unroll
         for (int k = 0; k < j; ++k) {
             const double f = L[j][k];
+#pragma unroll
             for (int r = j; r < 6; ++r) L[r][j] -= f * L[r][k];
         }
         const double d = L[j][j];
-        if (!(d > 0.0)) return false;     // Cholesky::new -> None on a non-positive pivot
-        const double sd = sqrt(d);
+        ok = ok && (d > 0.0);             // Cholesky::new -> None on a non-positive pivot
+        const double sd = sqrt(d > 0.0 ? d : 1.0);
+        const double inv = 1.0 / sd;
         L[j][j] = sd;
-        for (int r = j + 1; r < 6; ++r) L[r][j] /= sd;
+#pragma unroll
+        for (int r = j + 1; r < 6; ++r) L[r][j] *= inv;
     }
+    if (!ok) return false;
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
+#pragma unroll
         for (int k = 0; k < i; ++k) s -= L[i][k] * x[k];
         x[i] = s / L[i][i];
     }
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = x[i];
+#pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
         x[i] = s / L[i][i];
     }
     return true;
 }
 
-__device__ bool lu6_solve(const double Ain[6][6], const double b[6], double x[6]) {
+__device__ __noinline__ bool lu6_solve(const double Ain[6][6], const double b[6], double x[6]) {
     double A[6][6];
     for (int i = 0; i < 6; ++i) { x[i] = b[i]; for (int j = 0; j < 6; ++j) A[i][j] = Ain[i][j]; }
     for (int i = 0; i < 6; ++i) {
@@ -711,29 +726,29 @@ __device__ void finish_iteration(IcpState *st, float mse, uint32_t n) {
 }
 
 template <bool P2PLANE>
-__global__ void __launch_bounds__(1024) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
+__global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
                                                            IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply, uint32_t *__restrict__ rlist) {
     if (st->done) return;
-    __shared__ double sm[32][TC_ICP_SUMS_STRIDE];
+    __shared__ double sm[8][TC_ICP_SUMS_STRIDE];
     if (do_sum) {
-        // 32 row groups x 32 columns; every group folds its rows in a fixed order with
-        // 4 independent loads in flight, then column t folds the 32 groups in order.
+        // 8 row groups x 32 columns; every group folds its rows in a fixed order with 4 independent
+        // loads in flight, then column t folds the 8 groups in order.
         const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         uint32_t b = grp;
-        for (; b + 96 < nblocks; b += 128) {
+        for (; b + 24 < nblocks; b += 32) {
             s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
-            s1 += partials[(size_t)(b + 32) * TC_ICP_SUMS_STRIDE + col];
-            s2 += partials[(size_t)(b + 64) * TC_ICP_SUMS_STRIDE + col];
-            s3 += partials[(size_t)(b + 96) * TC_ICP_SUMS_STRIDE + col];
+            s1 += partials[(size_t)(b + 8) * TC_ICP_SUMS_STRIDE + col];
+            s2 += partials[(size_t)(b + 16) * TC_ICP_SUMS_STRIDE + col];
+            s3 += partials[(size_t)(b + 24) * TC_ICP_SUMS_STRIDE + col];
         }
-        for (; b < nblocks; b += 32) s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
+        for (; b < nblocks; b += 8) s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
         sm[grp][col] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
             double tot = 0.0;
 #pragma unroll
-            for (int gi = 0; gi < 32; ++gi) tot += sm[gi][threadIdx.x];
+            for (int gi = 0; gi < 8; ++gi) tot += sm[gi][threadIdx.x];
             st->sums[threadIdx.x] = tot;
         }
         if (threadIdx.x == 0 && rlist) rlist[0] = 0;     // refine list consumed: ready for the next iteration
@@ -746,7 +761,11 @@ __global__ void __launch_bounds__(1024) icp_finalize_kernel(const double *__rest
         if (cnt < 6.0) { st->status = TC_ALGORITHM; st->done = 1; return; }     // registration.rs:568-572
         double A[6][6], b[6], x[6];
         int o = 0;
-        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r][c] = S[o]; A[c][r] = S[o]; ++o; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) { A[r][c] = S[o]; A[c][r] = S[o]; ++o; }
+#pragma unroll
         for (int r = 0; r < 6; ++r) b[r] = S[21 + r];
         if (!chol6_solve(A, b, x)) {
             if (!lu6_solve(A, b, x)) { st->status = TC_ALGORITHM; st->done = 1; return; }   // :432-438
@@ -853,10 +872,10 @@ static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, 
         ProfScope ps(ctx, "icp_finalize");
         const uint32_t rows = kRefineBlocks;      // the refine pass folded the main pass's rows into its own
         if (p2plane)
-            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(1024), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
+            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(256), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
                                (do_apply && !(dbg & 32)) ? 1 : 0, do_sum ? rlist : nullptr);
         else
-            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(1024), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
+            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(256), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
                                (do_apply && !(dbg & 32)) ? 1 : 0, do_sum ? rlist : nullptr);
     }
 }
