@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
 // stop as soon as a whole shell misses the ball).  ~2-3 dependent memory round trips per ring and
 // query instead of one per row, and thousands of waves in flight.  Per-block sums go to the
 // partial rows after the main pass's rows.
-constexpr int kRefineBlocks = 128;
+constexpr int kRefineBlocks = 256;
 constexpr int kRefineThreads = 1024;
 constexpr int kRG = 32;                     // lanes per query
 

@@ -73,3 +73,43 @@ def registration_pair(n, seed=1, transform=None, scale=(1.0, 1.0, 1.0)):
     Minv = invert_isometry(T)
     src = (tgt.astype(np.float64) @ Minv[:3, :3].T + Minv[:3, 3]).astype(np.float32)
     return src, tgt, T
+
+
+# ---- scan-shaped synthetic clouds (BASELINE configs [2] and [4]) ----------
+def _smooth_noise(u, v, seed):
+    """cheap smooth 2-D field in [-1, 1] (sum of a few seeded sinusoids)."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros_like(u, dtype=np.float64)
+    for _ in range(6):
+        fu, fv, ph = rng.uniform(0.5, 4.0), rng.uniform(0.5, 4.0), rng.uniform(0, 2 * np.pi)
+        out += np.sin(fu * u + fv * v + ph)
+    return out / 6.0
+
+
+def tum_shaped_cloud(width=1155, height=866, seed=0, step=1):
+    """Pinhole back-projection of a synthetic depth map z(u,v) = 1.5 + 0.5*smooth_noise (metres);
+    fx = fy = 525*width/640, principal point centred (the reference's TUM loader uses fx=fy=525,
+    cx=319.5, cy=239.5: examples/threecrate_dataset_bench.rs:339-357)."""
+    us, vs = np.meshgrid(np.arange(0, width, step, dtype=np.float64), np.arange(0, height, step, dtype=np.float64))
+    fx = 525.0 * width / 640.0
+    cx, cy = (width - 1) / 2.0, (height - 1) / 2.0
+    z = 1.5 + 0.5 * _smooth_noise(us / width * 6.0, vs / height * 6.0, seed)
+    x = (us - cx) / fx * z
+    y = (vs - cy) / fx * z
+    return np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(np.float32)
+
+
+def kitti_shaped_cloud(beams=64, azimuth_steps=1875, seed=0, noise=0.02):
+    """64 beams (elevation -24.8..+2 deg) x azimuth steps ray-cast onto the ground plane z = -1.73 m and
+    four walls at +-20 m, range noise sigma = 2 cm."""
+    rng = np.random.default_rng(seed)
+    el = np.deg2rad(np.linspace(-24.8, 2.0, beams))[:, None]
+    az = np.linspace(0, 2 * np.pi, azimuth_steps, endpoint=False)[None, :]
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el) * np.ones_like(az)], axis=-1).reshape(-1, 3)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_ground = np.where(d[:, 2] < -1e-6, -1.73 / d[:, 2], np.inf)
+        t_wx = np.where(np.abs(d[:, 0]) > 1e-9, 20.0 / np.abs(d[:, 0]), np.inf)
+        t_wy = np.where(np.abs(d[:, 1]) > 1e-9, 20.0 / np.abs(d[:, 1]), np.inf)
+    t = np.minimum(np.minimum(t_ground, t_wx), t_wy)
+    t = t + rng.normal(0.0, noise, t.shape)
+    return (d * t[:, None]).astype(np.float32)
