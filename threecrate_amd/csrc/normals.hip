@@ -136,11 +136,11 @@ __device__ __forceinline__ float axis_gap_n(float q, float mn, float h, int c) {
 }
 
 // visit the records of the cells of block [c-R, c+R]^3 that (a) lie outside block [c-Rin, c+Rin]^3
-// (Rin < 0: none excluded) and (b) whose box is within sqrt(limit2) of q (ball pruning; the limit is
-// re-read per row so it may shrink while scanning).  Returns whether any cell qualified.
-template <typename LIM, typename F>
+// (Rin < 0: none excluded) and (b) whose box is within sqrt(lim) of q (ball pruning).  Returns
+// whether any cell qualified.
+template <typename F>
 __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q, int cx, int cy, int cz, int Rin, int R,
-                                            LIM &&limit2, F &&f) {
+                                            const float lim, F &&f) {
     const GridGeom &g = gv.g;
     const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
     const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
@@ -151,7 +151,6 @@ __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q,
         for (int y = y0; y <= y1; ++y) {
             const float gy = axis_gap_n(q.y, g.miny, g.h, y);
             const float rg = gy * gy + gz * gz;
-            const float lim = limit2();
             if (rg > lim) continue;
             const bool inner_row = (abs(z - cz) <= Rin) && (abs(y - cy) <= Rin);
             // x window reachable by the ball
@@ -212,16 +211,16 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
             syy = fma(dy, dy, syy); syz = fma(dy, dz, syz); szz = fma(dz, dz, szz);
         }
     };
-    auto kth = [&]() {
-        float tk = d[0];
-#pragma unroll
-        for (int t = 1; t < L; ++t) tk = ((uint32_t)t == prm.k) ? d[t] : tk;
-        return tk;
-    };
+#define TC_KTH(OUT)                                                                 \
+    do {                                                                            \
+        float tk_ = d[0];                                                           \
+        _Pragma("unroll") for (int t = 1; t < L; ++t) tk_ = ((uint32_t)t == prm.k) ? d[t] : tk_; \
+        (OUT) = tk_;                                                                \
+    } while (0)
     // ring R0: the whole block (no bound known yet)
     scan_block(gv, cx, cy, cz, R, visit1);
     for (;;) {
-        tau = kth();
+        TC_KTH(tau);
         const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
                             (cz - R <= 0) && (cz + R >= g.gz - 1);
         const float bound = ((float)R + mf - 2e-3f) * g.h;
@@ -235,10 +234,11 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         // the grid box is convex and contains the query, so a shell that misses it ends the search.
         ++R;
         const float need2 = RADIUS ? fmaxf(r2, 0.0f) : 0.0f;     // radius mode must also see the whole radius ball
-        const bool touched = scan_pruned(gv, q, cx, cy, cz, R - 1, R, [&]() { return fmaxf(kth(), need2); }, visit1);
-        if (!touched) { tau = kth(); use_radius = RADIUS && cnt_r >= prm.k; break; }
+        const bool touched = scan_pruned(gv, q, cx, cy, cz, R - 1, R, fmaxf(tau, need2), visit1);
+        if (!touched) { TC_KTH(tau); use_radius = RADIUS && cnt_r >= prm.k; break; }
     }
 
+#undef TC_KTH
     float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
     if (RADIUS && use_radius) {
         const double nn = (double)cnt_r + 1.0;                     // + the query itself (normals.rs:338-340)
@@ -257,7 +257,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     const uint32_t quota = K1 - min(n_lt, K1);
     uint32_t cnt = 0, ties = 0;
     // rescan only the cells within sqrt(tau) of the query (same visiting order as phase 1)
-    scan_pruned(gv, q, cx, cy, cz, -1, R, [&]() { return tau; }, [&](uint32_t j, const float4 &c) {
+    scan_pruned(gv, q, cx, cy, cz, -1, R, tau, [&](uint32_t j, const float4 &c) {
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
         bool take = v < tau;
         if (!take && v == tau && ties < quota) { take = true; ++ties; }
