@@ -197,6 +197,17 @@ tc_status   tc_icp_shard_apply(tc_icp_shard *s);               /* solve + compos
 tc_status   tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *result);
 void        tc_icp_shard_destroy(tc_icp_shard *s);
 
+/* ---- voxel_grid_filter ----
+ * voxel_grid_filter(&PointCloud<Point3f>, voxel_size) -> Result<PointCloud<Point3f>>
+ * (threecrate-algorithms/src/filtering.rs:38-133): one f32 centroid per occupied voxel, keys
+ * floor((p - bbox_min) / voxel_size), f64 sums in input order.  The reference's output order is
+ * unspecified (HashMap); here voxels come out sorted by (kx, ky, kz).  out: capacity n x 3.
+ * n == 0 -> TC_OK; voxel_size <= 0 -> TC_INVALID_DATA; > 2^25 voxels in the bbox -> TC_UNSUPPORTED. */
+tc_status tc_voxel_grid_filter(tc_context *ctx, const float *xyz, size_t n, float voxel_size,
+                               float *out_xyz, size_t *n_out);
+tc_status tc_voxel_grid_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float voxel_size,
+                                      float *d_out_xyz, size_t *n_out);
+
 /* ---- profiling ---- */
 /* on: 0 = off, 1 = hipEvents around every kernel, 2 = only around every 4th launch of the dominant
    kernel (icp_correspond_reduce): ~1 % overhead, used inside bench.py's timed region */

@@ -250,3 +250,34 @@ def test_kitti_shaped_lidar_frame(ctx):
     r = O.icp_detailed(cur, prev, None, 12, 2.0, 0.0)
     assert g.iterations == r.iterations == 12
     assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= 1e-3
+
+
+@pytest.mark.parametrize("n,voxel,scale", [(10000, 0.1, (1, 1, 1)), (200000, 0.02, (1, 1, 1)), (50000, 0.5, (20, 20, 3))])
+def test_voxel_grid_filter_bit_exact(ctx, n, voxel, scale):
+    """voxel_grid_filter (filtering.rs:38-133): same keys, f64 sums in the same (input) order ->
+    bit-identical centroids; both sides emit voxels sorted by (kx, ky, kz)."""
+    pts = synth.uniform_cloud(n, seed=4, scale=scale)
+    g = ctx.voxel_grid_filter(pts, voxel)
+    r = O.voxel_grid_filter(pts, voxel)
+    assert g.shape == r.shape
+    assert np.array_equal(g, r)
+    # size-independent property: the filter of the filtered cloud (same voxel) keeps the count
+    assert len(ctx.voxel_grid_filter(g, voxel)) <= len(g)
+
+
+def test_voxel_grid_filter_kats_and_errors(ctx):
+    """filtering.rs:537-576"""
+    import threecrate_amd as tc
+    assert len(ctx.voxel_grid_filter(np.zeros((0, 3), np.float32), 0.1)) == 0
+    assert len(ctx.voxel_grid_filter(np.array([[0, 0, 0]], np.float32), 0.1)) == 1
+    pts = np.array([[0, 0, 0], [0, 0, 0], [0.1, 0, 0], [0.1, 0, 0], [0, 0.1, 0]], np.float32)
+    out = ctx.voxel_grid_filter(pts, 0.05)
+    assert len(out) == 3 and np.array_equal(out, O.voxel_grid_filter(pts, 0.05))
+    for bad in (0.0, -1.0):
+        with pytest.raises(tc.InvalidData):
+            ctx.voxel_grid_filter(np.array([[0, 0, 0]], np.float32), bad)
+    frame = synth.kitti_shaped_cloud(seed=2)
+    assert np.array_equal(ctx.voxel_grid_filter(frame, 0.2), O.voxel_grid_filter(frame, 0.2))
+    torch = pytest.importorskip("torch")
+    d = ctx.voxel_grid_filter(torch.from_numpy(frame).cuda(), 0.2)
+    assert np.array_equal(d.cpu().numpy(), O.voxel_grid_filter(frame, 0.2))

@@ -178,6 +178,21 @@ class GpuContext:
         """GpuContext::compute_normals (threecrate-gpu/src/normals.rs:367-374): normals only (N, 3)."""
         return self.estimate_normals(points, k)[:, 3:]
 
+    # ---- voxel grid filter ----
+    def voxel_grid_filter(self, cloud, voxel_size: float):
+        """filtering.rs:38-133 -> (M, 3) centroids, sorted by voxel key (kx, ky, kz)."""
+        n_out = C.c_size_t(0)
+        if _is_torch(cloud):
+            import torch
+            x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            out = torch.empty((max(1, x.shape[0]), 3), dtype=torch.float32, device=x.device)
+            self._check(self._L.tc_voxel_grid_filter_device(self._h, x.data_ptr(), x.shape[0], voxel_size, out.data_ptr(), C.byref(n_out)))
+            return out[: n_out.value]
+        x = _as_host(cloud)
+        out = np.empty((max(1, x.shape[0]), 3), np.float32)
+        self._check(self._L.tc_voxel_grid_filter(self._h, x.ctypes.data, x.shape[0], voxel_size, out.ctypes.data, C.byref(n_out)))
+        return out[: n_out.value].copy()
+
     # ---- ICP ----
     def _result(self, r, ns, corr, want_pairs):
         T = np.array(list(r.transformation), np.float32)
@@ -297,6 +312,15 @@ def estimate_normals_with_config(cloud, config, ctx=None):
 
 def estimate_normals_radius(cloud, radius, consistent_orientation, ctx=None):
     return (ctx or default_context()).estimate_normals_radius(cloud, radius, consistent_orientation)
+
+
+def voxel_grid_filter(cloud, voxel_size, ctx=None):
+    return (ctx or default_context()).voxel_grid_filter(cloud, voxel_size)
+
+
+def gpu_voxel_grid_filter(gpu_context, cloud, voxel_size):
+    """threecrate-gpu/src/lib.rs:50 facade name; semantics of the CPU voxel_grid_filter (centroids)."""
+    return gpu_context.voxel_grid_filter(cloud, voxel_size)
 
 
 def icp(source, target, init=None, max_iters=50, ctx=None):

@@ -134,7 +134,7 @@ void tc_context_destroy(tc_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    free_index(ctx->tgt_index); free_index(ctx->src_index);
+    free_index(ctx->tgt_index); free_index(ctx->src_index); free_index(ctx->vox_index);
     free_buf(ctx->in_a); free_buf(ctx->in_b); free_buf(ctx->in_c); free_buf(ctx->out_a); free_buf(ctx->bbox);
     free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->overflow);
     for (auto &t : ctx->timers) for (auto &p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -302,6 +302,39 @@ tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp
     std::vector<std::thread> th;
     for (size_t c = 0; c < n_ctx; ++c) th.emplace_back(worker, c);
     for (auto &t : th) t.join();
+    return TC_OK;
+}
+
+// ---- voxel_grid_filter (filtering.rs:38-133) --------------------------------------------------
+static tc_status voxel_validate(tc_context *ctx, size_t n, float voxel, size_t *n_out, bool *empty) {
+    *empty = false;
+    if (!ctx || !n_out) return TC_INVALID_DATA;
+    *n_out = 0;
+    if (n == 0) { *empty = true; return TC_OK; }                                              // filtering.rs:42-44
+    if (!(voxel > 0.0f)) return fail(ctx, TC_INVALID_DATA, "voxel_size must be positive");    // :46-50
+    if (n >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    return TC_OK;
+}
+
+tc_status tc_voxel_grid_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float voxel_size, float *d_out, size_t *n_out) {
+    bool empty;
+    if (tc_status s = voxel_validate(ctx, n, voxel_size, n_out, &empty)) return s;
+    if (empty) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return voxel_filter_device(ctx, d_xyz, n, voxel_size, d_out, n_out);
+}
+
+tc_status tc_voxel_grid_filter(tc_context *ctx, const float *xyz, size_t n, float voxel_size, float *out, size_t *n_out) {
+    bool empty;
+    if (tc_status s = voxel_validate(ctx, n, voxel_size, n_out, &empty)) return s;
+    if (empty) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = ensure(ctx, ctx->in_a, n * 3 * sizeof(float))) return s;
+    if (tc_status s = ensure(ctx, ctx->out_a, n * 3 * sizeof(float))) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (tc_status s = voxel_filter_device(ctx, (const float *)ctx->in_a.p, n, voxel_size, (float *)ctx->out_a.p, n_out)) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out_a.p, *n_out * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
 }
 

@@ -265,6 +265,35 @@ TileGeom make_tiles(const GridGeom &g, int tx, int ty, int tz) {
     return t;
 }
 
+tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out, DevBuf &blocksum) {
+    hipStream_t st = ctx->stream;
+    const uint32_t nscan = (n + kScanTile - 1) / kScanTile;
+    if (tc_status s = ensure(ctx, blocksum, (size_t)nscan * sizeof(uint32_t))) return s;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, (uint32_t *)blocksum.p, nscan);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (const uint32_t *)blocksum.p, d_out);
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
+tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3]) {
+    hipStream_t st = ctx->stream;
+    const int nb = (int)((n + 255) / 256);
+    const int bb = std::min(nb, kBboxBlocks);
+    if (tc_status s = ensure(ctx, ctx->bbox, (size_t)kBboxBlocks * 6 * sizeof(float))) return s;
+    {
+        ProfScope ps(ctx, "bbox");
+        hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, (float *)ctx->bbox.p);
+    }
+    float *hb = (float *)((char *)ctx->pinned + 2048);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(hb, ctx->bbox.p, (size_t)bb * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int c = 0; c < 3; ++c) { mn[c] = INFINITY; mx[c] = -INFINITY; }
+    for (int b = 0; b < bb; ++b)
+        for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hb[6 * b + c]); mx[c] = std::fmax(mx[c], hb[6 * b + 3 + c]); }
+    return TC_OK;
+}
+
 tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n, float cell_factor,
                       const GridGeom *reuse_geom, const IcpState *d_state_transform, const TileGeom *tile_major,
                       float min_cell_edge) {
@@ -277,18 +306,8 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         ix.geom = *reuse_geom;
         ix.geom.n = n32;
     } else {
-        const int bb = std::min(nb, kBboxBlocks);
-        if (tc_status s = ensure(ctx, ctx->bbox, (size_t)kBboxBlocks * 6 * sizeof(float))) return s;
-        {
-            ProfScope ps(ctx, "bbox");
-            hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, n32, (float *)ctx->bbox.p);
-        }
-        float *hb = (float *)((char *)ctx->pinned + 2048);
-        TC_HIP_TRY(ctx, hipMemcpyAsync(hb, ctx->bbox.p, (size_t)bb * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
-        TC_HIP_TRY(ctx, hipStreamSynchronize(st));
-        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int b = 0; b < bb; ++b)
-            for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hb[6 * b + c]); mx[c] = std::fmax(mx[c], hb[6 * b + 3 + c]); }
+        float mn[3], mx[3];
+        if (tc_status s = cloud_bbox(ctx, d_xyz, n, mn, mx)) return s;
         for (int c = 0; c < 3; ++c)
             if (!(mn[c] <= mx[c]) || !std::isfinite(mn[c]) || !std::isfinite(mx[c])) { mn[c] = 0.0f; mx[c] = 0.0f; }
         derive_geom(ix.geom, mn, mx, n, cell_factor, min_cell_edge);
@@ -310,8 +329,6 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     if (tc_status s = ensure(ctx, ix.arrival, n * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, ix.fill, (size_t)nkeys * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, ix.cell_start, ((size_t)nkeys + 1) * sizeof(uint32_t))) return s;
-    const uint32_t nscan = (nkeys + kScanTile - 1) / kScanTile;
-    if (tc_status s = ensure(ctx, ix.blocksum, (size_t)nscan * sizeof(uint32_t))) return s;
 
     TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)nkeys * sizeof(uint32_t), st));
     {
@@ -321,11 +338,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     }
     {
         ProfScope ps(ctx, "cell_scan");
-        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nscan), dim3(kScanBlock), 0, st, (const uint32_t *)ix.fill.p, nkeys,
-                           (uint32_t *)ix.blocksum.p);
-        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, (uint32_t *)ix.blocksum.p, nscan);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, (const uint32_t *)ix.fill.p, nkeys,
-                           (const uint32_t *)ix.blocksum.p, (uint32_t *)ix.cell_start.p);
+        if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, nkeys, (uint32_t *)ix.cell_start.p, ix.blocksum)) return s;
     }
     {
         ProfScope ps(ctx, "cell_scatter");

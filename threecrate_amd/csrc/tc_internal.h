@@ -131,7 +131,8 @@ struct tc_context {
     tc::DevBuf state;               // IcpState
     tc::DevBuf partials;            // double * kMaxPartialBlocks * TC_ICP_SUMS_STRIDE
     tc::DevBuf corr;                // u32 * n_source
-    tc::DevBuf overflow;            // u32 * (n + 1)  (normals ring-overflow list, [0] = count)
+    tc::DevBuf overflow;            // scratch (voxel filter: occupied-cell flags / output slots)
+    tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
     size_t pinned_cap = 0;
 };
@@ -163,6 +164,13 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
 TileGeom make_tiles(const GridGeom &g, int tx, int ty, int tz);
 tc_status gather_normals(tc_context *ctx, DeviceIndex &ix, const float *d_normals, size_t stride);
 GridView view_of(const DeviceIndex &ix);
+
+// grid.hip (shared with voxel.hip)
+tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out /* n+1 */, DevBuf &blocksum);
+tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3]);
+
+// voxel.hip
+tc_status voxel_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float voxel, float *d_out, size_t *n_out);
 
 // normals.hip
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg,

@@ -1,0 +1,132 @@
+// voxel.hip -- voxel_grid_filter (threecrate-algorithms/src/filtering.rs:38-133): one centroid per
+// occupied voxel, f64 accumulation, keys = floor((p - bbox_min) / voxel_size) per axis.
+//
+// The reference folds the cloud into a HashMap in input order, so every voxel's f64 sum runs in
+// ascending original index and the output order is unspecified.  Here: dense voxel grid (x-major
+// linear id => output sorted by (kx, ky, kz)), counting sort by voxel id with the arrival-rank
+// scatter + stable re-rank of grid.hip (points of a voxel end up in ascending original index), then
+// one lane per occupied voxel folds its points in that order in f64: bit-identical centroids.
+#include "tc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace tc {
+
+struct VoxGeom {
+    float minx, miny, minz, voxel;
+    int gx, gy, gz;
+    uint32_t ncell;
+};
+
+__device__ __forceinline__ uint32_t voxel_id(const VoxGeom &v, float x, float y, float z) {
+    // filtering.rs:96-101: ((p - min) / voxel_size).floor() as i32  (true division, not * 1/voxel)
+    int kx = (int)floorf((x - v.minx) / v.voxel), ky = (int)floorf((y - v.miny) / v.voxel),
+        kz = (int)floorf((z - v.minz) / v.voxel);
+    kx = min(max(kx, 0), v.gx - 1); ky = min(max(ky, 0), v.gy - 1); kz = min(max(kz, 0), v.gz - 1);
+    return ((uint32_t)kx * v.gy + ky) * v.gz + kz;       // x-major: ascending id = (kx, ky, kz) order
+}
+
+__global__ void __launch_bounds__(256) vox_hist_kernel(const float *__restrict__ xyz, uint32_t n, VoxGeom v,
+                                                      uint32_t *__restrict__ cell_of, uint32_t *__restrict__ hist,
+                                                      uint32_t *__restrict__ arrival) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = voxel_id(v, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
+    cell_of[i] = c;
+    arrival[i] = atomicAdd(&hist[c], 1u);
+}
+
+__global__ void __launch_bounds__(256) vox_scatter_kernel(const uint32_t *__restrict__ cell_of, uint32_t n,
+                                                         const uint32_t *__restrict__ cell_start,
+                                                         const uint32_t *__restrict__ arrival, uint32_t *__restrict__ slot) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    slot[cell_start[cell_of[i]] + arrival[i]] = i;
+}
+
+// stable order inside the voxel: ascending original index
+__global__ void __launch_bounds__(256) vox_rank_kernel(uint32_t n, const uint32_t *__restrict__ cell_of,
+                                                      const uint32_t *__restrict__ cell_start,
+                                                      const uint32_t *__restrict__ slot, uint32_t *__restrict__ order) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t i = slot[p];
+    const uint32_t c = cell_of[i];
+    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+    uint32_t rank = 0;
+    for (uint32_t j = s; j < e; ++j) rank += (slot[j] < i) ? 1u : 0u;
+    order[s + rank] = i;
+}
+
+__global__ void __launch_bounds__(256) vox_flag_kernel(const uint32_t *__restrict__ cell_start, uint32_t ncell,
+                                                      uint32_t *__restrict__ flag) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    flag[c] = (cell_start[c + 1] > cell_start[c]) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) vox_centroid_kernel(const float *__restrict__ xyz, const uint32_t *__restrict__ cell_start,
+                                                          uint32_t ncell, const uint32_t *__restrict__ order,
+                                                          const uint32_t *__restrict__ outpos, float *__restrict__ out) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+    if (e == s) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;          // filtering.rs:108-118
+    for (uint32_t j = s; j < e; ++j) {
+        const size_t i = order[j];
+        sx += (double)xyz[3 * i]; sy += (double)xyz[3 * i + 1]; sz += (double)xyz[3 * i + 2];
+    }
+    const double inv = 1.0 / (double)(e - s);      // filtering.rs:122-128
+    float *o = out + 3 * (size_t)outpos[c];
+    o[0] = (float)(sx * inv); o[1] = (float)(sy * inv); o[2] = (float)(sz * inv);
+}
+
+tc_status voxel_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float voxel, float *d_out, size_t *n_out) {
+    hipStream_t st = ctx->stream;
+    float mn[3], mx[3];
+    if (tc_status s = cloud_bbox(ctx, d_xyz, n, mn, mx)) return s;
+    for (int c = 0; c < 3; ++c)
+        if (!(mn[c] <= mx[c]) || !std::isfinite(mn[c]) || !std::isfinite(mx[c]))
+            return fail(ctx, TC_INVALID_DATA, "voxel_grid_filter: non-finite coordinates");
+    VoxGeom v;
+    v.minx = mn[0]; v.miny = mn[1]; v.minz = mn[2]; v.voxel = voxel;
+    double dims[3];
+    for (int c = 0; c < 3; ++c) dims[c] = std::floor((double)((mx[c] - mn[c]) / voxel)) + 1.0;
+    const double ncd = dims[0] * dims[1] * dims[2];
+    if (!(ncd < 33554432.0)) return fail(ctx, TC_UNSUPPORTED, "voxel_grid_filter: more than 2^25 voxels in the bounding box (dense-grid limit of this build)");
+    v.gx = (int)dims[0]; v.gy = (int)dims[1]; v.gz = (int)dims[2];
+    v.ncell = (uint32_t)ncd;
+    DeviceIndex &ix = ctx->vox_index;
+    const uint32_t n32 = (uint32_t)n;
+    const int nb = (int)((n + 255) / 256), ncb = (int)((v.ncell + 255) / 256);
+    if (tc_status s = ensure(ctx, ix.cell_of, n * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.slot, n * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.arrival, n * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.pts, n * sizeof(uint32_t))) return s;                       // order[]
+    if (tc_status s = ensure(ctx, ix.fill, (size_t)v.ncell * sizeof(uint32_t))) return s;        // histogram, then flags
+    if (tc_status s = ensure(ctx, ix.cell_start, ((size_t)v.ncell + 1) * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ctx->overflow, ((size_t)v.ncell + 1) * sizeof(uint32_t))) return s;   // output slots
+    TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)v.ncell * sizeof(uint32_t), st));
+    ProfScope ps(ctx, "voxel_grid_filter");
+    hipLaunchKernelGGL(vox_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, v, (uint32_t *)ix.cell_of.p, (uint32_t *)ix.fill.p,
+                       (uint32_t *)ix.arrival.p);
+    if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, v.ncell, (uint32_t *)ix.cell_start.p, ix.blocksum)) return s;
+    hipLaunchKernelGGL(vox_scatter_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)ix.cell_of.p, n32,
+                       (const uint32_t *)ix.cell_start.p, (const uint32_t *)ix.arrival.p, (uint32_t *)ix.slot.p);
+    hipLaunchKernelGGL(vox_rank_kernel, dim3(nb), dim3(256), 0, st, n32, (const uint32_t *)ix.cell_of.p,
+                       (const uint32_t *)ix.cell_start.p, (const uint32_t *)ix.slot.p, (uint32_t *)ix.pts.p);
+    hipLaunchKernelGGL(vox_flag_kernel, dim3(ncb), dim3(256), 0, st, (const uint32_t *)ix.cell_start.p, v.ncell, (uint32_t *)ix.fill.p);
+    if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, v.ncell, (uint32_t *)ctx->overflow.p, ix.blocksum)) return s;
+    hipLaunchKernelGGL(vox_centroid_kernel, dim3(ncb), dim3(256), 0, st, d_xyz, (const uint32_t *)ix.cell_start.p, v.ncell,
+                       (const uint32_t *)ix.pts.p, (const uint32_t *)ctx->overflow.p, d_out);
+    uint32_t *hcount = (uint32_t *)((char *)ctx->pinned + 1024);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(hcount, (uint32_t *)ctx->overflow.p + v.ncell, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+    TC_HIP_TRY(ctx, hipGetLastError());
+    *n_out = *hcount;
+    return TC_OK;
+}
+
+}  // namespace tc
