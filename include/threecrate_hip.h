@@ -197,6 +197,17 @@ tc_status   tc_icp_shard_apply(tc_icp_shard *s);               /* solve + compos
 tc_status   tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *result);
 void        tc_icp_shard_destroy(tc_icp_shard *s);
 
+/* ---- batch k-NN export ----
+ * NearestNeighborSearch::find_k_nearest(&query, k) -> Vec<(usize, f32)> for many queries
+ * (threecrate-core/src/traits.rs:6-12, threecrate-algorithms/src/nearest_neighbor.rs:177-251;
+ * gpu_find_k_nearest_batch threecrate-gpu/src/nearest_neighbor.rs:345-355; Python KdTree.knn
+ * threecrate-python/src/lib.rs:735-745).  Row q of idx / dist (nq x k) holds count[q] = min(k, n)
+ * neighbours in ascending distance = sqrt(d2); k == 0 or n == 0 -> count = 0.  k <= 65. */
+tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *queries, size_t nq, size_t k,
+                 uint32_t *idx, float *dist, uint32_t *count);
+tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, size_t k,
+                        uint32_t *d_idx, float *d_dist, uint32_t *d_count);
+
 /* ---- voxel_grid_filter ----
  * voxel_grid_filter(&PointCloud<Point3f>, voxel_size) -> Result<PointCloud<Point3f>>
  * (threecrate-algorithms/src/filtering.rs:38-133): one f32 centroid per occupied voxel, keys

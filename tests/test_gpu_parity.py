@@ -281,3 +281,32 @@ def test_voxel_grid_filter_kats_and_errors(ctx):
     torch = pytest.importorskip("torch")
     d = ctx.voxel_grid_filter(torch.from_numpy(frame).cuda(), 0.2)
     assert np.array_equal(d.cpu().numpy(), O.voxel_grid_filter(frame, 0.2))
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 17, 32])
+def test_knn_export_matches_kdtree(ctx, k):
+    """find_k_nearest (nearest_neighbor.rs:177-251): same neighbour sets, bit-identical distances,
+    ascending order; queries inside, on and far outside the cloud."""
+    pts = synth.uniform_cloud(30000, seed=2)
+    inside = synth.uniform_cloud(1500, seed=12)
+    outside = (synth.uniform_cloud(500, seed=13) * 3.0 - 1.0).astype(np.float32)
+    qs = np.concatenate([inside, outside, pts[:200]])
+    gi, gd, gc = ctx.find_k_nearest_batch(pts, qs, k)
+    oi, od, oc = O.knn_batch(pts, qs, k)
+    assert np.array_equal(gc, oc) and (gc == k).all()
+    assert np.array_equal(gd, od)
+    assert np.all(np.diff(gd, axis=1) >= 0)
+    same = np.array([set(a.tolist()) == set(b.tolist()) for a, b in zip(gi, oi.astype(np.int64))])
+    assert same.all()
+
+
+def test_knn_export_edge_cases(ctx):
+    """nearest_neighbor.rs:541-563 (k = 0, k > n) and the unit-cube KAT (:429-483)"""
+    cube = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [1, 0, 1], [0, 1, 1], [1, 1, 1]], np.float32)
+    idx, dist, cnt = ctx.find_k_nearest_batch(cube, np.array([[0, 0, 0]], np.float32), 0)
+    assert cnt[0] == 0
+    idx, dist, cnt = ctx.find_k_nearest_batch(cube, np.array([[0, 0, 0]], np.float32), 20)
+    assert cnt[0] == 8 and np.all(np.diff(dist[0, :8]) >= 0)
+    res = ctx.find_k_nearest(cube, [0.5, 0.5, 0.5], 3)
+    bi, bd = O.brute_knn(cube, [0.5, 0.5, 0.5], 3)
+    assert len(res) == 3 and np.allclose([d for _, d in res], bd, atol=1e-6)

@@ -49,7 +49,7 @@ EXPORTS = [
     "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
     "tc_icp_shard_reduce", "tc_icp_shard_get_sums", "tc_icp_shard_set_sums", "tc_icp_shard_done",
     "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
-    "tc_voxel_grid_filter", "tc_voxel_grid_filter_device", "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
+    "tc_knn", "tc_knn_device", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device", "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
 ]
 
 _lib = None
@@ -119,6 +119,8 @@ def load():
     L.tc_icp_shard_finish.argtypes = [vp, sz, resp]
     L.tc_icp_shard_destroy.argtypes = [vp]
     L.tc_icp_shard_destroy.restype = None
+    L.tc_knn.argtypes = [vp, f32p, sz, f32p, sz, sz, vp, vp, vp]
+    L.tc_knn_device.argtypes = [vp, f32p, sz, f32p, sz, sz, vp, vp, vp]
     L.tc_voxel_grid_filter.argtypes = [vp, f32p, sz, f, f32p, C.POINTER(C.c_size_t)]
     L.tc_voxel_grid_filter_device.argtypes = [vp, f32p, sz, f, f32p, C.POINTER(C.c_size_t)]
     L.tc_profile_enable.argtypes = [vp, i]

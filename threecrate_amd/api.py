@@ -178,6 +178,25 @@ class GpuContext:
         """GpuContext::compute_normals (threecrate-gpu/src/normals.rs:367-374): normals only (N, 3)."""
         return self.estimate_normals(points, k)[:, 3:]
 
+    # ---- batch k-NN ----
+    def find_k_nearest_batch(self, cloud, queries, k: int):
+        """gpu_find_k_nearest_batch (threecrate-gpu/src/nearest_neighbor.rs:345-355) /
+        KdTree.knn (threecrate-python/src/lib.rs:735-745): (idx (nq,k) int64, dist (nq,k) f32, count (nq,)).
+        Rows are ascending by distance; entries past count[q] are undefined."""
+        c, q = _as_host(cloud), _as_host(queries)
+        kk = max(int(k), 1)
+        idx = np.zeros((len(q), kk), np.uint32)
+        dist = np.zeros((len(q), kk), np.float32)
+        cnt = np.zeros(len(q), np.uint32)
+        self._check(self._L.tc_knn(self._h, c.ctypes.data, c.shape[0], q.ctypes.data, q.shape[0], int(k), idx.ctypes.data,
+                                   dist.ctypes.data, cnt.ctypes.data))
+        return idx.astype(np.int64), dist, cnt
+
+    def find_k_nearest(self, cloud, query, k: int):
+        """gpu_find_k_nearest (threecrate-gpu/src/nearest_neighbor.rs:332-343): [(index, distance), ...]"""
+        idx, dist, cnt = self.find_k_nearest_batch(cloud, np.asarray(query, np.float32).reshape(1, 3), k)
+        return [(int(idx[0, i]), float(dist[0, i])) for i in range(int(cnt[0]))]
+
     # ---- voxel grid filter ----
     def voxel_grid_filter(self, cloud, voxel_size: float):
         """filtering.rs:38-133 -> (M, 3) centroids, sorted by voxel key (kx, ky, kz)."""

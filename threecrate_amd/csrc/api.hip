@@ -305,6 +305,46 @@ tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp
     return TC_OK;
 }
 
+// ---- batch k-NN (nearest_neighbor.rs:177-251; gpu/nearest_neighbor.rs:332-355) ----------------
+tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, size_t k,
+                        uint32_t *d_idx, float *d_dist, uint32_t *d_count) {
+    if (!ctx) return TC_INVALID_DATA;
+    if (nq == 0) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (k == 0 || n == 0) {        // nearest_neighbor.rs:178-180: empty result
+        TC_HIP_TRY(ctx, hipMemsetAsync(d_count, 0, nq * sizeof(uint32_t), ctx->stream));
+        TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return TC_OK;
+    }
+    if (n >= 0xFFFFFFF0ull || nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1) * 2.0f, nullptr, nullptr)) return s;
+    if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k, d_idx, d_dist, d_count)) return s;
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *queries, size_t nq, size_t k,
+                 uint32_t *idx, float *dist, uint32_t *count) {
+    if (!ctx) return TC_INVALID_DATA;
+    if (nq == 0) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (k == 0 || n == 0) { std::memset(count, 0, nq * sizeof(uint32_t)); return TC_OK; }
+    if (tc_status s = ensure(ctx, ctx->in_a, n * 3 * sizeof(float))) return s;
+    if (tc_status s = ensure(ctx, ctx->in_b, nq * 3 * sizeof(float))) return s;
+    if (tc_status s = ensure(ctx, ctx->out_a, nq * k * 8 + nq * 4)) return s;
+    uint32_t *d_idx = (uint32_t *)ctx->out_a.p;
+    float *d_dist = (float *)(d_idx + nq * k);
+    uint32_t *d_cnt = (uint32_t *)(d_dist + nq * k);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, cloud, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_b.p, queries, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (tc_status s = tc_knn_device(ctx, (const float *)ctx->in_a.p, n, (const float *)ctx->in_b.p, nq, k, d_idx, d_dist, d_cnt)) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(idx, d_idx, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(count, d_cnt, nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
 // ---- voxel_grid_filter (filtering.rs:38-133) --------------------------------------------------
 static tc_status voxel_validate(tc_context *ctx, size_t n, float voxel, size_t *n_out, bool *empty) {
     *empty = false;

@@ -352,6 +352,103 @@ static void launch_variant(hipStream_t st, const GridView &gv, const NormalParam
     hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
 }
 
+// ---- batch k-NN export -----------------------------------------------------
+// NearestNeighborSearch::find_k_nearest (nearest_neighbor.rs:177-251, trait core/traits.rs:6-12;
+// gpu_find_k_nearest_batch threecrate-gpu/src/nearest_neighbor.rs:345-355): for every query the k
+// nearest cloud points, ascending, as (original index, sqrt(d2)).  Same machinery as the normals
+// kernel: sorted register list for the k-th distance, ball-pruned ring continuation (queries may lie
+// outside the grid: |p - q|^2 >= |p - clamp(q)|^2 + |q - clamp(q)|^2), LDS position lists, ranking.
+template <int L, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__restrict__ queries, uint32_t nq, uint32_t k,
+                                                    uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
+                                                    uint32_t *__restrict__ out_count) {
+    __shared__ uint32_t ldsA_[L * BLOCK];
+    __shared__ uint32_t ldsB_[L * BLOCK];
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= nq) return;
+    uint32_t *ldsA = ldsA_ + threadIdx.x, *ldsB = ldsB_ + threadIdx.x;
+    const GridGeom &g = gv.g;
+    float4 q;
+    q.x = queries[3 * (size_t)t]; q.y = queries[3 * (size_t)t + 1]; q.z = queries[3 * (size_t)t + 2]; q.w = 0.0f;
+    const float qx = fminf(fmaxf(q.x, g.minx), g.maxx), qy = fminf(fmaxf(q.y, g.miny), g.maxy), qz = fminf(fmaxf(q.z, g.minz), g.maxz);
+    const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx), cy = cell_coord(qy, g.miny, g.inv_h, g.gy), cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
+    const float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy, fz = (qz - g.minz) * g.inv_h - (float)cz;
+    const float mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
+    const float ex = q.x - qx, ey = q.y - qy, ez = q.z - qz;
+    const float out2 = (ex * ex + ey * ey + ez * ez) * 0.9999f;
+    const uint32_t K1 = min(k, g.n);
+    float d[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) d[i] = INFINITY;
+    auto visit1 = [&](uint32_t, const float4 &c) { list_insert<L>(d, d2_nc(c.x, c.y, c.z, q.x, q.y, q.z)); };
+    int R = 1;
+    float tau = INFINITY;
+    scan_block(gv, cx, cy, cz, R, visit1);
+    for (;;) {
+        tau = d[0];
+#pragma unroll
+        for (int i = 1; i < L; ++i) tau = ((uint32_t)i == K1 - 1) ? d[i] : tau;
+        const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
+                            (cz - R <= 0) && (cz + R >= g.gz - 1);
+        const float bound = ((float)R + mf - 2e-3f) * g.h;
+        if (covers || tau <= bound * bound + out2) break;
+        ++R;
+        if (!scan_pruned(gv, q, cx, cy, cz, R - 1, R, tau, visit1)) {
+            tau = d[0];
+#pragma unroll
+            for (int i = 1; i < L; ++i) tau = ((uint32_t)i == K1 - 1) ? d[i] : tau;
+            break;
+        }
+    }
+    uint32_t n_lt = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) n_lt += (d[i] < tau) ? 1u : 0u;
+    const uint32_t quota = K1 - min(n_lt, K1);
+    uint32_t cnt = 0, ties = 0;
+    scan_pruned(gv, q, cx, cy, cz, -1, R, tau, [&](uint32_t j, const float4 &c) {
+        const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+        bool take = v < tau;
+        if (!take && v == tau && ties < quota) { take = true; ++ties; }
+        if (take && cnt < K1) { ldsA[cnt * BLOCK] = j; ++cnt; }
+    });
+    unsigned long long taken_lo = 0ull, taken_hi = 0ull;
+    auto is_taken = [&](uint32_t r) { return r < 64 ? ((taken_lo >> r) & 1ull) : ((taken_hi >> (r - 64)) & 1ull); };
+    for (uint32_t e = 0; e < cnt; ++e) {
+        const uint32_t j = ldsA[e * BLOCK];
+        const float4 c = gv.pts[j];
+        const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) r += (d[i] < v) ? 1u : 0u;
+        while (is_taken(r)) ++r;
+        if (r < 64) taken_lo |= 1ull << r; else taken_hi |= 1ull << (r - 64);
+        ldsB[r * BLOCK] = j;
+    }
+    for (uint32_t r = 0; r < cnt; ++r) {
+        const float4 c = gv.pts[ldsB[r * BLOCK]];
+        out_idx[(size_t)t * k + r] = __float_as_uint(c.w);
+        out_dist[(size_t)t * k + r] = sqrtf(d2_nc(c.x, c.y, c.z, q.x, q.y, q.z));     // nearest_neighbor.rs:249
+    }
+    out_count[t] = cnt;
+}
+
+tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, size_t k,
+                     uint32_t *d_idx, float *d_dist, uint32_t *d_count) {
+    if (k > 65) return fail(ctx, TC_UNSUPPORTED, "k > 65 is not supported by the HIP k-NN export");
+    const GridView gv = view_of(ix);
+    ProfScope ps(ctx, "knn_batch");
+    hipStream_t st = ctx->stream;
+#define TC_KNN(LL, BB) hipLaunchKernelGGL((knn_kernel<LL, BB>), dim3((unsigned)((nq + BB - 1) / BB)), dim3(BB), 0, st, gv, d_queries, \
+                                          (uint32_t)nq, (uint32_t)k, d_idx, d_dist, d_count)
+    if (k <= 9) TC_KNN(9, 256);
+    else if (k <= 17) TC_KNN(17, 256);
+    else if (k <= 33) TC_KNN(33, 128);
+    else TC_KNN(65, 64);
+#undef TC_KNN
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg, const float vp[3],
                          float *d_out6) {
     if (cfg.k_neighbors + 1 > 65) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 64 is not supported by the HIP backend");

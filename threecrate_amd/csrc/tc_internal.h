@@ -176,6 +176,9 @@ tc_status voxel_filter_device(tc_context *ctx, const float *d_xyz, size_t n, flo
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg,
                          const float vp[3], float *d_out6);
 
+tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, size_t k,
+                     uint32_t *d_idx, float *d_dist, uint32_t *d_count);
+
 // icp.hip
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters,
