@@ -197,6 +197,27 @@ tc_status   tc_icp_shard_apply(tc_icp_shard *s);               /* solve + compos
 tc_status   tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *result);
 void        tc_icp_shard_destroy(tc_icp_shard *s);
 
+/* ---- multiscale ICP ----
+ * multiscale_icp_point_to_point(source, target, init, &MultiScaleIcpConfig) -> Result<ICPResult>
+ * (threecrate-algorithms/src/registration.rs:704-789; config :26-71): per level voxel_grid_filter both
+ * clouds, icp_point_to_point from the running transform, then a full-resolution refinement;
+ * iterations are summed.  max_correspondence_distance < 0 encodes None. */
+typedef struct tc_icp_scale_level {          /* IcpScaleLevel, registration.rs:27-35 */
+    float  voxel_size;
+    size_t max_iterations;
+    float  max_correspondence_distance;
+} tc_icp_scale_level;
+typedef struct tc_multiscale_icp_config {    /* MultiScaleIcpConfig, registration.rs:38-44 */
+    const tc_icp_scale_level *levels;
+    size_t n_levels;
+    size_t final_refinement_iterations;
+    float  final_max_correspondence_distance;
+    float  convergence_threshold;
+} tc_multiscale_icp_config;
+tc_status tc_multiscale_icp_point_to_point(tc_context *ctx, const float *source, size_t n_source,
+                          const float *target, size_t n_target, const float init[7],
+                          const tc_multiscale_icp_config *config, tc_icp_result *result);
+
 /* ---- batch k-NN export ----
  * NearestNeighborSearch::find_k_nearest(&query, k) -> Vec<(usize, f32)> for many queries
  * (threecrate-core/src/traits.rs:6-12, threecrate-algorithms/src/nearest_neighbor.rs:177-251;

@@ -321,3 +321,28 @@ def isometry_to_matrix(T):
     T7, m = _f32(T).reshape(7), np.zeros(16, np.float32)
     lib().tco_isometry_to_matrix(_p(T7), _p(m))
     return m.reshape(4, 4)
+
+
+def multiscale_icp_point_to_point(src, tgt, init, levels, final_refinement_iterations, final_max_correspondence_distance,
+                                  convergence_threshold, threads=0):
+    """registration.rs:704-789 composed from the restated pieces (voxel_grid_filter + icp_point_to_point).
+    levels = [(voxel_size, max_iterations, max_correspondence_distance or None), ...]"""
+    s, t = _f32(src, 3), _f32(tgt, 3)
+    if len(s) == 0 or len(t) == 0 or len(levels) == 0 or not (convergence_threshold > 0) or final_refinement_iterations == 0:
+        raise OracleError(INVALID_DATA)
+    cur = _f32(IDENTITY if init is None else init).reshape(7)
+    total, last = 0, None
+    for voxel, iters, md in levels:
+        if not (voxel > 0) or iters == 0:
+            raise OracleError(INVALID_DATA)
+        sd, td = voxel_grid_filter(s, voxel), voxel_grid_filter(t, voxel)
+        if len(sd) < 3 or len(td) < 3:
+            continue
+        last = icp_point_to_point(sd, td, cur, iters, convergence_threshold, md, threads)
+        cur = last.transformation
+        total += last.iterations
+    if last is None:
+        raise OracleError(ALGORITHM)
+    fin = icp_point_to_point(s, t, cur, final_refinement_iterations, convergence_threshold, final_max_correspondence_distance, threads)
+    fin.iterations += total
+    return fin

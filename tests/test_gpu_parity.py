@@ -310,3 +310,24 @@ def test_knn_export_edge_cases(ctx):
     res = ctx.find_k_nearest(cube, [0.5, 0.5, 0.5], 3)
     bi, bd = O.brute_knn(cube, [0.5, 0.5, 0.5], 3)
     assert len(res) == 3 and np.allclose([d for _, d in res], bd, atol=1e-6)
+
+
+def test_multiscale_icp_matches_oracle(ctx):
+    """multiscale_icp_point_to_point (registration.rs:704-789; the reference has no unit test for it):
+    default pyramid (0.20 / 0.10 / 0.05 voxels + refinement) on a 60k-point room-sized cloud."""
+    import threecrate_amd as tc
+    pts = synth.uniform_cloud(60000, seed=21, scale=(6.0, 5.0, 2.5))
+    T = synth.yaw_isometry((0.08, -0.05, 0.03), 0.02)
+    Minv = synth.invert_isometry(T)
+    src = (pts.astype(np.float64) @ Minv[:3, :3].T + Minv[:3, 3]).astype(np.float32)
+    cfg = tc.MultiScaleIcpConfig()
+    g = ctx.multiscale_icp_point_to_point(src, pts, None, cfg)
+    r = O.multiscale_icp_point_to_point(src, pts, None, [(l.voxel_size, l.max_iterations, l.max_correspondence_distance) for l in cfg.levels],
+                                        cfg.final_refinement_iterations, cfg.final_max_correspondence_distance, cfg.convergence_threshold)
+    assert (g.iterations, g.converged) == (r.iterations, r.converged)
+    assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= 1e-5
+    assert np.linalg.norm(O.isometry_to_matrix(g.transformation).astype(np.float64) - synth.isometry_matrix(T)) < 1e-4
+    with pytest.raises(tc.InvalidData):
+        ctx.multiscale_icp_point_to_point(src, pts, None, tc.MultiScaleIcpConfig(levels=[]))
+    with pytest.raises(tc.InvalidData):
+        ctx.multiscale_icp_point_to_point(src, pts, None, tc.MultiScaleIcpConfig(convergence_threshold=0.0))

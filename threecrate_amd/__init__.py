@@ -6,6 +6,7 @@ operator interface for that one path (estimate_normals / icp / icp_point_to_plan
 threecrate-gpu facade).  It never falls back to a CPU implementation.
 """
 from .api import (  # noqa: F401
+    IcpScaleLevel, MultiScaleIcpConfig,
     AlgorithmError, BatchICPJob, BatchICPResult, Error, GpuContext, GpuError, ICPResult, IDENTITY, InvalidData,
     NormalEstimationConfig, Unsupported, default_context, estimate_normals, estimate_normals_radius,
     estimate_normals_with_config, gpu_batch_icp, gpu_estimate_normals, gpu_icp, gpu_icp_point_to_plane, icp,

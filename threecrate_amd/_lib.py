@@ -36,6 +36,15 @@ class BatchResultC(C.Structure):
                 ("iterations", C.c_uint64), ("status", C.c_int32)]
 
 
+class ScaleLevelC(C.Structure):
+    _fields_ = [("voxel_size", C.c_float), ("max_iterations", C.c_size_t), ("max_correspondence_distance", C.c_float)]
+
+
+class MultiScaleConfigC(C.Structure):
+    _fields_ = [("levels", C.POINTER(ScaleLevelC)), ("n_levels", C.c_size_t), ("final_refinement_iterations", C.c_size_t),
+                ("final_max_correspondence_distance", C.c_float), ("convergence_threshold", C.c_float)]
+
+
 class KernelStatC(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -49,7 +58,7 @@ EXPORTS = [
     "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
     "tc_icp_shard_reduce", "tc_icp_shard_get_sums", "tc_icp_shard_set_sums", "tc_icp_shard_done",
     "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
-    "tc_knn", "tc_knn_device", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device", "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
+    "tc_multiscale_icp_point_to_point", "tc_knn", "tc_knn_device", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device", "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
 ]
 
 _lib = None
@@ -119,6 +128,7 @@ def load():
     L.tc_icp_shard_finish.argtypes = [vp, sz, resp]
     L.tc_icp_shard_destroy.argtypes = [vp]
     L.tc_icp_shard_destroy.restype = None
+    L.tc_multiscale_icp_point_to_point.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(MultiScaleConfigC), resp]
     L.tc_knn.argtypes = [vp, f32p, sz, f32p, sz, sz, vp, vp, vp]
     L.tc_knn_device.argtypes = [vp, f32p, sz, f32p, sz, sz, vp, vp, vp]
     L.tc_voxel_grid_filter.argtypes = [vp, f32p, sz, f, f32p, C.POINTER(C.c_size_t)]

@@ -55,6 +55,24 @@ class NormalEstimationConfig:
 
 
 @dataclass
+class IcpScaleLevel:
+    """registration.rs:27-35"""
+    voxel_size: float
+    max_iterations: int
+    max_correspondence_distance: Optional[float] = None
+
+
+@dataclass
+class MultiScaleIcpConfig:
+    """registration.rs:38-71 (same defaults)"""
+    levels: list = field(default_factory=lambda: [IcpScaleLevel(0.20, 10, 0.50), IcpScaleLevel(0.10, 10, 0.25),
+                                                  IcpScaleLevel(0.05, 15, 0.15)])
+    final_refinement_iterations: int = 10
+    final_max_correspondence_distance: Optional[float] = 0.10
+    convergence_threshold: float = 1e-5
+
+
+@dataclass
 class ICPResult:
     """registration.rs:13-24; `transformation` is the 7-float Isometry3 (qi qj qk qw tx ty tz)."""
     transformation: np.ndarray
@@ -269,6 +287,25 @@ class GpuContext:
         self._check(self._L.tc_icp(self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], i7.ctypes.data, max_iters,
                                    out.ctypes.data))
         return out
+
+    def multiscale_icp_point_to_point(self, source, target, init=None, config=None):
+        """registration.rs:704-789"""
+        cfg = config or MultiScaleIcpConfig()
+        s, t = _as_host(source), _as_host(target)
+        i7 = np.ascontiguousarray(IDENTITY if init is None else np.asarray(init, np.float32).reshape(7))
+        lv = (_lib.ScaleLevelC * max(1, len(cfg.levels)))()
+        for i, l in enumerate(cfg.levels):
+            lv[i].voxel_size, lv[i].max_iterations = float(l.voxel_size), int(l.max_iterations)
+            lv[i].max_correspondence_distance = -1.0 if l.max_correspondence_distance is None else float(l.max_correspondence_distance)
+        c = _lib.MultiScaleConfigC(lv, len(cfg.levels), int(cfg.final_refinement_iterations),
+                                   -1.0 if cfg.final_max_correspondence_distance is None else float(cfg.final_max_correspondence_distance),
+                                   float(cfg.convergence_threshold))
+        r = _lib.IcpResultC()
+        corr = np.empty(max(1, s.shape[0]), np.uint32)
+        r.corr_target = corr.ctypes.data
+        self._check(self._L.tc_multiscale_icp_point_to_point(self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0],
+                                                             i7.ctypes.data, C.byref(c), C.byref(r)))
+        return self._result(r, s.shape[0], corr[: s.shape[0]], True)
 
     def icp_point_to_plane_detailed(self, source, target, target_normals, init=None, max_iters=50,
                                     max_correspondence_distance=None, convergence_threshold=1e-6, correspondences=True):

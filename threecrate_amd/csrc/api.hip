@@ -305,6 +305,67 @@ tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp
     return TC_OK;
 }
 
+// ---- multiscale ICP (registration.rs:704-789) ---------------------------------------------------
+tc_status tc_multiscale_icp_point_to_point(tc_context *ctx, const float *source, size_t ns, const float *target, size_t nt,
+                                           const float init[7], const tc_multiscale_icp_config *cfg, tc_icp_result *result) {
+    if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
+    if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");              // :710-714
+    if (cfg->n_levels == 0) return fail(ctx, TC_INVALID_DATA, "At least one ICP scale level is required");          // :715-719
+    if (!(cfg->convergence_threshold > 0.0f)) return fail(ctx, TC_INVALID_DATA, "Convergence threshold must be positive");   // :720-724
+    if (cfg->final_refinement_iterations == 0) return fail(ctx, TC_INVALID_DATA, "Final refinement iterations must be positive");   // :725-729
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // full-resolution clouds and the per-level down-sampled clouds live in caller-independent buffers
+    DevBuf full_s, full_t, down_s, down_t;
+    auto cleanup = [&]() { for (DevBuf *b : {&full_s, &full_t, &down_s, &down_t}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } };
+    tc_status st = TC_OK;
+    if ((st = ensure(ctx, full_s, ns * 12)) || (st = ensure(ctx, full_t, nt * 12)) || (st = ensure(ctx, down_s, ns * 12)) ||
+        (st = ensure(ctx, down_t, nt * 12))) { cleanup(); return st; }
+    (void)hipMemcpyAsync(full_s.p, source, ns * 12, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(full_t.p, target, nt * 12, hipMemcpyHostToDevice, ctx->stream);
+    float cur[7];
+    std::memcpy(cur, init, sizeof(cur));
+    uint64_t total_iters = 0;
+    bool any = false;
+    tc_icp_result r;
+    for (size_t l = 0; l < cfg->n_levels; ++l) {
+        const tc_icp_scale_level &lv = cfg->levels[l];
+        if (!(lv.voxel_size > 0.0f)) { cleanup(); return fail(ctx, TC_INVALID_DATA, "Scale voxel_size must be positive"); }       // :736-740
+        if (lv.max_iterations == 0) { cleanup(); return fail(ctx, TC_INVALID_DATA, "Scale max_iterations must be positive"); }    // :741-745
+        size_t nds = 0, ndt = 0;
+        if ((st = voxel_filter_device(ctx, (const float *)full_s.p, ns, lv.voxel_size, (float *)down_s.p, &nds)) ||
+            (st = voxel_filter_device(ctx, (const float *)full_t.p, nt, lv.voxel_size, (float *)down_t.p, &ndt))) { cleanup(); return st; }
+        if (nds < 3 || ndt < 3) continue;                                                                             // :749-751
+        std::memset(&r, 0, sizeof(r));
+        st = icp_run(ctx, false, (const float *)down_s.p, nds, (const float *)down_t.p, ndt, nullptr, 0, cur, lv.max_iterations,
+                     lv.max_correspondence_distance, cfg->convergence_threshold, &r, true);
+        if (st != TC_OK) { cleanup(); return st; }
+        std::memcpy(cur, r.transformation, sizeof(cur));
+        total_iters += r.iterations;
+        any = true;
+    }
+    if (!any) { cleanup(); return fail(ctx, TC_ALGORITHM, "No multiscale ICP level had enough downsampled points"); }   // :767-771
+    tc_icp_result fin;
+    std::memset(&fin, 0, sizeof(fin));
+    DevBuf dcorr;
+    if (result->corr_target) {
+        if ((st = ensure(ctx, dcorr, ns * 4))) { cleanup(); return st; }
+        fin.corr_target = (uint32_t *)dcorr.p;
+    }
+    st = icp_run(ctx, false, (const float *)full_s.p, ns, (const float *)full_t.p, nt, nullptr, 0, cur, cfg->final_refinement_iterations,
+                 cfg->final_max_correspondence_distance, cfg->convergence_threshold, &fin, true);
+    if (st == TC_OK) {
+        std::memcpy(result->transformation, fin.transformation, sizeof(fin.transformation));
+        result->mse = fin.mse;
+        result->iterations = total_iters + fin.iterations;                                                           // :782-788
+        result->converged = fin.converged;
+        result->n_correspondences = fin.n_correspondences;
+        if (result->corr_target) (void)hipMemcpy(result->corr_target, dcorr.p, ns * 4, hipMemcpyDeviceToHost);
+    }
+    if (dcorr.p) (void)hipFree(dcorr.p);
+    cleanup();
+    return st;
+}
+
 // ---- batch k-NN (nearest_neighbor.rs:177-251; gpu/nearest_neighbor.rs:332-355) ----------------
 tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, size_t k,
                         uint32_t *d_idx, float *d_dist, uint32_t *d_count) {
