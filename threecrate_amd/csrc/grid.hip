@@ -323,14 +323,17 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         nkeys = (uint32_t)nk;
     }
 
-    if (tc_status s = ensure(ctx, ix.pts, n * sizeof(float4))) return s;
+    if (tc_status s = ensure(ctx, ix.pts, (n + kPtsPad) * sizeof(float4))) return s;
     if (tc_status s = ensure(ctx, ix.cell_of, n * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, ix.slot, n * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, ix.arrival, n * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, ix.fill, (size_t)nkeys * sizeof(uint32_t))) return s;
-    if (tc_status s = ensure(ctx, ix.cell_start, ((size_t)nkeys + 1) * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.cell_start, ((size_t)nkeys + 1 + kCellStartPad) * sizeof(uint32_t))) return s;
 
     TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)nkeys * sizeof(uint32_t), st));
+    // records past the end: huge finite coordinates -> d2 = +inf, never a match (kernels may read, never select them)
+    TC_HIP_TRY(ctx, hipMemsetAsync((float4 *)ix.pts.p + n, 0x7F, kPtsPad * sizeof(float4), st));
+    TC_HIP_TRY(ctx, hipMemsetAsync((uint32_t *)ix.cell_start.p + nkeys + 1, 0, kCellStartPad * sizeof(uint32_t), st));
     {
         ProfScope ps(ctx, "cell_hist");
         hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0,

@@ -130,6 +130,19 @@ __device__ __forceinline__ void nn_search_global(const GridView &gv, float x, fl
     }
 }
 
+// sum over the 64 lanes of a wave, returned in every lane (wave-uniform): four DPP steps inside the
+// rows of 16 lanes, two row broadcasts, total read from lane 63.  One VALU instruction per step
+// (no LDS crossbar traffic); the summation tree is fixed, so results are run-to-run identical.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); // row_bcast15 -> rows 1, 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)); // row_bcast31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 template <int NACC, int NW = kIcpBlock / 64>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *__restrict__ out_row, double (*sm)[TC_ICP_SUMS_STRIDE],
                                                    double extra = 0.0) {
@@ -174,24 +187,28 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *
 // (registration.rs:417-427); a lane adds its handful of pairs in f32, then wave shuffles -> LDS
 // -> per-block partial rows in f64, folded in a fixed order by icp_finalize_kernel.
 
-struct Span9 {
-    uint32_t s[9], e[9];
-};
+// The (up to) nine row spans of a query live in LDS ([row][lane], one ds_read_b64 per span switch)
+// instead of 18 registers + a select chain: the main kernel is bound by loads in flight, i.e. by
+// waves per SIMD, i.e. by its VGPR count.
+constexpr int kSpanRows = 9;
 
-__device__ __forceinline__ void span_select(const Span9 &sp, int k, uint32_t &s, uint32_t &e) {
-    s = sp.s[0]; e = sp.e[0];
-#pragma unroll
-    for (int i = 1; i < 9; ++i) {
-        s = (k == i) ? sp.s[i] : s;
-        e = (k == i) ? sp.e[i] : e;
-    }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+
+// raw buffer descriptor over a whole allocation (no range check: 4 GiB window): buffer loads take a
+// 32-bit byte offset per lane (no 64-bit address arithmetic) and accept dword-aligned 16-byte reads
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0xFFFFFFFF, 0x00020000);
 }
 
 // exact 1-NN of (x, y, z); ub2 = a valid upper bound of the squared NN distance (or +inf)
 __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, float y, float z, float ub2,
-                                                 float &best, uint32_t &bestj, bool &refine, int &cx, int &cy,
-                                                 int &cz, float &mf, float &out2, float max_dist) {
+                                                 float &best, uint32_t &bestj, bool &refine, float max_dist,
+                                                 uint2 (*spans)[kIcpBlock], int dbg = 0) {
     const GridGeom &g = gv.g;
+    int cx, cy, cz;
+    float mf, out2;
     const float qx = fminf(fmaxf(x, g.minx), g.maxx), qy = fminf(fmaxf(y, g.miny), g.maxy),
                 qz = fminf(fmaxf(z, g.minz), g.maxz);
     cx = cell_coord(qx, g.minx, g.inv_h, g.gx);
@@ -209,58 +226,73 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     const float ay2[3] = {lo_y * lo_y, 0.0f, hi_y * hi_y};
     const float az2[3] = {lo_z * lo_z, 0.0f, hi_z * hi_z};
     const float ub = ub2 - out2;     // budget left inside the box (|p-q|^2 >= |p-q'|^2 + |q-q'|^2)
-    Span9 sp;
-    uint32_t mask = 0;
+    // One unaligned 16-byte window of cell_start per row, [row + cx - 1, row + cx + 2], issued for all
+    // nine rows back to back and without branches (one round trip): it holds the start of the left,
+    // own and right cell and the end of the right cell.  A row the ball does not reach reads window 0
+    // and becomes the empty span.  (cell_start is padded by kCellStartPad entries.)
+    const __amdgpu_buffer_rsrc_t cs_rsrc = raw_rsrc(gv.cell_start);
+    const int wb = max(cx - 1, 0);
+    uint32_t s0[kSpanRows], e0[kSpanRows];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < kSpanRows; ++k) {
         const int dz = k / 3 - 1, dy = k % 3 - 1;
         const int yy = cy + dy, zz = cz + dz;
         const float r2 = ay2[dy + 1] + az2[dz + 1];
-        bool on = (yy >= 0) && (yy < g.gy) && (zz >= 0) && (zz < g.gz) && !(r2 > ub);
+        const bool on = (yy >= 0) && (yy < g.gy) && (zz >= 0) && (zz < g.gz) && !(r2 > ub);
         // x window: the left / right cell only if the ball reaches it
-        const int xa = (cx > 0 && !(r2 + ax2[0] > ub)) ? cx - 1 : cx;
-        const int xb = (cx < g.gx - 1 && !(r2 + ax2[2] > ub)) ? cx + 1 : cx;
-        uint32_t s0 = 0, e0 = 0;
-        if (on) {
-            const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
-            s0 = gv.cell_start[row + xa];
-            e0 = gv.cell_start[row + xb + 1];
-        }
-        sp.s[k] = s0; sp.e[k] = e0;
-        if (on) mask |= 1u << k;
+        const bool left = cx > 0 && !(r2 + ax2[0] > ub), right = cx < g.gx - 1 && !(r2 + ax2[2] > ub);
+        const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(cs_rsrc, (on ? row + (uint32_t)wb : 0u) << 2, 0, 0);
+        // entry offsets: start of cell xa = cx - left, end of cell xb = cx + right
+        const int oa = cx - wb - (left ? 1 : 0);            // 0 or 1
+        const int ob = cx - wb + 1 + (right ? 1 : 0);       // 1, 2 or 3
+        const uint32_t sa = oa == 0 ? w.x : w.y;
+        const uint32_t eb = ob == 1 ? w.y : (ob == 2 ? w.z : w.w);
+        s0[k] = on ? sa : 0u;
+        e0[k] = on ? eb : 0u;
     }
+    uint32_t mask = 0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-        if (sp.s[k] == sp.e[k]) mask &= ~(1u << k);     // empty spans
-    // flattened walk over the surviving spans, four records per step (four independent gathers in
-    // flight per lane); a lane switches to its next span as soon as the current one is exhausted
-    unsigned long long bestkey = ~0ull;                 // (d2 bits << 32) | position
+    for (int k = 0; k < kSpanRows; ++k) {
+        spans[k][threadIdx.x] = make_uint2(s0[k], e0[k]);
+        if (s0[k] != e0[k]) mask |= 1u << k;            // non-empty spans only
+    }
+    if (dbg & 4) mask = 0;
+    // Flattened walk over the surviving spans, four records per step (four independent gathers in
+    // flight per lane); a lane switches to its next span as soon as the current one is exhausted.
+    // A step may read up to three records past its span: real target points of the next cells (or
+    // the +inf padding behind the array), harmless as extra candidates.  Rows are visited in ascending
+    // order = ascending position, so the strict '<' keeps the lowest position among equal distances.
+    const __amdgpu_buffer_rsrc_t pt_rsrc = raw_rsrc(gv.pts);
+    best = INFINITY;
+    bestj = 0xFFFFFFFFu;
     uint32_t j = 0, e = 0;
     while (true) {
         if (j >= e) {
             if (!mask) break;
             const int k = __ffs(mask) - 1;
             mask &= mask - 1;
-            span_select(sp, k, j, e);
+            const uint2 se = spans[k][threadIdx.x];
+            j = se.x; e = se.y;
         }
-        const uint32_t last = e - 1;
-        const uint32_t j0 = j, j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
-        const float4 c0 = gv.pts[j0], c1 = gv.pts[j1], c2 = gv.pts[j2], c3 = gv.pts[j3];
+        const uint32_t o = j << 4;                      // byte offset (positions < 2^28, checked by icp_setup)
+        const f32x3 c0 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o, 0, 0));
+        const f32x3 c1 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u, 0, 0));
+        const f32x3 c2 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 32u, 0, 0));
+        const f32x3 c3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 48u, 0, 0));
         const float v0 = d2_nc(c0.x, c0.y, c0.z, x, y, z), v1 = d2_nc(c1.x, c1.y, c1.z, x, y, z);
         const float v2 = d2_nc(c2.x, c2.y, c2.z, x, y, z), v3 = d2_nc(c3.x, c3.y, c3.z, x, y, z);
-        // duplicates (clamped positions) produce identical keys: harmless
-        const unsigned long long k0 = ((unsigned long long)__float_as_uint(v0) << 32) | j0;
-        const unsigned long long k1 = ((unsigned long long)__float_as_uint(v1) << 32) | j1;
-        const unsigned long long k2 = ((unsigned long long)__float_as_uint(v2) << 32) | j2;
-        const unsigned long long k3 = ((unsigned long long)__float_as_uint(v3) << 32) | j3;
-        const unsigned long long ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
-        const unsigned long long kc = ka < kb ? ka : kb;
-        bestkey = kc < bestkey ? kc : bestkey;
+        const bool b01 = v1 < v0, b23 = v3 < v2;
+        const float m01 = b01 ? v1 : v0, m23 = b23 ? v3 : v2;
+        const uint32_t i01 = b01 ? j + 1 : j, i23 = b23 ? j + 3 : j + 2;
+        const bool bb = m23 < m01;
+        const float m = bb ? m23 : m01;
+        const uint32_t im = bb ? i23 : i01;
+        const bool upd = m < best;
+        best = upd ? m : best;
+        bestj = upd ? im : bestj;
         j += 4;
     }
-    best = __uint_as_float((uint32_t)(bestkey >> 32));
-    bestj = (uint32_t)bestkey;
-    if (bestkey == ~0ull) { best = INFINITY; bestj = 0xFFFFFFFFu; }
     const bool covers = (cx - 1 <= 0) && (cx + 1 >= g.gx - 1) && (cy - 1 <= 0) && (cy + 1 >= g.gy - 1) &&
                         (cz - 1 <= 0) && (cz + 1 >= g.gz - 1);
     const float bound = (1.0f + mf - 2e-3f) * g.h;
@@ -302,9 +334,17 @@ __device__ __forceinline__ void accumulate_pair(const GridGeom &g, float (&acc)[
 
 // Main pass: ring-1 search (warm-start pruned).  Lanes whose ring-1 answer is not provably exact
 // (Poisson tail, queries outside the target's box) are NOT finished here: they go to a list served
-// by icp_refine_kernel in dense waves.  Keeping the ring>=2 code out of this kernel keeps its
-// register count (=> waves per SIMD) low; the kernel is bound by loads in flight.
-template <bool P2PLANE>
+// by icp_refine_kernel in dense waves.
+//
+// The kernel is bound by loads in flight = waves per SIMD = VGPRs, so the work of a group of
+// kIcpGroup x 256 points is split in two phases whose register sets do not add up:
+//   S  search: one point at a time, result -> corr_pos (no accumulators live);
+//   A  accumulate: the matched target records + normals of the lane's points are gathered together
+//      (independent loads, one round trip) and folded into the f32 per-lane sums, which are then
+//      wave-reduced into the block's f64 LDS row, so that nothing but that row survives the group.
+constexpr int kIcpGroup = 4;
+
+template <bool P2PLANE, int AW>
 __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
@@ -312,57 +352,107 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
     if (st->done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
+    __shared__ uint2 spans[kSpanRows][kIcpBlock];
+    __shared__ uint32_t rl_list[kIcpGroup * kIcpBlock];
+    __shared__ uint32_t rl_cnt, rl_base;
+    if (threadIdx.x == 0) rl_cnt = 0;
+    __syncthreads();
     const GridGeom &g = tgt.g;
     const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
     const float t[3] = {st->t[0], st->t[1], st->t[2]};
     const float max_dist = st->max_dist;
     const bool warm = st->iterations > 0 && !(dbg & 1);
-    float acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < TC_ICP_SUMS_STRIDE) red[w][lane] = 0.0;          // each wave owns one row
 
     const uint32_t lb = xcd_remap_icp(blockIdx.x, gridDim.x);
     const uint32_t beg = lb * chunk;
     const uint32_t end = min(beg + chunk, ns);
-    for (uint32_t jb = beg; jb < end; jb += kIcpBlock) {
-        const uint32_t j = jb + threadIdx.x;
-        if (j >= end) continue;
-        const float4 s = src[j];
-        float x, y, z;
-        iso_apply(q, t, s.x, s.y, s.z, x, y, z);
-        float ub2 = INFINITY;
-        if (warm) {
-            const uint32_t pj = corr_pos[j];
-            if (pj != 0xFFFFFFFFu) {
-                const float4 p = tgt.pts[pj];
-                ub2 = d2_nc(p.x, p.y, p.z, x, y, z);
+    for (uint32_t gb = beg; gb < end; gb += kIcpGroup * kIcpBlock) {
+        // ---- phase S ----
+        uint32_t ok = 0;
+#pragma unroll 1
+        for (int u = 0; u < kIcpGroup; ++u) {
+            const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
+            if (j >= end) break;
+            const float4 s = src[j];
+            float x, y, z;
+            iso_apply(q, t, s.x, s.y, s.z, x, y, z);
+            // branch-free warm start (corr_pos is allocated but meaningless before iteration 1)
+            uint32_t pj = corr_pos[j];
+            if (!warm) pj = 0xFFFFFFFFu;
+            const float4 p = tgt.pts[pj != 0xFFFFFFFFu ? pj : 0u];
+            float ub2 = pj != 0xFFFFFFFFu ? d2_nc(p.x, p.y, p.z, x, y, z) : INFINITY;
+            if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f);   // farther matches are rejected anyway
+            float best;
+            uint32_t bestg;
+            bool refine;
+            nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, max_dist, spans, dbg);
+            if (dbg & 12) refine = false;
+            if (refine) {
+                rl_list[atomicAdd(&rl_cnt, 1u)] = j;      // block-local list, flushed below
+                continue;
+            }
+            bool valid = bestg != 0xFFFFFFFFu;
+            if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
+            corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
+            if (valid && !(dbg & 8)) ok |= 1u << u;
+        }
+        // flush the block's refine list with ONE global atomic (thousands of per-wave atomics on
+        // one word serialise at ~90 per microsecond)
+        __syncthreads();
+        const uint32_t rl_n = rl_cnt;
+        if (rl_n) {
+            if (threadIdx.x == 0) rl_base = atomicAdd(&rlist[0], rl_n);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < rl_n; i += kIcpBlock) rlist[1 + rl_base + i] = rl_list[i];
+            __syncthreads();
+            if (threadIdx.x == 0) rl_cnt = 0;
+        }
+        // ---- phase A ----
+        float acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+#pragma unroll(AW == 1 ? 1 : kIcpGroup)
+        for (int u0 = 0; u0 < kIcpGroup; u0 += AW) {
+            float4 sv[AW], cv[AW], nv[AW];
+#pragma unroll
+            for (int v = 0; v < AW; ++v) {
+                const uint32_t j = gb + (u0 + v) * kIcpBlock + threadIdx.x;
+                const bool on = (ok >> (u0 + v)) & 1u;
+                sv[v] = cv[v] = nv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on) {
+                    sv[v] = src[j];
+                    const uint32_t pj = corr_pos[j];                 // this lane's own store of phase S
+                    cv[v] = tgt.pts[pj];
+                    if (P2PLANE) nv[v] = tgt_nrm[pj];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < AW; ++v) {
+                if ((ok >> (u0 + v)) & 1u) {
+                    float x, y, z;
+                    iso_apply(q, t, sv[v].x, sv[v].y, sv[v].z, x, y, z);
+                    accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, cv[v], nv[v]);
+                }
             }
         }
-        if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f);   // farther matches are rejected anyway
-        float best, mf, out2;
-        uint32_t bestg;
-        int cx, cy, cz;
-        bool refine;
-        nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, cx, cy, cz, mf, out2, max_dist);
-        if (refine) {
-            const uint32_t slot = atomicAdd(&rlist[0], 1u);
-            rlist[1 + slot] = j;
-            continue;
-        }
-        bool valid = bestg != 0xFFFFFFFFu;
-        if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
-        corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
-        if (valid) {
-            const float4 c = tgt.pts[bestg];
-            float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (P2PLANE) n = tgt_nrm[bestg];
-            accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, c, n);
+        // per-group fold: DPP wave sum (f32, fixed tree) -> this wave's f64 row
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            const float tot = wave_sum_f32(acc[i]);
+            if (lane == 0) red[w][i] += (double)tot;
         }
     }
-    double dacc[NACC];
+    __syncthreads();
+    if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
+        double sum = 0.0;
+        if (threadIdx.x < NACC) {
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) dacc[i] = (double)acc[i];
-    block_reduce_store<NACC>(dacc, partials + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE, red);
+            for (int w2 = 0; w2 < kIcpBlock / 64; ++w2) sum += red[w2][threadIdx.x];
+        }
+        partials[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = sum;
+    }
 }
 
 // Refine pass: the listed queries get the full ring search, kRG lanes per query: ring 1 = one cell
@@ -820,7 +910,8 @@ struct IcpLaunch {
 };
 static IcpLaunch plan_launch(size_t ns) {
     IcpLaunch l;
-    uint32_t nb = (uint32_t)std::min<size_t>((ns + kIcpBlock - 1) / kIcpBlock, (size_t)kMaxPartialBlocks);
+    static const int maxb = getenv("TC_MAXB") ? atoi(getenv("TC_MAXB")) : 1024;
+    uint32_t nb = (uint32_t)std::min<size_t>((ns + kIcpBlock - 1) / kIcpBlock, (size_t)std::min(maxb, kMaxPartialBlocks));
     nb = std::max<uint32_t>((nb + 7) / 8 * 8, 8);
     uint32_t chunk = (uint32_t)((ns + nb - 1) / nb);
     chunk = (chunk + kIcpBlock - 1) / kIcpBlock * kIcpBlock;
@@ -853,12 +944,11 @@ static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, 
     if (do_reduce) {
         {
             ProfScope ps(ctx, p2plane ? "icp_correspond_reduce_p2plane" : "icp_correspond_reduce_p2p", true);
-            if (p2plane)
-                hipLaunchKernelGGL(icp_correspond_reduce_kernel<true>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
-                                   l.chunk, st, corr_pos, rlist, partials, dbg);
-            else
-                hipLaunchKernelGGL(icp_correspond_reduce_kernel<false>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns,
-                                   l.chunk, st, corr_pos, rlist, partials, dbg);
+            static const int aw = getenv("TC_AW") ? atoi(getenv("TC_AW")) : 2;
+            auto kern = p2plane ? (aw == 1 ? icp_correspond_reduce_kernel<true, 1> : aw == 4 ? icp_correspond_reduce_kernel<true, 4> : icp_correspond_reduce_kernel<true, 2>)
+                                : (aw == 1 ? icp_correspond_reduce_kernel<false, 1> : aw == 4 ? icp_correspond_reduce_kernel<false, 4> : icp_correspond_reduce_kernel<false, 2>);
+            hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st, corr_pos, rlist,
+                               partials, dbg);
         }
         ProfScope ps(ctx, "icp_refine");
         if (p2plane)
