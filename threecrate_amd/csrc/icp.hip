@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     if (st->done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
     __shared__ uint2 spans[kSpanRows][kIcpBlock];
-    __shared__ uint32_t rl_list[kIcpGroup * kIcpBlock];
+    __shared__ uint2 rl_list[kIcpGroup * kIcpBlock];      // refine entries of the group: (source index, best known position)
     __shared__ uint32_t rl_cnt, rl_base;
     if (threadIdx.x == 0) rl_cnt = 0;
     __syncthreads();
@@ -382,7 +382,8 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
             uint32_t pj = corr_pos[j];
             if (!warm) pj = 0xFFFFFFFFu;
             const float4 p = tgt.pts[pj != 0xFFFFFFFFu ? pj : 0u];
-            float ub2 = pj != 0xFFFFFFFFu ? d2_nc(p.x, p.y, p.z, x, y, z) : INFINITY;
+            const float ub2p = pj != 0xFFFFFFFFu ? d2_nc(p.x, p.y, p.z, x, y, z) : INFINITY;
+            float ub2 = ub2p;
             if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f);   // farther matches are rejected anyway
             float best;
             uint32_t bestg;
@@ -390,7 +391,12 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
             nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, max_dist, spans, dbg);
             if (dbg & 12) refine = false;
             if (refine) {
-                rl_list[atomicAdd(&rl_cnt, 1u)] = j;      // block-local list, flushed below
+                // hand the refine pass the best real point seen so far: previous match or ring-1 best
+                // (everything of ring 1 inside the ball has been examined: the refine pass starts at ring 2)
+                const unsigned long long kp = pj != 0xFFFFFFFFu ? (((unsigned long long)__float_as_uint(ub2p) << 32) | pj) : ~0ull;
+                const unsigned long long kb = bestg != 0xFFFFFFFFu ? (((unsigned long long)__float_as_uint(best) << 32) | bestg) : ~0ull;
+                const unsigned long long km = kb < kp ? kb : kp;
+                rl_list[atomicAdd(&rl_cnt, 1u)] = make_uint2(j, km != ~0ull ? (uint32_t)km : 0xFFFFFFFFu);   // block-local list, flushed below
                 continue;
             }
             bool valid = bestg != 0xFFFFFFFFu;
@@ -405,7 +411,8 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
         if (rl_n) {
             if (threadIdx.x == 0) rl_base = atomicAdd(&rlist[0], rl_n);
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < rl_n; i += kIcpBlock) rlist[1 + rl_base + i] = rl_list[i];
+            uint2 *__restrict__ entries = reinterpret_cast<uint2 *>(rlist + 2);
+            for (uint32_t i = threadIdx.x; i < rl_n; i += kIcpBlock) entries[rl_base + i] = rl_list[i];
             __syncthreads();
             if (threadIdx.x == 0) rl_cnt = 0;
         }
@@ -455,14 +462,18 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     }
 }
 
-// Refine pass: the listed queries get the full ring search, kRG lanes per query: ring 1 = one cell
-// per lane, farther rings = the shell cells that the ball |p - q| <= best can reach (ball pruning,
-// stop as soon as a whole shell misses the ball).  ~2-3 dependent memory round trips per ring and
-// query instead of one per row, and thousands of waves in flight.  Per-block sums go to the
-// partial rows after the main pass's rows.
+// Refine pass: the listed queries (a few thousand per iteration: Poisson tail, queries outside the
+// target's box) continue with ring 2, 3, ... , kRG lanes per query.  A shell is visited as the cells
+// the ball |p - q| <= best can reach (ball pruning; a shell that misses the ball ends the search).
+// The pass is latency bound (few waves, every query a chain of dependent reads), so the chain is kept
+// short: the list entry carries (source index, best known target position), a lane takes four shell
+// cells at a time with all their cell_start reads, then all their record reads, in flight together,
+// and the shell enumeration of ring 2 is compile-time.  Per-block sums go to the partial rows after
+// the main pass's rows.
 constexpr int kRefineBlocks = 256;
 constexpr int kRefineThreads = 1024;
 constexpr int kRG = 32;                     // lanes per query
+constexpr int kRB = 4;                      // shell cells per lane and batch
 
 __device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v) {
 #pragma unroll
@@ -471,6 +482,84 @@ __device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v
         v = w < v ? w : v;
     }
     return v;
+}
+
+// offset of cell `idx` of the shell of radius R (W = 2R+1, V = W-2): two z faces (W x W), two y
+// faces (W x V), two x faces (V x V)
+__device__ __forceinline__ void shell_cell(int idx, int R, int W, int V, int &ox, int &oy, int &oz) {
+    const int nz = 2 * W * W, ny = 2 * W * V;
+    if (idx < nz) {
+        const int f = idx / (W * W), r = idx - f * W * W;
+        oz = f ? R : -R; oy = r / W - R; ox = r - (r / W) * W - R;
+    } else if (idx < nz + ny) {
+        const int i2 = idx - nz, f = i2 / (W * V), r = i2 - f * W * V;
+        oy = f ? R : -R; oz = r / W - (R - 1); ox = r - (r / W) * W - R;
+    } else {
+        const int i3 = idx - nz - ny, f = i3 / (V * V), r = i3 - f * V * V;
+        ox = f ? R : -R; oz = r / V - (R - 1); oy = r - (r / V) * V - (R - 1);
+    }
+}
+
+// one shell: returns the group's best key of the shell; touched = some cell of the shell lies in the ball
+template <int RC>      // RC > 0: compile-time radius (divisions by constants); RC == 0: run-time R
+__device__ __forceinline__ unsigned long long refine_shell(const GridView &tgt, const __amdgpu_buffer_rsrc_t &cs_rsrc,
+                                                           const __amdgpu_buffer_rsrc_t &pt_rsrc, int Rrt, int lg, float x, float y,
+                                                           float z, int cx, int cy, int cz, unsigned long long bestkey, bool &touched) {
+    const GridGeom &g = tgt.g;
+    const int R = RC > 0 ? RC : Rrt;
+    const int W = 2 * R + 1, V = W - 2;
+    const int ncell = 2 * W * W + 2 * W * V + 2 * V * V;
+    const float bestd = __uint_as_float((uint32_t)(bestkey >> 32));     // NaN pattern when empty
+    const bool have = bestkey != ~0ull;
+    unsigned long long lk = ~0ull;
+    touched = false;
+    for (int idx0 = lg; idx0 < ncell; idx0 += kRG * kRB) {
+        uint32_t s0[kRB], e0[kRB];
+#pragma unroll
+        for (int t = 0; t < kRB; ++t) {
+            const int idx = idx0 + t * kRG;
+            int ox = 0, oy = 0, oz = 0;
+            shell_cell(min(idx, ncell - 1), R, W, V, ox, oy, oz);
+            const int ccx = cx + ox, ccy = cy + oy, ccz = cz + oz;
+            bool in = idx < ncell && ccx >= 0 && ccx < g.gx && ccy >= 0 && ccy < g.gy && ccz >= 0 && ccz < g.gz;
+            if (in && have) {
+                const float gx = axis_gap(x, g.minx, g.h, ccx), gy = axis_gap(y, g.miny, g.h, ccy),
+                            gz = axis_gap(z, g.minz, g.h, ccz);
+                in = !(gx * gx + gy * gy + gz * gz > bestd);               // inside the ball
+            }
+            touched |= in;
+            const uint32_t c = in ? ((uint32_t)ccz * g.gy + ccy) * g.gx + ccx : 0u;
+            const uint2 w = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(cs_rsrc, c << 2, 0, 0));
+            s0[t] = w.x;
+            e0[t] = in ? w.y : w.x;
+        }
+        // first four records of every cell (reads past a cell hit real points of the next cells or the
+        // +inf padding: harmless extra candidates), then the rare long cells
+#pragma unroll
+        for (int t = 0; t < kRB; ++t) {
+            const uint32_t jj = s0[t], o = jj << 4;
+            const f32x3 p0 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o, 0, 0));
+            const f32x3 p1 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u, 0, 0));
+            const f32x3 p2 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 32u, 0, 0));
+            const f32x3 p3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 48u, 0, 0));
+            const unsigned long long k0 = ((unsigned long long)__float_as_uint(d2_nc(p0.x, p0.y, p0.z, x, y, z)) << 32) | jj;
+            const unsigned long long k1 = ((unsigned long long)__float_as_uint(d2_nc(p1.x, p1.y, p1.z, x, y, z)) << 32) | (jj + 1);
+            const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2_nc(p2.x, p2.y, p2.z, x, y, z)) << 32) | (jj + 2);
+            const unsigned long long k3 = ((unsigned long long)__float_as_uint(d2_nc(p3.x, p3.y, p3.z, x, y, z)) << 32) | (jj + 3);
+            const unsigned long long ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
+            const unsigned long long kc = ka < kb ? ka : kb;
+            if (s0[t] < e0[t]) lk = kc < lk ? kc : lk;
+        }
+#pragma unroll
+        for (int t = 0; t < kRB; ++t) {
+            for (uint32_t jj = s0[t] + 4; jj < e0[t]; ++jj) {
+                const f32x3 p = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, jj << 4, 0, 0));
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d2_nc(p.x, p.y, p.z, x, y, z)) << 32) | jj;
+                lk = key < lk ? key : lk;
+            }
+        }
+    }
+    return group_min_u64(lk);
 }
 
 template <bool P2PLANE>
@@ -492,12 +581,13 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
     const float t[3] = {st->t[0], st->t[1], st->t[2]};
     const float max_dist = st->max_dist;
-    const bool warm = st->iterations > 0;
     const uint32_t count = rlist[0];
+    const uint2 *__restrict__ entries = reinterpret_cast<const uint2 *>(rlist + 2);     // (source index, best known position)
     if ((uint32_t)blockIdx.x * (kRefineThreads / kRG) >= count) {      // no query for this block: folded rows only
         if (threadIdx.x < TC_ICP_SUMS_STRIDE) partial_rows[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = folded;
         return;
     }
+    const __amdgpu_buffer_rsrc_t pt_rsrc = raw_rsrc(tgt.pts), cs_rsrc = raw_rsrc(tgt.cell_start);
     const int lg = threadIdx.x & (kRG - 1);
     const uint32_t group = (blockIdx.x * kRefineThreads + threadIdx.x) / kRG, ngroups = gridDim.x * kRefineThreads / kRG;
     const unsigned long long gmask = (kRG == 64) ? ~0ull : (((1ull << kRG) - 1ull) << ((threadIdx.x & 63) & ~(kRG - 1)));
@@ -505,8 +595,10 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
     for (uint32_t i = group; i < count; i += ngroups) {
-        const uint32_t j = rlist[1 + i];
+        const uint2 ent = entries[i];
+        const uint32_t j = ent.x, pj = ent.y;
         const float4 s = src[j];
+        const float4 p = tgt.pts[pj != 0xFFFFFFFFu ? pj : 0u];
         float x, y, z;
         iso_apply(q, t, s.x, s.y, s.z, x, y, z);
         const float qx = fminf(fmaxf(x, g.minx), g.maxx), qy = fminf(fmaxf(y, g.miny), g.maxy),
@@ -517,61 +609,24 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
                     fz = (qz - g.minz) * g.inv_h - (float)cz;
         const float mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
         const float out2 = outside_d2(x, y, z, qx, qy, qz);
-        // warm start: the previous match is a real candidate
+        // start: the best real point the main pass knows (previous match or its ring-1 result); ring 1 is done
         unsigned long long bestkey = ~0ull;
-        if (warm) {
-            const uint32_t pj = corr_pos[j];
-            if (pj != 0xFFFFFFFFu) {
-                const float4 p = tgt.pts[pj];
-                bestkey = ((unsigned long long)__float_as_uint(d2_nc(p.x, p.y, p.z, x, y, z)) << 32) | pj;
-            }
-        }
-        for (int R = 1;; ++R) {
-            const int W = 2 * R + 1, V = W - 2;
-            const int nz = 2 * W * W, ny = 2 * W * V, nx = 2 * V * V;
-            const int ncell = (R == 1) ? 27 : nz + ny + nx;
-            const float bestd = __uint_as_float((uint32_t)(bestkey >> 32));     // +inf / NaN pattern when empty
-            const bool have = bestkey != ~0ull;
-            unsigned long long lk = ~0ull;
-            bool touched = false;
-            for (int idx = lg; idx < ncell; idx += kRG) {
-                int ox, oy, oz;
-                if (R == 1) {
-                    oz = idx / 9 - 1; oy = (idx - (idx / 9) * 9) / 3 - 1; ox = idx - (idx / 3) * 3 - 1;
-                } else if (idx < nz) {
-                    const int f = idx / (W * W), r = idx - f * W * W;
-                    oz = f ? R : -R; oy = r / W - R; ox = r - (r / W) * W - R;
-                } else if (idx < nz + ny) {
-                    const int i2 = idx - nz, f = i2 / (W * V), r = i2 - f * W * V;
-                    oy = f ? R : -R; oz = r / W - (R - 1); ox = r - (r / W) * W - R;
-                } else {
-                    const int i3 = idx - nz - ny, f = i3 / (V * V), r = i3 - f * V * V;
-                    ox = f ? R : -R; oz = r / V - (R - 1); oy = r - (r / V) * V - (R - 1);
-                }
-                const int ccx = cx + ox, ccy = cy + oy, ccz = cz + oz;
-                if (ccx < 0 || ccx >= g.gx || ccy < 0 || ccy >= g.gy || ccz < 0 || ccz >= g.gz) continue;
-                if (have) {
-                    const float gx = axis_gap(x, g.minx, g.h, ccx), gy = axis_gap(y, g.miny, g.h, ccy),
-                                gz = axis_gap(z, g.minz, g.h, ccz);
-                    if (gx * gx + gy * gy + gz * gz > bestd) continue;       // outside the ball
-                }
-                touched = true;
-                const uint32_t c = ((uint32_t)ccz * g.gy + ccy) * g.gx + ccx;
-                const uint32_t s0 = tgt.cell_start[c], e0 = tgt.cell_start[c + 1];
-                for (uint32_t jj = s0; jj < e0; ++jj) {
-                    const float4 p = tgt.pts[jj];
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(d2_nc(p.x, p.y, p.z, x, y, z)) << 32) | jj;
-                    lk = key < lk ? key : lk;
-                }
-            }
-            lk = group_min_u64(lk);
+        if (pj != 0xFFFFFFFFu) bestkey = ((unsigned long long)__float_as_uint(d2_nc(p.x, p.y, p.z, x, y, z)) << 32) | pj;
+        for (int R = 2;; ++R) {
+            bool touched;
+            const unsigned long long lk = (R == 2) ? refine_shell<2>(tgt, cs_rsrc, pt_rsrc, 2, lg, x, y, z, cx, cy, cz, bestkey, touched)
+                                                   : refine_shell<0>(tgt, cs_rsrc, pt_rsrc, R, lg, x, y, z, cx, cy, cz, bestkey, touched);
             bestkey = lk < bestkey ? lk : bestkey;
             const bool any_touched = (__ballot(touched) & gmask) != 0ull;
             const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
                                 (cz - R <= 0) && (cz + R >= g.gz - 1);
             const float bound = ((float)R + mf - 2e-3f) * g.h;
             const float bd = __uint_as_float((uint32_t)(bestkey >> 32));
-            if (covers || (R > 1 && !any_touched)) break;
+#ifdef TC_REFINE_STATS
+            if (lg == 0 && (covers || !any_touched || (bestkey != ~0ull && bd <= bound * bound + out2) || (max_dist >= 0.0f && bound > max_dist)))
+                atomicAdd(const_cast<uint32_t *>(&st->refine_ring_hist[min(R, 7)]), 1u);
+#endif
+            if (covers || !any_touched) break;
             if (bestkey != ~0ull && bd <= bound * bound + out2) break;
             if (max_dist >= 0.0f && bound > max_dist) break;   // everything unscanned would be rejected
         }
@@ -589,10 +644,22 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
             }
         }
     }
-    double dacc[NACC];
+    // block fold: DPP wave sums (only the group leaders hold data) -> LDS -> one row
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) dacc[i] = (double)acc[i];
-    block_reduce_store<NACC, kRefineThreads / 64>(dacc, partial_rows + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE, red, folded);
+    for (int i = 0; i < NACC; ++i) {
+        const float tot = wave_sum_f32(acc[i]);
+        if (lane == 0) red[w][i] = (double)tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
+        double sum = 0.0;
+        if (threadIdx.x < NACC) {
+#pragma unroll
+            for (int w2 = 0; w2 < kRefineThreads / 64; ++w2) sum += red[w2][threadIdx.x];
+        }
+        partial_rows[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = sum + folded;
+    }
 }
 
 // ICPResult.correspondences (registration.rs:22-23): matched ORIGINAL target index per ORIGINAL
@@ -841,7 +908,11 @@ __global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restr
             for (int gi = 0; gi < 8; ++gi) tot += sm[gi][threadIdx.x];
             st->sums[threadIdx.x] = tot;
         }
-        if (threadIdx.x == 0 && rlist) rlist[0] = 0;     // refine list consumed: ready for the next iteration
+        if (threadIdx.x == 0 && rlist) {                 // refine list consumed: ready for the next iteration
+            st->refine_total += rlist[0];
+            st->refine_max = max(st->refine_max, rlist[0]);
+            rlist[0] = 0;
+        }
         __syncthreads();
     }
     if (!do_apply || threadIdx.x != 0) return;
@@ -999,7 +1070,7 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &ctx->tgt_index.geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
     out.l = plan_launch(ns);
     if (tc_status s = ensure(ctx, ctx->partials, ((size_t)(kMaxPartialBlocks + kRefineBlocks) * TC_ICP_SUMS_STRIDE + 2) * sizeof(double))) return s;
-    if (tc_status s = ensure(ctx, ctx->corr, (3 * ns + 2) * sizeof(uint32_t))) return s;   // corr | corr_pos | refine list
+    if (tc_status s = ensure(ctx, ctx->corr, (4 * ns + 4) * sizeof(uint32_t))) return s;   // corr | corr_pos | refine count, pad | refine entries (uint2)
     TC_HIP_TRY(ctx, hipMemsetAsync((uint32_t *)ctx->corr.p + 2 * ns, 0, sizeof(uint32_t), ctx->stream));
     out.tv = view_of(ctx->tgt_index);
     return TC_OK;
@@ -1059,6 +1130,10 @@ tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, 
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
     for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
     TC_HIP_TRY(ctx, hipGetLastError());
+    if (getenv("TC_DEBUG") && (atoi(getenv("TC_DEBUG")) & 64))
+        fprintf(stderr, "[tc] icp: %u iterations, refine queries total %u max %u  exit ring hist %u %u %u %u %u %u %u %u\n", hs->iterations,
+                hs->refine_total, hs->refine_max, hs->refine_ring_hist[0], hs->refine_ring_hist[1], hs->refine_ring_hist[2], hs->refine_ring_hist[3],
+                hs->refine_ring_hist[4], hs->refine_ring_hist[5], hs->refine_ring_hist[6], hs->refine_ring_hist[7]);
     if (hs->status != TC_OK) {
         return fail(ctx, (tc_status)hs->status,
                     p2plane ? "Insufficient correspondences for point-to-plane ICP (need >= 6) or ill-conditioned system"

@@ -56,6 +56,9 @@ struct IcpState {
     uint32_t n_corr;        // valid pairs of the last executed iteration
     float    conv_thr;
     float    max_dist;      // < 0 : none
+    uint32_t refine_total;  // statistics: queries served by the refine pass (sum / max over iterations)
+    uint32_t refine_max;
+    uint32_t refine_ring_hist[8];   // TC_REFINE_STATS builds only: exit ring of the refine queries
     double   sums[TC_ICP_SUMS_STRIDE];   // packed, fully reduced sums of the current iteration
 };
 
