@@ -353,10 +353,13 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     if (st->done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
     __shared__ uint2 spans[kSpanRows][kIcpBlock];
-    __shared__ uint2 rl_list[kIcpGroup * kIcpBlock];      // refine entries of the group: (source index, best known position)
-    __shared__ uint32_t rl_cnt, rl_base;
-    if (threadIdx.x == 0) rl_cnt = 0;
-    __syncthreads();
+    // refine entries of the group, one region per wave: (source index, best known position).  Entries
+    // are appended in (trip, lane) order by ballot prefix and the block's segment of the global list is
+    // the concatenation of its waves' regions, so the list -- and with it every sum -- is deterministic.
+    __shared__ uint2 rl_list[kIcpBlock / 64][kIcpGroup * 64];
+    __shared__ uint32_t rl_wcnt[kIcpBlock / 64];
+    uint32_t seg_count = 0;                                // entries this block has written to its segment
+    uint2 *__restrict__ const seg = reinterpret_cast<uint2 *>(rlist + kMaxPartialBlocks) + (size_t)blockIdx.x * chunk;
     const GridGeom &g = tgt.g;
     const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
     const float t[3] = {st->t[0], st->t[1], st->t[2]};
@@ -370,7 +373,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     const uint32_t end = min(beg + chunk, ns);
     for (uint32_t gb = beg; gb < end; gb += kIcpGroup * kIcpBlock) {
         // ---- phase S ----
-        uint32_t ok = 0;
+        uint32_t ok = 0, wcnt = 0;                         // wcnt: this wave's entries of the group (wave-uniform)
 #pragma unroll 1
         for (int u = 0; u < kIcpGroup; ++u) {
             const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
@@ -390,32 +393,38 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
             bool refine;
             nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, max_dist, spans, dbg);
             if (dbg & 12) refine = false;
+            const unsigned long long rmask = __ballot(refine);
             if (refine) {
                 // hand the refine pass the best real point seen so far: previous match or ring-1 best
                 // (everything of ring 1 inside the ball has been examined: the refine pass starts at ring 2)
                 const unsigned long long kp = pj != 0xFFFFFFFFu ? (((unsigned long long)__float_as_uint(ub2p) << 32) | pj) : ~0ull;
                 const unsigned long long kb = bestg != 0xFFFFFFFFu ? (((unsigned long long)__float_as_uint(best) << 32) | bestg) : ~0ull;
                 const unsigned long long km = kb < kp ? kb : kp;
-                rl_list[atomicAdd(&rl_cnt, 1u)] = make_uint2(j, km != ~0ull ? (uint32_t)km : 0xFFFFFFFFu);   // block-local list, flushed below
-                continue;
+                rl_list[w][wcnt + __popcll(rmask & ((1ull << lane) - 1ull))] = make_uint2(j, km != ~0ull ? (uint32_t)km : 0xFFFFFFFFu);
             }
+            wcnt += __popcll(rmask);
+            if (refine) continue;
             bool valid = bestg != 0xFFFFFFFFu;
             if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
             corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
             if (valid && !(dbg & 8)) ok |= 1u << u;
         }
-        // flush the block's refine list with ONE global atomic (thousands of per-wave atomics on
-        // one word serialise at ~90 per microsecond)
+        // flush the group's entries to the block's segment of the global list (no atomics)
+        wcnt = __builtin_amdgcn_readfirstlane(wcnt);       // lanes past the chunk's end left the loop early
+        if (lane == 0) rl_wcnt[w] = wcnt;
         __syncthreads();
-        const uint32_t rl_n = rl_cnt;
-        if (rl_n) {
-            if (threadIdx.x == 0) rl_base = atomicAdd(&rlist[0], rl_n);
-            __syncthreads();
-            uint2 *__restrict__ entries = reinterpret_cast<uint2 *>(rlist + 2);
-            for (uint32_t i = threadIdx.x; i < rl_n; i += kIcpBlock) entries[rl_base + i] = rl_list[i];
-            __syncthreads();
-            if (threadIdx.x == 0) rl_cnt = 0;
+        {
+            uint32_t woff = 0, tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < kIcpBlock / 64; ++w2) {
+                const uint32_t c = rl_wcnt[w2];
+                if (w2 < w) woff += c;
+                tot += c;
+            }
+            for (uint32_t i = lane; i < wcnt; i += 64) seg[seg_count + woff + i] = rl_list[w][i];
+            seg_count += tot;
         }
+        __syncthreads();
         // ---- phase A ----
         float acc[NACC];
 #pragma unroll
@@ -460,6 +469,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
         }
         partials[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = sum;
     }
+    if (threadIdx.x == 0) rlist[blockIdx.x] = seg_count;
 }
 
 // Refine pass: the listed queries (a few thousand per iteration: Poisson tail, queries outside the
@@ -563,10 +573,14 @@ __device__ __forceinline__ unsigned long long refine_shell(const GridView &tgt, 
 }
 
 template <bool P2PLANE>
+__device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
+                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE]);
+
+template <bool P2PLANE>
 __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src,
-    const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, const uint32_t *__restrict__ rlist,
-    const double *__restrict__ main_rows, uint32_t n_main_rows, double *__restrict__ partial_rows) {
+    IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
+    const double *__restrict__ main_rows, uint32_t n_main_rows, uint32_t seg_stride, double *__restrict__ partial_rows) {
     constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
     if (st->done) return;
     __shared__ double red[kRefineThreads / 64][TC_ICP_SUMS_STRIDE];
@@ -581,21 +595,68 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
     const float t[3] = {st->t[0], st->t[1], st->t[2]};
     const float max_dist = st->max_dist;
-    const uint32_t count = rlist[0];
-    const uint2 *__restrict__ entries = reinterpret_cast<const uint2 *>(rlist + 2);     // (source index, best known position)
-    if ((uint32_t)blockIdx.x * (kRefineThreads / kRG) >= count) {      // no query for this block: folded rows only
+    // refine list = the main blocks' segments; exclusive scan of their counts (every block computes
+    // the same scan), then query i -> (segment, local index) by binary search: balanced and
+    // deterministic without a global counter
+    __shared__ uint32_t seg_off[kMaxPartialBlocks + 1];
+    __shared__ uint32_t wave_tot[kRefineThreads / 64];
+    {
+        // thread t owns the `per` consecutive counts starting at t * per (per = 1 up to 1024 main blocks)
+        const uint32_t per = (n_main_rows + kRefineThreads - 1) / kRefineThreads;
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < per; ++k) {
+            const uint32_t b = threadIdx.x * per + k;
+            run += b < n_main_rows ? rlist[b] : 0u;
+        }
+        uint32_t inc = run;                                 // inclusive scan over the block: wave scan + wave totals
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o);
+            if ((int)(threadIdx.x & 63) >= o) inc += v;
+        }
+        if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t ex = inc - run;
+        for (int w2 = 0; w2 < (int)(threadIdx.x >> 6); ++w2) ex += wave_tot[w2];
+        for (uint32_t k = 0; k < per; ++k) {
+            const uint32_t b = threadIdx.x * per + k;
+            if (b <= n_main_rows) seg_off[b] = ex;
+            ex += b < n_main_rows ? rlist[b] : 0u;
+        }
+        if (threadIdx.x == kRefineThreads - 1) seg_off[n_main_rows] = ex;    // total
+        __syncthreads();
+    }
+    const uint32_t count = seg_off[n_main_rows];
+    const uint2 *__restrict__ entries = reinterpret_cast<const uint2 *>(rlist + kMaxPartialBlocks);     // (source index, best known position)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {             // statistics
+        st->refine_total += count;
+        st->refine_max = max(st->refine_max, count);
+    }
+    if ((uint32_t)blockIdx.x >= count) {                  // no query for this block: folded rows only
         if (threadIdx.x < TC_ICP_SUMS_STRIDE) partial_rows[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = folded;
         return;
     }
     const __amdgpu_buffer_rsrc_t pt_rsrc = raw_rsrc(tgt.pts), cs_rsrc = raw_rsrc(tgt.cell_start);
     const int lg = threadIdx.x & (kRG - 1);
-    const uint32_t group = (blockIdx.x * kRefineThreads + threadIdx.x) / kRG, ngroups = gridDim.x * kRefineThreads / kRG;
+    // neighbouring list entries come from one main block = one region of space: deal them out to
+    // different refine blocks (group ids are block-minor), or the hard regions land in a few blocks
+    const uint32_t group = (threadIdx.x / kRG) * gridDim.x + blockIdx.x, ngroups = gridDim.x * kRefineThreads / kRG;
     const unsigned long long gmask = (kRG == 64) ? ~0ull : (((1ull << kRG) - 1ull) << ((threadIdx.x & 63) & ~(kRG - 1)));
     float acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
     for (uint32_t i = group; i < count; i += ngroups) {
-        const uint2 ent = entries[i];
+        // segment of query i: last b with seg_off[b] <= i; kRG-ary search, one pivot per lane of the group
+        uint32_t lo = 0, nleft = n_main_rows;
+        while (nleft > 1) {
+            const uint32_t stride = (nleft + kRG - 1) / kRG;
+            const bool le = (uint32_t)lg * stride < nleft && seg_off[lo + lg * stride] <= i;     // true for a prefix of the lanes
+            const uint32_t m = (uint32_t)((__ballot(le) & gmask) >> ((threadIdx.x & 63) & ~(kRG - 1)));
+            const uint32_t k = 31u - (uint32_t)__clz((int)m);                                    // lane 0 always holds (invariant)
+            lo += k * stride;
+            nleft = min(stride, nleft - k * stride);
+        }
+        const uint2 ent = entries[(size_t)lo * seg_stride + (i - seg_off[lo])];
         const uint32_t j = ent.x, pj = ent.y;
         const float4 s = src[j];
         const float4 p = tgt.pts[pj != 0xFFFFFFFFu ? pj : 0u];
@@ -882,36 +943,33 @@ __device__ void finish_iteration(IcpState *st, float mse, uint32_t n) {
     st->prev_mse = mse;
 }
 
+// the first 256 threads of the calling block: fixed-order sum of the rows, solve, compose, bookkeeping
 template <bool P2PLANE>
-__global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
-                                                           IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply, uint32_t *__restrict__ rlist) {
-    if (st->done) return;
-    __shared__ double sm[8][TC_ICP_SUMS_STRIDE];
+__device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
+                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE]) {
     if (do_sum) {
-        // 8 row groups x 32 columns; every group folds its rows in a fixed order with 4 independent
-        // loads in flight, then column t folds the 8 groups in order.
-        const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        uint32_t b = grp;
-        for (; b + 24 < nblocks; b += 32) {
-            s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
-            s1 += partials[(size_t)(b + 8) * TC_ICP_SUMS_STRIDE + col];
-            s2 += partials[(size_t)(b + 16) * TC_ICP_SUMS_STRIDE + col];
-            s3 += partials[(size_t)(b + 24) * TC_ICP_SUMS_STRIDE + col];
+        // 8 row groups x 32 columns (threads 0..255; a larger block's other threads only take part in
+        // the barriers); every group folds its rows in a fixed order with 4 independent loads in
+        // flight, then column t folds the 8 groups in order.
+        if (threadIdx.x < 256) {
+            const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            uint32_t b = grp;
+            for (; b + 24 < nblocks; b += 32) {
+                s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
+                s1 += partials[(size_t)(b + 8) * TC_ICP_SUMS_STRIDE + col];
+                s2 += partials[(size_t)(b + 16) * TC_ICP_SUMS_STRIDE + col];
+                s3 += partials[(size_t)(b + 24) * TC_ICP_SUMS_STRIDE + col];
+            }
+            for (; b < nblocks; b += 8) s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
+            sm[grp][col] = (s0 + s1) + (s2 + s3);
         }
-        for (; b < nblocks; b += 8) s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
-        sm[grp][col] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
             double tot = 0.0;
 #pragma unroll
             for (int gi = 0; gi < 8; ++gi) tot += sm[gi][threadIdx.x];
             st->sums[threadIdx.x] = tot;
-        }
-        if (threadIdx.x == 0 && rlist) {                 // refine list consumed: ready for the next iteration
-            st->refine_total += rlist[0];
-            st->refine_max = max(st->refine_max, rlist[0]);
-            rlist[0] = 0;
         }
         __syncthreads();
     }
@@ -958,6 +1016,14 @@ __global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restr
         compose(st, dq, dt);
         finish_iteration(st, (float)(S[15] / cnt), (uint32_t)cnt);
     }
+}
+
+template <bool P2PLANE>
+__global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
+                                                           IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply) {
+    if (st->done) return;
+    __shared__ double sm[8][TC_ICP_SUMS_STRIDE];
+    finalize_body<P2PLANE>(partials, nblocks, st, g, do_sum, do_apply, sm);
 }
 
 // after the last iteration: not-converged epilogue (registration.rs:343-369 / :595-601)
@@ -1024,20 +1090,20 @@ static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, 
         ProfScope ps(ctx, "icp_refine");
         if (p2plane)
             hipLaunchKernelGGL(icp_refine_kernel<true>, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist,
-                               partials, l.nblocks, refine_rows);
+                               partials, l.nblocks, l.chunk, refine_rows);
         else
             hipLaunchKernelGGL(icp_refine_kernel<false>, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist,
-                               partials, l.nblocks, refine_rows);
+                               partials, l.nblocks, l.chunk, refine_rows);
     }
     if (do_sum || do_apply) {
         ProfScope ps(ctx, "icp_finalize");
         const uint32_t rows = kRefineBlocks;      // the refine pass folded the main pass's rows into its own
         if (p2plane)
             hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(256), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
-                               (do_apply && !(dbg & 32)) ? 1 : 0, do_sum ? rlist : nullptr);
+                               (do_apply && !(dbg & 32)) ? 1 : 0);
         else
             hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(256), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
-                               (do_apply && !(dbg & 32)) ? 1 : 0, do_sum ? rlist : nullptr);
+                               (do_apply && !(dbg & 32)) ? 1 : 0);
     }
 }
 
@@ -1070,8 +1136,8 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &ctx->tgt_index.geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
     out.l = plan_launch(ns);
     if (tc_status s = ensure(ctx, ctx->partials, ((size_t)(kMaxPartialBlocks + kRefineBlocks) * TC_ICP_SUMS_STRIDE + 2) * sizeof(double))) return s;
-    if (tc_status s = ensure(ctx, ctx->corr, (4 * ns + 4) * sizeof(uint32_t))) return s;   // corr | corr_pos | refine count, pad | refine entries (uint2)
-    TC_HIP_TRY(ctx, hipMemsetAsync((uint32_t *)ctx->corr.p + 2 * ns, 0, sizeof(uint32_t), ctx->stream));
+    // corr | corr_pos | refine counts (one per main block) | refine entries (uint2, one segment of `chunk` per main block)
+    if (tc_status s = ensure(ctx, ctx->corr, (2 * ns + kMaxPartialBlocks + 2 * (size_t)out.l.nblocks * out.l.chunk) * sizeof(uint32_t))) return s;
     out.tv = view_of(ctx->tgt_index);
     return TC_OK;
 }
