@@ -143,6 +143,27 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// the same tree for seven values at once: one fused v_add_f32_dpp per value and step (the compiler
+// cannot fold the DPP move into the add without no-signed-zeros).  Seven independent instructions
+// between the write and the DPP read of a register cover the DPP read-after-write hazard; the s_nop
+// covers the first one against whatever the compiler scheduled before the block.
+#define TC_DPP7(ctrl)                                                                                              \
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl  \
+                 "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\tv_add_f32_dpp %4, %4, %4 " ctrl "\n\tv_add_f32_dpp %5, %5, %5 " ctrl \
+                 "\n\tv_add_f32_dpp %6, %6, %6 " ctrl                                                              \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]))
+__device__ __forceinline__ void wave_sum_f32x7(float (&v)[7]) {
+    TC_DPP7("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    TC_DPP7("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    TC_DPP7("row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    TC_DPP7("row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    TC_DPP7("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    TC_DPP7("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#pragma unroll
+    for (int i = 0; i < 7; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
+}
+#undef TC_DPP7
+
 template <int NACC, int NW = kIcpBlock / 64>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *__restrict__ out_row, double (*sm)[TC_ICP_SUMS_STRIDE],
                                                    double extra = 0.0) {
@@ -232,31 +253,32 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     // and becomes the empty span.  (cell_start is padded by kCellStartPad entries.)
     const __amdgpu_buffer_rsrc_t cs_rsrc = raw_rsrc(gv.cell_start);
     const int wb = max(cx - 1, 0);
+    // per-axis facts shared by the nine rows; row starts by adding uniform strides to the centre row
+    // (no per-row integer multiplies: v_mul_lo_u32 is quarter rate)
+    const bool oky[3] = {cy > 0, true, cy < g.gy - 1}, okz[3] = {cz > 0, true, cz < g.gz - 1};
+    const bool has_l = cx > 0, has_r = cx < g.gx - 1;
+    const int stride_y = g.gx, stride_z = g.gx * g.gy;
+    const int row_c = (cz * g.gy + cy) * g.gx + wb;        // window start of the centre row
+    const bool own1 = cx > 0;                              // window offset of the own cell's start: 1 (0 for cx == 0)
     uint32_t s0[kSpanRows], e0[kSpanRows];
-#pragma unroll
-    for (int k = 0; k < kSpanRows; ++k) {
-        const int dz = k / 3 - 1, dy = k % 3 - 1;
-        const int yy = cy + dy, zz = cz + dz;
-        const float r2 = ay2[dy + 1] + az2[dz + 1];
-        const bool on = (yy >= 0) && (yy < g.gy) && (zz >= 0) && (zz < g.gz) && !(r2 > ub);
-        // x window: the left / right cell only if the ball reaches it
-        const bool left = cx > 0 && !(r2 + ax2[0] > ub), right = cx < g.gx - 1 && !(r2 + ax2[2] > ub);
-        const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
-        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(cs_rsrc, (on ? row + (uint32_t)wb : 0u) << 2, 0, 0);
-        // entry offsets: start of cell xa = cx - left, end of cell xb = cx + right
-        const int oa = cx - wb - (left ? 1 : 0);            // 0 or 1
-        const int ob = cx - wb + 1 + (right ? 1 : 0);       // 1, 2 or 3
-        const uint32_t sa = oa == 0 ? w.x : w.y;
-        const uint32_t eb = ob == 1 ? w.y : (ob == 2 ? w.z : w.w);
-        s0[k] = on ? sa : 0u;
-        e0[k] = on ? eb : 0u;
-    }
     uint32_t mask = 0;
 #pragma unroll
     for (int k = 0; k < kSpanRows; ++k) {
-        spans[k][threadIdx.x] = make_uint2(s0[k], e0[k]);
-        if (s0[k] != e0[k]) mask |= 1u << k;            // non-empty spans only
+        const int dz = k / 3 - 1, dy = k % 3 - 1;
+        const float r2 = ay2[dy + 1] + az2[dz + 1];
+        const bool on = oky[dy + 1] && okz[dz + 1] && !(r2 > ub);
+        // x window: the left / right cell only if the ball reaches it
+        const bool left = has_l && !(r2 + ax2[0] > ub), right = has_r && !(r2 + ax2[2] > ub);
+        const int row = row_c + dz * stride_z + dy * stride_y;
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(cs_rsrc, on ? (uint32_t)row << 2 : 0u, 0, 0);
+        // window = starts of the cells wb .. wb+3; span = [start of cell cx - left, start of cell cx + right + 1)
+        const uint32_t lo = own1 ? w.z : w.y, hi = own1 ? w.w : w.z;
+        s0[k] = (left || !own1) ? w.x : w.y;
+        e0[k] = right ? hi : lo;
+        if (on && s0[k] != e0[k]) mask |= 1u << k;         // rows the ball reaches, non-empty spans only
     }
+#pragma unroll
+    for (int k = 0; k < kSpanRows; ++k) spans[k][threadIdx.x] = make_uint2(s0[k], e0[k]);
     if (dbg & 4) mask = 0;
     // Flattened walk over the surviving spans, four records per step (four independent gathers in
     // flight per lane); a lane switches to its next span as soon as the current one is exhausted.
@@ -455,7 +477,18 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
         }
         // per-group fold: DPP wave sum (f32, fixed tree) -> this wave's f64 row
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) {
+        for (int i0 = 0; i0 + 7 <= NACC; i0 += 7) {
+            float v7[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) v7[i] = acc[i0 + i];
+            wave_sum_f32x7(v7);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) red[w][i0 + i] += (double)v7[i];
+            }
+        }
+#pragma unroll
+        for (int i = NACC / 7 * 7; i < NACC; ++i) {
             const float tot = wave_sum_f32(acc[i]);
             if (lane == 0) red[w][i] += (double)tot;
         }
