@@ -217,6 +217,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// squared distance of record c = (x, y, z, index bits) to the query, same operations and order as
+// d2_nc (dx*dx + dy*dy + dz*dz, no FMA), arranged as packed-f32 pairs
+__device__ __forceinline__ float d2_packed(const f32x4 &c, const f32x2 &qxy, const f32x2 &qz0) {
+    const f32x2 dxy = c.xy - qxy, dzw = c.zw - qz0;
+    const f32x2 sxy = dxy * dxy, szw = dzw * dzw;
+    return (sxy.x + sxy.y) + szw.x;
+}
+
 // raw buffer descriptor over a whole allocation (no range check: 4 GiB window): buffer loads take a
 // 32-bit byte offset per lane (no 64-bit address arithmetic) and accept dword-aligned 16-byte reads
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *p) {
@@ -226,7 +237,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *p) {
 // exact 1-NN of (x, y, z); ub2 = a valid upper bound of the squared NN distance (or +inf)
 __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, float y, float z, float ub2,
                                                  float &best, uint32_t &bestj, bool &refine, float max_dist,
-                                                 uint2 (*spans)[kIcpBlock], int dbg = 0) {
+                                                 uint2 (*spans)[kIcpBlock]) {
     const GridGeom &g = gv.g;
     int cx, cy, cz;
     float mf, out2;
@@ -279,13 +290,13 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     }
 #pragma unroll
     for (int k = 0; k < kSpanRows; ++k) spans[k][threadIdx.x] = make_uint2(s0[k], e0[k]);
-    if (dbg & 4) mask = 0;
     // Flattened walk over the surviving spans, four records per step (four independent gathers in
     // flight per lane); a lane switches to its next span as soon as the current one is exhausted.
     // A step may read up to three records past its span: real target points of the next cells (or
     // the +inf padding behind the array), harmless as extra candidates.  Rows are visited in ascending
     // order = ascending position, so the strict '<' keeps the lowest position among equal distances.
     const __amdgpu_buffer_rsrc_t pt_rsrc = raw_rsrc(gv.pts);
+    const f32x2 qxy = {x, y}, qz0 = {z, 0.0f};
     best = INFINITY;
     bestj = 0xFFFFFFFFu;
     uint32_t j = 0, e = 0;
@@ -298,12 +309,14 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
             j = se.x; e = se.y;
         }
         const uint32_t o = j << 4;                      // byte offset (positions < 2^28, checked by icp_setup)
-        const f32x3 c0 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o, 0, 0));
-        const f32x3 c1 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u, 0, 0));
-        const f32x3 c2 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 32u, 0, 0));
-        const f32x3 c3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 48u, 0, 0));
-        const float v0 = d2_nc(c0.x, c0.y, c0.z, x, y, z), v1 = d2_nc(c1.x, c1.y, c1.z, x, y, z);
-        const float v2 = d2_nc(c2.x, c2.y, c2.z, x, y, z), v3 = d2_nc(c3.x, c3.y, c3.z, x, y, z);
+        // whole 16-byte records: (x, y) and (z, index) sit in aligned register pairs, so the differences
+        // and squares are packed-f32 instructions without shuffles (the index lane is computed and ignored)
+        const f32x4 c0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o, 0, 0));
+        const f32x4 c1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 16u, 0, 0));
+        const f32x4 c2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 32u, 0, 0));
+        const f32x4 c3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 48u, 0, 0));
+        const float v0 = d2_packed(c0, qxy, qz0), v1 = d2_packed(c1, qxy, qz0);
+        const float v2 = d2_packed(c2, qxy, qz0), v3 = d2_packed(c3, qxy, qz0);
         const bool b01 = v1 < v0, b23 = v3 < v2;
         const float m01 = b01 ? v1 : v0, m23 = b23 ? v3 : v2;
         const uint32_t i01 = b01 ? j + 1 : j, i23 = b23 ? j + 3 : j + 2;
@@ -366,7 +379,7 @@ __device__ __forceinline__ void accumulate_pair(const GridGeom &g, float (&acc)[
 //      wave-reduced into the block's f64 LDS row, so that nothing but that row survives the group.
 constexpr int kIcpGroup = 4;
 
-template <bool P2PLANE, int AW>
+template <bool P2PLANE>
 __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
@@ -413,8 +426,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
             float best;
             uint32_t bestg;
             bool refine;
-            nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, max_dist, spans, dbg);
-            if (dbg & 12) refine = false;
+            nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, max_dist, spans);
             const unsigned long long rmask = __ballot(refine);
             if (refine) {
                 // hand the refine pass the best real point seen so far: previous match or ring-1 best
@@ -429,7 +441,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
             bool valid = bestg != 0xFFFFFFFFu;
             if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
             corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
-            if (valid && !(dbg & 8)) ok |= 1u << u;
+            if (valid) ok |= 1u << u;
         }
         // flush the group's entries to the block's segment of the global list (no atomics)
         wcnt = __builtin_amdgcn_readfirstlane(wcnt);       // lanes past the chunk's end left the loop early
@@ -451,29 +463,18 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
         float acc[NACC];
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
-#pragma unroll(AW == 1 ? 1 : kIcpGroup)
-        for (int u0 = 0; u0 < kIcpGroup; u0 += AW) {
-            float4 sv[AW], cv[AW], nv[AW];
-#pragma unroll
-            for (int v = 0; v < AW; ++v) {
-                const uint32_t j = gb + (u0 + v) * kIcpBlock + threadIdx.x;
-                const bool on = (ok >> (u0 + v)) & 1u;
-                sv[v] = cv[v] = nv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (on) {
-                    sv[v] = src[j];
-                    const uint32_t pj = corr_pos[j];                 // this lane's own store of phase S
-                    cv[v] = tgt.pts[pj];
-                    if (P2PLANE) nv[v] = tgt_nrm[pj];
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < AW; ++v) {
-                if ((ok >> (u0 + v)) & 1u) {
-                    float x, y, z;
-                    iso_apply(q, t, sv[v].x, sv[v].y, sv[v].z, x, y, z);
-                    accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, cv[v], nv[v]);
-                }
-            }
+#pragma unroll 1
+        for (int u = 0; u < kIcpGroup; ++u) {
+            if (!((ok >> u) & 1u)) continue;
+            const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
+            const float4 sv = src[j];
+            const uint32_t pj = corr_pos[j];                 // this lane's own store of phase S
+            const float4 cv = tgt.pts[pj];
+            float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P2PLANE) nv = tgt_nrm[pj];
+            float x, y, z;
+            iso_apply(q, t, sv.x, sv.y, sv.z, x, y, z);
+            accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, cv, nv);
         }
         // per-group fold: DPP wave sum (f32, fixed tree) -> this wave's f64 row
 #pragma unroll
@@ -1080,8 +1081,10 @@ struct IcpLaunch {
 };
 static IcpLaunch plan_launch(size_t ns) {
     IcpLaunch l;
-    static const int maxb = getenv("TC_MAXB") ? atoi(getenv("TC_MAXB")) : 1024;
-    uint32_t nb = (uint32_t)std::min<size_t>((ns + kIcpBlock - 1) / kIcpBlock, (size_t)std::min(maxb, kMaxPartialBlocks));
+    // one point per lane for small clouds, up to kMaxPartialBlocks blocks; at 1 M points that is 1024
+    // points per block (4 per lane).  More, smaller blocks measured slower (per-block sums: 2048 blocks
+    // +7 %, 4096 +15 %); larger clouds get longer chunks (10 M points: no difference between 1024 and 4096 blocks).
+    uint32_t nb = (uint32_t)std::min<size_t>((ns + kIcpBlock - 1) / kIcpBlock, (size_t)kMaxPartialBlocks);
     nb = std::max<uint32_t>((nb + 7) / 8 * 8, 8);
     uint32_t chunk = (uint32_t)((ns + nb - 1) / nb);
     chunk = (chunk + kIcpBlock - 1) / kIcpBlock * kIcpBlock;
@@ -1114,11 +1117,12 @@ static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, 
     if (do_reduce) {
         {
             ProfScope ps(ctx, p2plane ? "icp_correspond_reduce_p2plane" : "icp_correspond_reduce_p2p", true);
-            static const int aw = getenv("TC_AW") ? atoi(getenv("TC_AW")) : 2;
-            auto kern = p2plane ? (aw == 1 ? icp_correspond_reduce_kernel<true, 1> : aw == 4 ? icp_correspond_reduce_kernel<true, 4> : icp_correspond_reduce_kernel<true, 2>)
-                                : (aw == 1 ? icp_correspond_reduce_kernel<false, 1> : aw == 4 ? icp_correspond_reduce_kernel<false, 4> : icp_correspond_reduce_kernel<false, 2>);
-            hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st, corr_pos, rlist,
-                               partials, dbg);
+            if (p2plane)
+                hipLaunchKernelGGL(icp_correspond_reduce_kernel<true>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st,
+                                   corr_pos, rlist, partials, dbg);
+            else
+                hipLaunchKernelGGL(icp_correspond_reduce_kernel<false>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st,
+                                   corr_pos, rlist, partials, dbg);
         }
         ProfScope ps(ctx, "icp_refine");
         if (p2plane)
@@ -1151,6 +1155,8 @@ struct IcpSetup {
 static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                            const float *d_nrm, size_t nstride, const float init[7], float max_dist, float conv_thr,
                            IcpSetup &out) {
+    // the search addresses target records by 32-bit byte offsets (16 B each)
+    if (nt >= (1ull << 28)) return fail(ctx, TC_UNSUPPORTED, "ICP target clouds are limited to 2^28 - 1 points");
     if (tc_status s = build_index(ctx, ctx->tgt_index, d_tgt, nt, icp_cell_factor(), nullptr, nullptr)) return s;
     if (p2plane)
         if (tc_status s = gather_normals(ctx, ctx->tgt_index, d_nrm, nstride)) return s;
