@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     const double *__restrict__ main_rows, uint32_t n_main_rows, uint32_t seg_stride, double *__restrict__ partial_rows) {
     constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
     if (st->done) return;
-    __shared__ double red[kRefineThreads / 64][TC_ICP_SUMS_STRIDE];
+    __shared__ float lacc[kRefineThreads / kRG][TC_ICP_SUMS_STRIDE];
     // every refine block also folds its share of the main pass's per-block rows (written by the
     // previous launch) into its own row, in a fixed order: icp_finalize then reads kRefineBlocks rows
     const uint32_t rows_per = (n_main_rows + gridDim.x - 1) / gridDim.x;
@@ -676,9 +676,11 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     // different refine blocks (group ids are block-minor), or the hard regions land in a few blocks
     const uint32_t group = (threadIdx.x / kRG) * gridDim.x + blockIdx.x, ngroups = gridDim.x * kRefineThreads / kRG;
     const unsigned long long gmask = (kRG == 64) ? ~0ull : (((1ull << kRG) - 1ull) << ((threadIdx.x & 63) & ~(kRG - 1)));
-    float acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+    // per-group f32 sums live in LDS (the group leader is the only writer): no accumulator registers
+    // across the search, and the block fold below reads 32 x NACC words instead of reducing 16 waves
+    float *const acc = lacc[threadIdx.x / kRG];
+    if (lg < NACC) acc[lg] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     for (uint32_t i = group; i < count; i += ngroups) {
         // segment of query i: last b with seg_off[b] <= i; kRG-ary search, one pivot per lane of the group
         uint32_t lo = 0, nleft = n_main_rows;
@@ -735,23 +737,22 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
                 const float4 c = tgt.pts[bestg];
                 float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (P2PLANE) n = tgt_nrm[bestg];
-                accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, c, n);
+                float a[NACC];
+#pragma unroll
+                for (int k = 0; k < NACC; ++k) a[k] = acc[k];
+                accumulate_pair<P2PLANE, NACC>(g, a, x, y, z, c, n);
+#pragma unroll
+                for (int k = 0; k < NACC; ++k) acc[k] = a[k];
             }
         }
     }
-    // block fold: DPP wave sums (only the group leaders hold data) -> LDS -> one row
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        const float tot = wave_sum_f32(acc[i]);
-        if (lane == 0) red[w][i] = (double)tot;
-    }
+    // block fold: the groups' rows in group order (f64), plus the folded main rows
     __syncthreads();
     if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
         double sum = 0.0;
         if (threadIdx.x < NACC) {
-#pragma unroll
-            for (int w2 = 0; w2 < kRefineThreads / 64; ++w2) sum += red[w2][threadIdx.x];
+#pragma unroll 8
+            for (int g2 = 0; g2 < kRefineThreads / kRG; ++g2) sum += (double)lacc[g2][threadIdx.x];
         }
         partial_rows[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = sum + folded;
     }
