@@ -378,6 +378,7 @@ __device__ __forceinline__ void accumulate_pair(const GridGeom &g, float (&acc)[
 //      (independent loads, one round trip) and folded into the f32 per-lane sums, which are then
 //      wave-reduced into the block's f64 LDS row, so that nothing but that row survives the group.
 constexpr int kIcpGroup = 4;
+constexpr int kRefineBlocks = 256;          // blocks of the refine pass = rows handed to the finalize step
 
 template <bool P2PLANE>
 __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
@@ -514,7 +515,6 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
 // cells at a time with all their cell_start reads, then all their record reads, in flight together,
 // and the shell enumeration of ring 2 is compile-time.  Per-block sums go to the partial rows after
 // the main pass's rows.
-constexpr int kRefineBlocks = 256;
 constexpr int kRefineThreads = 1024;
 constexpr int kRG = 32;                     // lanes per query
 constexpr int kRB = 4;                      // shell cells per lane and batch
@@ -796,51 +796,57 @@ __global__ void __launch_bounds__(kIcpBlock) icp_final_mse_kernel(GridView tgt, 
 }
 
 // ---- small f64 solvers (one lane) -----------------------------------------------------------
-__device__ __forceinline__ bool chol6_solve(const double A[6][6], const double b[6], double x[6]) {
-    // fully unrolled (static indices only) so that L lives in registers, not scratch
-    double L[6][6];
+// 6x6 Cholesky solve, fully unrolled on the packed lower triangle (21 + 6 doubles in registers, static
+// indices only, no scratch); rolled loops over LDS arrays measured 8 us slower (every operand an LDS
+// round trip on one dependent chain).
+// Su = upper triangle by rows (= lower triangle by columns) of the symmetric matrix.
+__device__ __forceinline__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }   // r >= c
+__device__ __forceinline__ bool chol6_solve(const double *Su, const double *b, double (&x)[6]) {
+    double L[21];
+    {
+        int o = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) L[i][j] = A[i][j];
+            for (int c = r; c < 6; ++c) { L[tri(c, r)] = Su[o]; ++o; }
+    }
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
 #pragma unroll
         for (int k = 0; k < j; ++k) {
-            const double f = L[j][k];
+            const double f = L[tri(j, k)];
 #pragma unroll
-            for (int r = j; r < 6; ++r) L[r][j] -= f * L[r][k];
+            for (int r = j; r < 6; ++r) L[tri(r, j)] -= f * L[tri(r, k)];
         }
-        const double d = L[j][j];
+        const double d = L[tri(j, j)];
         ok = ok && (d > 0.0);             // Cholesky::new -> None on a non-positive pivot
         const double sd = sqrt(d > 0.0 ? d : 1.0);
         const double inv = 1.0 / sd;
-        L[j][j] = sd;
+        L[tri(j, j)] = sd;
 #pragma unroll
-        for (int r = j + 1; r < 6; ++r) L[r][j] *= inv;
+        for (int r = j + 1; r < 6; ++r) L[tri(r, j)] *= inv;
     }
     if (!ok) return false;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
 #pragma unroll
-        for (int k = 0; k < i; ++k) s -= L[i][k] * x[k];
-        x[i] = s / L[i][i];
+        for (int k = 0; k < i; ++k) s -= L[tri(i, k)] * x[k];
+        x[i] = s / L[tri(i, i)];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = x[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
-        x[i] = s / L[i][i];
+        for (int k = i + 1; k < 6; ++k) s -= L[tri(k, i)] * x[k];
+        x[i] = s / L[tri(i, i)];
     }
     return true;
 }
 
-__device__ __noinline__ bool lu6_solve(const double Ain[6][6], const double b[6], double x[6]) {
-    double A[6][6];
-    for (int i = 0; i < 6; ++i) { x[i] = b[i]; for (int j = 0; j < 6; ++j) A[i][j] = Ain[i][j]; }
+// works in place on LDS (dynamic row indexing in registers would put the whole kernel on scratch)
+__device__ __noinline__ bool lu6_solve(double (*A)[6], double *x) {
     for (int i = 0; i < 6; ++i) {
         int piv = i; double best = fabs(A[i][i]);
         for (int r = i + 1; r < 6; ++r) { const double v = fabs(A[r][i]); if (v > best) { best = v; piv = r; } }
@@ -990,6 +996,19 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
             const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             uint32_t b = grp;
+            if (nblocks == 256) {
+                // the usual case (kRefineBlocks rows): 16 loads of the thread in flight at once (2 rounds),
+                // same summation order as the generic loop below
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    double v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = partials[(size_t)(grp + 8 * (16 * h + k)) * TC_ICP_SUMS_STRIDE + col];
+#pragma unroll
+                    for (int k = 0; k < 16; k += 4) { s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; s3 += v[k + 3]; }
+                }
+                b = 256 + grp;
+            }
             for (; b + 24 < nblocks; b += 32) {
                 s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
                 s1 += partials[(size_t)(b + 8) * TC_ICP_SUMS_STRIDE + col];
@@ -1013,16 +1032,20 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
     if (P2PLANE) {
         const double cnt = S[28];
         if (cnt < 6.0) { st->status = TC_ALGORITHM; st->done = 1; return; }     // registration.rs:568-572
-        double A[6][6], b[6], x[6];
-        int o = 0;
+        double x[6];
+        if (!chol6_solve(S, S + 21, x)) {
+            // LU fallback on LDS arrays (dynamic row indexing; rare)
+            __shared__ double sA[6][6], sx[6];
+            int o = 0;
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+            for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = r; c < 6; ++c) { A[r][c] = S[o]; A[c][r] = S[o]; ++o; }
+                for (int c = r; c < 6; ++c) { sA[r][c] = S[o]; sA[c][r] = S[o]; ++o; }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) b[r] = S[21 + r];
-        if (!chol6_solve(A, b, x)) {
-            if (!lu6_solve(A, b, x)) { st->status = TC_ALGORITHM; st->done = 1; return; }   // :432-438
+            for (int r = 0; r < 6; ++r) sx[r] = S[21 + r];
+            if (!lu6_solve(sA, sx)) { st->status = TC_ALGORITHM; st->done = 1; return; }   // :432-438
+#pragma unroll
+            for (int r = 0; r < 6; ++r) x[r] = sx[r];
         }
         // Rz(x2) * Ry(x1) * Rx(x0) as axis-angle quaternions (:441-444), f32 like the reference
         const float hx = (float)x[0] / 2.0f, hy = (float)x[1] / 2.0f, hz = (float)x[2] / 2.0f;
