@@ -220,12 +220,13 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// squared distance of record c = (x, y, z, index bits) to the query, same operations and order as
-// d2_nc (dx*dx + dy*dy + dz*dz, no FMA), arranged as packed-f32 pairs
-__device__ __forceinline__ float d2_packed(const f32x4 &c, const f32x2 &qxy, const f32x2 &qz0) {
-    const f32x2 dxy = c.xy - qxy, dzw = c.zw - qz0;
-    const f32x2 sxy = dxy * dxy, szw = dzw * dzw;
-    return (sxy.x + sxy.y) + szw.x;
+// squared distance of record c to the query, same operations and order as d2_nc
+// (dx*dx + dy*dy + dz*dz, no FMA), with the (x, y) part as packed f32
+__device__ __forceinline__ float d2_packed(const f32x3 &c, const f32x2 &qxy, float qz) {
+    const f32x2 dxy = c.xy - qxy;
+    const float dz = c.z - qz;
+    const f32x2 sxy = dxy * dxy;
+    return (sxy.x + sxy.y) + dz * dz;
 }
 
 // raw buffer descriptor over a whole allocation (no range check: 4 GiB window): buffer loads take a
@@ -296,7 +297,7 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     // the +inf padding behind the array), harmless as extra candidates.  Rows are visited in ascending
     // order = ascending position, so the strict '<' keeps the lowest position among equal distances.
     const __amdgpu_buffer_rsrc_t pt_rsrc = raw_rsrc(gv.pts);
-    const f32x2 qxy = {x, y}, qz0 = {z, 0.0f};
+    const f32x2 qxy = {x, y};
     best = INFINITY;
     bestj = 0xFFFFFFFFu;
     uint32_t j = 0, e = 0;
@@ -309,14 +310,14 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
             j = se.x; e = se.y;
         }
         const uint32_t o = j << 4;                      // byte offset (positions < 2^28, checked by icp_setup)
-        // whole 16-byte records: (x, y) and (z, index) sit in aligned register pairs, so the differences
-        // and squares are packed-f32 instructions without shuffles (the index lane is computed and ignored)
-        const f32x4 c0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o, 0, 0));
-        const f32x4 c1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 16u, 0, 0));
-        const f32x4 c2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 32u, 0, 0));
-        const f32x4 c3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 48u, 0, 0));
-        const float v0 = d2_packed(c0, qxy, qz0), v1 = d2_packed(c1, qxy, qz0);
-        const float v2 = d2_packed(c2, qxy, qz0), v3 = d2_packed(c3, qxy, qz0);
+        // 12 of the 16 bytes of a record (the texture data path is ~90 % busy: bytes count); (x, y) is
+        // an aligned register pair: packed-f32 difference and square, z scalar
+        const f32x3 c0 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o, 0, 0));
+        const f32x3 c1 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u, 0, 0));
+        const f32x3 c2 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 32u, 0, 0));
+        const f32x3 c3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 48u, 0, 0));
+        const float v0 = d2_packed(c0, qxy, z), v1 = d2_packed(c1, qxy, z);
+        const float v2 = d2_packed(c2, qxy, z), v3 = d2_packed(c3, qxy, z);
         const bool b01 = v1 < v0, b23 = v3 < v2;
         const float m01 = b01 ? v1 : v0, m23 = b23 ? v3 : v2;
         const uint32_t i01 = b01 ? j + 1 : j, i23 = b23 ? j + 3 : j + 2;
