@@ -70,10 +70,18 @@ static float normals_cell_factor(size_t k) {
     return (float)(0.95 * c / 2.0);
 }
 
+// points per occupied cell wanted on a SURFACE: the disc of radius ~1.9 h (ring 2) must hold the same
+// lambda(k) points the volumetric factor above puts into the ring-2 sphere: sigma h^2 = lambda / (pi 1.9^2)
+static float normals_target_ppo(size_t k) {
+    const double K1 = (double)k + 1.0;
+    return (float)((K1 + 3.1 * std::sqrt(K1) + 2.0) / 11.3);
+}
+
 static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, float *d_out) {
     // radius mode: ring 2 must cover the radius ball, so the cell edge is at least radius / 2
     const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
-    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(cfg->k_neighbors), nullptr, nullptr, nullptr, min_h)) return s;
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(cfg->k_neighbors), nullptr, nullptr, nullptr, min_h,
+                                  normals_target_ppo(cfg->k_neighbors))) return s;
     float vp[3];
     if (cfg->has_viewpoint) {
         vp[0] = cfg->viewpoint[0]; vp[1] = cfg->viewpoint[1]; vp[2] = cfg->viewpoint[2];

@@ -1182,7 +1182,7 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
                            IcpSetup &out) {
     // the search addresses target records by 32-bit byte offsets (16 B each)
     if (nt >= (1ull << 28)) return fail(ctx, TC_UNSUPPORTED, "ICP target clouds are limited to 2^28 - 1 points");
-    if (tc_status s = build_index(ctx, ctx->tgt_index, d_tgt, nt, icp_cell_factor(), nullptr, nullptr)) return s;
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_tgt, nt, icp_cell_factor(), nullptr, nullptr, nullptr, 0.0f, 2.5f)) return s;
     if (p2plane)
         if (tc_status s = gather_normals(ctx, ctx->tgt_index, d_nrm, nstride)) return s;
     if (tc_status s = ensure(ctx, ctx->state, sizeof(IcpState))) return s;

@@ -166,7 +166,7 @@ struct ProfScope {
 // grid.hip
 tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n,
                       float cell_factor, const GridGeom *reuse_geom, const IcpState *d_state_transform,
-                      const TileGeom *tile_major = nullptr, float min_cell_edge = 0.0f);
+                      const TileGeom *tile_major = nullptr, float min_cell_edge = 0.0f, float target_ppo = 0.0f);
 TileGeom make_tiles(const GridGeom &g, int tx, int ty, int tz);
 tc_status gather_normals(tc_context *ctx, DeviceIndex &ix, const float *d_normals, size_t stride);
 GridView view_of(const DeviceIndex &ix);
