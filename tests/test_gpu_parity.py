@@ -231,6 +231,26 @@ def test_tum_shaped_surface_cloud(ctx):
     assert (g.correspondences != r.correspondences).any(axis=1).mean() < 1e-3 if len(g.correspondences) == len(r.correspondences) else False
 
 
+def test_large_surface_cloud_adapted_cell_edge(ctx):
+    """>= 2^18 points on a surface: the index shrinks its cell edge from the measured occupancy
+    (grid.hip build_index) -- same exact answers: normals and a few ICP iterations against the oracle."""
+    tgt = synth.tum_shaped_cloud(seed=5, step=1.9)        # ~277k points
+    assert len(tgt) >= (1 << 18)
+    rng = np.random.default_rng(5)
+    tgt = (tgt + rng.normal(0, 1e-4, tgt.shape)).astype(np.float32)
+    gpu = ctx.estimate_normals(tgt, 16)
+    ref = O.estimate_normals(tgt, 16)
+    c = cos_abs(gpu[:, 3:], ref[:, 3:])
+    assert (c < 1 - COS_TOL).sum() <= 2, f"{(c < 1 - COS_TOL).sum()} normals beyond 1e-4, worst {1 - c.min():.2e}"
+    src = _rigid(tgt, np.array([0, 0, -np.sin(0.001), np.cos(0.001), -0.004, 0.003, -0.002], np.float32))
+    g = ctx.icp_point_to_plane_detailed(src, tgt, ref[:, 3:], None, 6, None, 0.0)
+    r = O.icp_point_to_plane_detailed(src, tgt, ref[:, 3:], None, 6, None, 0.0)
+    assert g.iterations == r.iterations
+    assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= 2e-5
+    assert len(g.correspondences) == len(r.correspondences)
+    assert (g.correspondences != r.correspondences).any(axis=1).mean() < 1e-3
+
+
 def test_kitti_shaped_lidar_frame(ctx):
     """BASELINE config [4] shape: 120k-point LiDAR frame (1/r^2 density, ground + walls)."""
     frame = synth.kitti_shaped_cloud(seed=1)
