@@ -70,7 +70,8 @@ def aux_modes(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    ctx = tc.GpuContext(local_rank)
+    # on torch's current stream: the sharded loop (kernels, copies, RCCL all-reduce) is then stream ordered
+    ctx = tc.GpuContext(local_rank, stream=torch.cuda.current_stream(dev).cuda_stream) if args.mode == "sharded" else tc.GpuContext(local_rank)
     if args.mode == "sharded":
         n = args.points if args.points != N_POINTS else 10_000_000
         tgt_h = synth.uniform_cloud(n, seed=7, scale=(10.0, 10.0, 1.0))

@@ -125,6 +125,7 @@ class GpuContext:
             raise GpuError(f"no usable HIP device {device} (tc_status {rc}); threecrate_amd has no CPU fallback")
         self._h = h
         self.device = device
+        self.stream = stream          # raw hipStream_t the context enqueues on (None: its own stream)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -54,15 +54,20 @@ class HipShardBackend:
         ctx._check(rc)
         self.h = h
         self.sums = torch.zeros(SUMS, dtype=torch.float64, device=self.s.device)
+        # a context created on torch's current stream (GpuContext(device, stream=torch.cuda.current_stream().cuda_stream))
+        # shares the stream the collective is enqueued on: the whole loop is stream ordered, no host waits
+        self.same_stream = ctx.stream is not None and ctx.stream == torch.cuda.current_stream(self.s.device).cuda_stream
 
     def reduce(self):
         self.ctx._check(self.L.tc_icp_shard_reduce(self.h))
         self.ctx._check(self.L.tc_icp_shard_get_sums(self.h, self.sums.data_ptr()))
-        self.ctx._check(self.L.tc_synchronize(self.ctx._h))     # the collective runs on torch's stream
+        if not self.same_stream:
+            self.ctx._check(self.L.tc_synchronize(self.ctx._h))     # the collective runs on torch's stream
         return self.sums
 
     def apply(self, sums):
-        self.torch.cuda.current_stream().synchronize()
+        if not self.same_stream:
+            self.torch.cuda.current_stream().synchronize()
         self.ctx._check(self.L.tc_icp_shard_set_sums(self.h, sums.data_ptr()))
         self.ctx._check(self.L.tc_icp_shard_apply(self.h))
 
