@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cloud", choices=["uniform", "tum"], default="uniform",
+                    help="pairs mode: uniform-random cloud (BASELINE configs[1], the judged line) or a TUM-RGB-D-shaped "
+                         "depth-map surface of ~1 M points (configs[2]; auxiliary)")
     ap.add_argument("--mode", choices=["pairs", "sharded", "stream"], default="pairs",
                     help="pairs (default, the judged metric): one independent 1M pair per GPU; sharded: ONE cloud, source "
                          "sharded over the ranks, one all-reduce of the packed 6x6 system per iteration (BASELINE config [3]); "
@@ -168,7 +171,15 @@ def main():
 
     n = args.points
     # every rank owns an independent scan pair (seed differs per rank)
-    src_h, tgt_h, _ = synth.registration_pair(n, seed=1 + rank, transform=synth.harness_transform())
+    if args.cloud == "tum":
+        # ~1 M-point depth-map surface, scan-to-scan motion of a hand-held camera (1 cm, 0.3 deg)
+        tgt_h = synth.tum_shaped_cloud(seed=1 + rank)
+        rng = np.random.default_rng(100 + rank)
+        tgt_h = (tgt_h + rng.normal(0, 1e-4, tgt_h.shape)).astype(np.float32)
+        src_h = synth.apply_isometry(synth.yaw_isometry((-0.01, 0.004, 0.002), -np.deg2rad(0.3)), tgt_h)
+        n = len(tgt_h)
+    else:
+        src_h, tgt_h, _ = synth.registration_pair(n, seed=1 + rank, transform=synth.harness_transform())
     src, tgt = torch.from_numpy(src_h).to(dev), torch.from_numpy(tgt_h).to(dev)
     ctx = tc.GpuContext(local_rank)
     # sampled hipEvents around the dominant kernel only (every 4th launch): ~1 % overhead in the timed region
@@ -231,8 +242,10 @@ def main():
             "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n}-pt uniform-random cloud, k={K_NORMALS} normals + {ICP_ITERS}-iter point-to-plane ICP "
-                                   "(BASELINE configs[1]; one independent pair per GPU)",
+            "config": {"workload": (f"{n}-pt uniform-random cloud, k={K_NORMALS} normals + {ICP_ITERS}-iter point-to-plane ICP "
+                                    "(BASELINE configs[1]; one independent pair per GPU)") if args.cloud == "uniform" else
+                                   (f"{n}-pt TUM-RGB-D-shaped depth-map surface, k={K_NORMALS} normals + {ICP_ITERS}-iter point-to-plane ICP "
+                                    "(BASELINE configs[2] shape; one independent pair per GPU; auxiliary line)"),
                        "points": n, "k": K_NORMALS, "icp_iterations": ICP_ITERS, "parallelism": f"pairs{world}"},
             "normals_mpts_per_s": n * args.steps * world / tn / 1e6,
             "icp_only_it_per_s": ICP_ITERS * args.steps * world / ti,
@@ -242,6 +255,9 @@ def main():
             "kernels_us_avg": {kk: round(1e3 * ms / max(c, 1), 2) for kk, (c, ms) in stats.items()},
             "final_mse": last.mse,
         }
+        if args.cloud != "uniform":
+            out["roofline"]["traffic"] = None          # PMC passes were collected on the uniform config
+            out["roofline"].pop("traffic_detail", None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, tgt_h, src_h)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
