@@ -240,6 +240,49 @@ tc_status tc_voxel_grid_filter(tc_context *ctx, const float *xyz, size_t n, floa
 tc_status tc_voxel_grid_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float voxel_size,
                                       float *d_out_xyz, size_t *n_out);
 
+/* ---- LiDAR frame streaming ----
+ * A bounded queue of host frames in front of the per-frame pipeline
+ *   voxel_grid_filter -> estimate_normals(previous frame) -> icp_point_to_plane(current -> previous),
+ * modelled on RealtimePipeline (threecrate-algorithms/src/streaming.rs:540-646; BackpressureConfig
+ * .max_queue_depth): send() blocks the producer while max_queue_depth frames are waiting, try_send()
+ * drops the frame instead (metrics.items_dropped), finish() closes the input, drains the queue, joins
+ * the worker and returns one result per consecutive frame pair (init = identity) plus the metrics.
+ * The host->device copy of frame i+1 overlaps the kernels of frame i (second HIP stream).  Frames are
+ * n x 3 floats (stride_floats = 3) or KITTI records x, y, z, intensity (stride_floats = 4); the
+ * caller's buffer is free when send returns.  The context must not be used by other calls while the
+ * stream exists.  voxel_size <= 0: no filter.  max_correspondence_distance < 0: None. */
+typedef struct tc_frame_stream tc_frame_stream;
+typedef struct tc_frame_stream_config {
+    size_t max_points;                  /* capacity of one frame */
+    size_t max_queue_depth;
+    float  voxel_size;
+    size_t k_neighbors;
+    size_t max_iterations;
+    float  max_correspondence_distance;
+    float  convergence_threshold;
+} tc_frame_stream_config;
+typedef struct tc_frame_result {
+    float    transformation[7];         /* current frame -> previous frame */
+    float    mse;
+    uint64_t iterations;
+    int32_t  converged;
+    int32_t  status;                    /* tc_status of this frame's pipeline */
+    uint64_t n_points_in, n_points;     /* before / after the voxel filter */
+} tc_frame_result;
+typedef struct tc_frame_stream_metrics {    /* RealtimeMetrics, streaming.rs */
+    uint64_t items_queued, items_processed, items_dropped, max_depth_seen;
+} tc_frame_stream_metrics;
+tc_status tc_frame_stream_create(tc_context *ctx, const tc_frame_stream_config *config, tc_frame_stream **out);
+tc_status tc_frame_stream_send(tc_frame_stream *s, const float *frame, size_t n, size_t stride_floats);
+tc_status tc_frame_stream_try_send(tc_frame_stream *s, const float *frame, size_t n, size_t stride_floats, int *accepted);
+tc_status tc_frame_stream_finish(tc_frame_stream *s, tc_frame_result *results, size_t capacity, size_t *n_results,
+                                 tc_frame_stream_metrics *metrics);
+void      tc_frame_stream_destroy(tc_frame_stream *s);
+/* VelodyneKittiBinReader::read (threecrate-io/src/lidar.rs:310-343): 16-byte little-endian records
+ * x, y, z, intensity -> n x 3 floats.  out_xyz == NULL: only *n_points is set (size query).  A file
+ * size that is not a multiple of 16, or a capacity below the point count: TC_INVALID_DATA. */
+tc_status tc_read_kitti_bin(const char *path, float *out_xyz, size_t capacity_points, size_t *n_points);
+
 /* ---- profiling ---- */
 /* on: 0 = off, 1 = hipEvents around every kernel, 2 = only around every 4th launch of the dominant
    kernel (icp_correspond_reduce): ~1 % overhead, used inside bench.py's timed region */

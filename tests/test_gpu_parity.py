@@ -6,6 +6,8 @@ ICP transform within 1e-5 Frobenius (4x4 homogeneous matrix).
 import numpy as np
 import pytest
 
+import threecrate_amd as tc
+
 from oracle import oracle as O
 from tests.helpers import cos_abs, frob
 from threecrate_amd import synth
@@ -351,3 +353,41 @@ def test_multiscale_icp_matches_oracle(ctx):
         ctx.multiscale_icp_point_to_point(src, pts, None, tc.MultiScaleIcpConfig(levels=[]))
     with pytest.raises(tc.InvalidData):
         ctx.multiscale_icp_point_to_point(src, pts, None, tc.MultiScaleIcpConfig(convergence_threshold=0.0))
+
+
+def test_frame_stream_matches_per_frame_calls(ctx):
+    """tc_frame_stream_* (RealtimePipeline shape, streaming.rs:540-646): the streamed pipeline gives
+    exactly the results of the same calls made frame by frame, keeps every frame under send()
+    (backpressure), and accounts for dropped frames under try_send()."""
+    ego = synth.yaw_isometry((-1.0, 0.0, 0.0), -np.deg2rad(0.5))
+    frames = []
+    f = synth.kitti_shaped_cloud(seed=3)
+    for i in range(5):
+        frames.append(f)
+        f = synth.apply_isometry(ego, synth.kitti_shaped_cloud(seed=3 + i + 1))
+    kitti = [np.concatenate([fr, np.full((len(fr), 1), 0.5, np.float32)], axis=1) for fr in frames]   # x y z intensity
+    fs = tc.FrameStream(ctx, max_points=130000, voxel_size=0.25, k_neighbors=16, max_iterations=30,
+                        max_correspondence_distance=2.0, convergence_threshold=1e-6,
+                        backpressure=tc.BackpressureConfig(max_queue_depth=2))
+    for fr in kitti:
+        fs.send(fr)
+    res, m = fs.finish()
+    assert m.items_queued == 5 and m.items_processed == 5 and m.items_dropped == 0 and 1 <= m.max_depth_seen <= 2
+    assert len(res) == 4 and all(r.status == 0 for r in res)
+    # the same pipeline, call by call
+    prev = ctx.voxel_grid_filter(frames[0], 0.25)
+    for i in range(1, 5):
+        cur = ctx.voxel_grid_filter(frames[i], 0.25)
+        nrm = ctx.estimate_normals(prev, 16)
+        r = ctx.icp_point_to_plane_detailed(cur, prev, nrm, None, 30, 2.0, 1e-6, correspondences=False)
+        assert res[i - 1].n_points == len(cur) and res[i - 1].n_points_in == len(frames[i])
+        assert res[i - 1].iterations == r.iterations and res[i - 1].converged == r.converged
+        assert np.array_equal(res[i - 1].transformation, r.transformation) and res[i - 1].mse == r.mse
+        prev = cur
+    # try_send never blocks: with a queue of 1 and a burst of frames some are dropped, none are lost silently
+    fs = tc.FrameStream(ctx, max_points=130000, voxel_size=0.25, max_iterations=30, max_correspondence_distance=2.0,
+                        backpressure=tc.BackpressureConfig(max_queue_depth=1))
+    accepted = sum(fs.try_send(frames[i % 5]) for i in range(12))
+    res, m = fs.finish()
+    assert m.items_queued == accepted and m.items_dropped == 12 - accepted and m.items_processed == accepted
+    assert len(res) == max(accepted - 1, 0)

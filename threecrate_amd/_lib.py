@@ -45,6 +45,22 @@ class MultiScaleConfigC(C.Structure):
                 ("final_max_correspondence_distance", C.c_float), ("convergence_threshold", C.c_float)]
 
 
+class FrameStreamConfigC(C.Structure):
+    _fields_ = [("max_points", C.c_size_t), ("max_queue_depth", C.c_size_t), ("voxel_size", C.c_float),
+                ("k_neighbors", C.c_size_t), ("max_iterations", C.c_size_t),
+                ("max_correspondence_distance", C.c_float), ("convergence_threshold", C.c_float)]
+
+
+class FrameResultC(C.Structure):
+    _fields_ = [("transformation", C.c_float * 7), ("mse", C.c_float), ("iterations", C.c_uint64),
+                ("converged", C.c_int32), ("status", C.c_int32), ("n_points_in", C.c_uint64), ("n_points", C.c_uint64)]
+
+
+class FrameStreamMetricsC(C.Structure):
+    _fields_ = [("items_queued", C.c_uint64), ("items_processed", C.c_uint64), ("items_dropped", C.c_uint64),
+                ("max_depth_seen", C.c_uint64)]
+
+
 class KernelStatC(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -58,7 +74,9 @@ EXPORTS = [
     "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
     "tc_icp_shard_reduce", "tc_icp_shard_get_sums", "tc_icp_shard_set_sums", "tc_icp_shard_done",
     "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
-    "tc_multiscale_icp_point_to_point", "tc_knn", "tc_knn_device", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device", "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
+    "tc_multiscale_icp_point_to_point", "tc_knn", "tc_knn_device", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device",
+    "tc_frame_stream_create", "tc_frame_stream_send", "tc_frame_stream_try_send", "tc_frame_stream_finish",
+    "tc_frame_stream_destroy", "tc_read_kitti_bin", "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
 ]
 
 _lib = None
@@ -133,6 +151,13 @@ def load():
     L.tc_knn_device.argtypes = [vp, f32p, sz, f32p, sz, sz, vp, vp, vp]
     L.tc_voxel_grid_filter.argtypes = [vp, f32p, sz, f, f32p, C.POINTER(C.c_size_t)]
     L.tc_voxel_grid_filter_device.argtypes = [vp, f32p, sz, f, f32p, C.POINTER(C.c_size_t)]
+    L.tc_frame_stream_create.argtypes = [vp, C.POINTER(FrameStreamConfigC), ctxpp]
+    L.tc_frame_stream_send.argtypes = [vp, f32p, sz, sz]
+    L.tc_frame_stream_try_send.argtypes = [vp, f32p, sz, sz, C.POINTER(C.c_int)]
+    L.tc_frame_stream_finish.argtypes = [vp, C.POINTER(FrameResultC), sz, C.POINTER(C.c_size_t), C.POINTER(FrameStreamMetricsC)]
+    L.tc_frame_stream_destroy.argtypes = [vp]
+    L.tc_frame_stream_destroy.restype = None
+    L.tc_read_kitti_bin.argtypes = [C.c_char_p, f32p, sz, C.POINTER(C.c_size_t)]
     L.tc_profile_enable.argtypes = [vp, i]
     L.tc_profile_enable.restype = None
     L.tc_profile_reset.argtypes = [vp]

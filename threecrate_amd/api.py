@@ -10,6 +10,7 @@ take the host entry points (H2D staging inside the library); torch CUDA tensors 
 *_device entry points with zero copies.  There is no CPU fallback.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -469,3 +470,107 @@ def gpu_batch_icp(gpu_contexts, jobs):
         raise InvalidData("tc_batch_icp: bad arguments")
     return [BatchICPResult(np.array(list(cr[i].transformation), np.float32), float(cr[i].final_error),
                            int(cr[i].iterations), int(cr[i].status)) for i in range(len(jobs))]
+
+
+# ---- LiDAR frame streaming (RealtimePipeline, threecrate-algorithms/src/streaming.rs:540-646) -------
+@dataclass
+class BackpressureConfig:
+    """streaming.rs BackpressureConfig: only max_queue_depth applies to whole-frame items."""
+    max_queue_depth: int = 4
+
+
+@dataclass
+class FrameResult:
+    transformation: np.ndarray      # current frame -> previous frame (7-float Isometry3)
+    mse: float
+    iterations: int
+    converged: bool
+    status: int
+    n_points_in: int
+    n_points: int
+
+    @property
+    def matrix(self):
+        return isometry_to_matrix(self.transformation)
+
+
+@dataclass
+class RealtimeMetrics:
+    items_queued: int
+    items_processed: int
+    items_dropped: int
+    max_depth_seen: int
+
+
+class FrameStream:
+    """Bounded-queue frame registration pipeline on one GPU (tc_frame_stream_*): send() blocks when the
+    queue is full, try_send() drops instead, finish() drains and returns (results, metrics).  Frames are
+    host arrays (n, 3) or KITTI records (n, 4)."""
+
+    def __init__(self, ctx: "GpuContext", max_points: int, voxel_size: float = 0.2, k_neighbors: int = 16,
+                 max_iterations: int = 50, max_correspondence_distance=None, convergence_threshold: float = 1e-6,
+                 backpressure: BackpressureConfig = None):
+        self._ctx, self._L = ctx, _lib.load()
+        bp = backpressure or BackpressureConfig()
+        cfg = _lib.FrameStreamConfigC(max_points, bp.max_queue_depth, voxel_size, k_neighbors, max_iterations,
+                                      -1.0 if max_correspondence_distance is None else float(max_correspondence_distance),
+                                      convergence_threshold)
+        h = C.c_void_p()
+        ctx._check(self._L.tc_frame_stream_create(ctx._h, C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._sent = 0
+
+    def _frame(self, frame):
+        a = np.ascontiguousarray(np.asarray(frame, np.float32))
+        if a.ndim != 2 or a.shape[1] not in (3, 4):
+            raise InvalidData("a frame is an (n, 3) xyz or (n, 4) KITTI x, y, z, intensity array")
+        return a
+
+    def send(self, frame):
+        a = self._frame(frame)
+        self._ctx._check(self._L.tc_frame_stream_send(self._h, a.ctypes.data, a.shape[0], a.shape[1]))
+        self._sent += 1
+
+    def try_send(self, frame) -> bool:
+        a = self._frame(frame)
+        ok = C.c_int(0)
+        self._ctx._check(self._L.tc_frame_stream_try_send(self._h, a.ctypes.data, a.shape[0], a.shape[1], C.byref(ok)))
+        self._sent += int(ok.value)
+        return bool(ok.value)
+
+    def finish(self):
+        cap = max(self._sent, 1)
+        res = (_lib.FrameResultC * cap)()
+        n = C.c_size_t(0)
+        m = _lib.FrameStreamMetricsC()
+        rc = self._L.tc_frame_stream_finish(self._h, res, cap, C.byref(n), C.byref(m))
+        self._L.tc_frame_stream_destroy(self._h)
+        self._h = None
+        self._ctx._check(rc)
+        out = [FrameResult(np.array(list(r.transformation), np.float32), float(r.mse), int(r.iterations), bool(r.converged),
+                           int(r.status), int(r.n_points_in), int(r.n_points)) for r in res[:min(n.value, cap)]]
+        return out, RealtimeMetrics(int(m.items_queued), int(m.items_processed), int(m.items_dropped), int(m.max_depth_seen))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.tc_frame_stream_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def read_kitti_bin(path):
+    """VelodyneKittiBinReader::read (threecrate-io/src/lidar.rs:310-343) -> (n, 3) float32."""
+    L = _lib.load()
+    n = C.c_size_t(0)
+    p = os.fsencode(path)
+    rc = L.tc_read_kitti_bin(p, None, 0, C.byref(n))
+    if rc != _lib.TC_OK:
+        raise InvalidData(f"Velodyne KITTI binary: cannot read {path} or its size is not a multiple of 16 bytes")
+    out = np.empty((n.value, 3), np.float32)
+    if n.value:
+        rc = L.tc_read_kitti_bin(p, out.ctypes.data, n.value, C.byref(n))
+        if rc != _lib.TC_OK:
+            raise InvalidData(f"Velodyne KITTI binary: cannot read {path}")
+    return out
