@@ -218,6 +218,25 @@ tc_status tc_multiscale_icp_point_to_point(tc_context *ctx, const float *source,
                           const float *target, size_t n_target, const float init[7],
                           const tc_multiscale_icp_config *config, tc_icp_result *result);
 
+/* ---- KISS-ICP ----
+ * kiss_icp(source, target, init, KissIcpConfig) -> Result<ICPResult>  (threecrate-algorithms/src/kiss_icp.rs:
+ * 183-300; config :28-49, defaults voxel 1.0, max_range 100, min_range 0.5, 50 iterations): range filter
+ * (:56-70) and voxel down-sampling of the source, adaptive correspondence threshold from `init` (:82-95),
+ * point-to-point updates against the full target, mse measured AFTER each update, |prev - mse| < 1e-6 rule,
+ * not converged -> last mse.  correspondences index the DOWN-SAMPLED source (here: voxels in (kx, ky, kz)
+ * order; the reference's HashMap order is unspecified): corr_target (capacity n_source) gets
+ * *n_source_down entries. */
+typedef struct tc_kiss_icp_config {
+    float  voxel_size;
+    float  max_range;
+    float  min_range;
+    size_t max_iterations;
+} tc_kiss_icp_config;
+tc_status tc_kiss_icp(tc_context *ctx, const float *source, size_t n_source, const float *target, size_t n_target,
+                      const float init[7], const tc_kiss_icp_config *config, tc_icp_result *result, size_t *n_source_down);
+tc_status tc_kiss_icp_device(tc_context *ctx, const float *d_source, size_t n_source, const float *d_target, size_t n_target,
+                             const float init[7], const tc_kiss_icp_config *config, tc_icp_result *result, size_t *n_source_down);
+
 /* ---- batch k-NN export ----
  * NearestNeighborSearch::find_k_nearest(&query, k) -> Vec<(usize, f32)> for many queries
  * (threecrate-core/src/traits.rs:6-12, threecrate-algorithms/src/nearest_neighbor.rs:177-251;

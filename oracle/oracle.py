@@ -66,6 +66,10 @@ def lib():
         L.tco_icp.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, f32p, C.c_size_t, f32p, C.c_int]
         L.tco_icp.restype = None
         L.tco_voxel_grid_filter.argtypes = [f32p, C.c_size_t, C.c_float, f32p, C.POINTER(C.c_size_t)]
+        L.tco_kiss_adaptive_threshold.argtypes = [f32p, C.c_float]
+        L.tco_kiss_adaptive_threshold.restype = C.c_float
+        L.tco_kiss_icp.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, f32p, C.c_float, C.c_float, C.c_float, C.c_size_t,
+                                   C.POINTER(_IcpResult), C.POINTER(C.c_size_t), C.c_int]
         L.tco_p2plane_partial.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_void_p, f32p, f32p, f32p, C.c_float, f64p, u32p]
         L.tco_p2p_partial.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_void_p, f32p, f32p, C.c_float, f64p, u32p]
         L.tco_symmetric_eigen3.argtypes = [f32p, f32p, f32p]
@@ -228,6 +232,28 @@ def icp_point_to_plane_detailed(src, tgt, tgt_normals, init, max_iters, max_corr
 def icp_point_to_plane(src, tgt, tgt_normals, init, max_iters, threads=0):
     """registration.rs:488-496"""
     return icp_point_to_plane_detailed(src, tgt, tgt_normals, init, max_iters, None, 1e-6, threads)
+
+
+def kiss_icp(src, tgt, init=None, voxel_size=1.0, max_range=100.0, min_range=0.5, max_iterations=50, threads=0):
+    """kiss_icp.rs:183-300 (KissIcpConfig defaults :40-49); correspondences index the voxel-downsampled source.
+    Returns (IcpResult, number of downsampled source points)."""
+    s, t = _f32(src, 3), _f32(tgt, 3)
+    r = _IcpResult()
+    cs = np.zeros(max(1, len(s)), np.uint64)
+    ct = np.zeros(max(1, len(s)), np.uint64)
+    r.corr_src = _p(cs, C.c_uint64)
+    r.corr_tgt = _p(ct, C.c_uint64)
+    i7 = _f32(IDENTITY if init is None else init).reshape(7)
+    nd = C.c_size_t(0)
+    rc = lib().tco_kiss_icp(_p(s), len(s), _p(t), len(t), _p(i7), voxel_size, max_range, min_range, max_iterations,
+                            C.byref(r), C.byref(nd), threads)
+    if rc:
+        raise OracleError(rc)
+    return IcpResult(r, len(s), cs, ct), int(nd.value)
+
+
+def kiss_adaptive_threshold(init, voxel_size):
+    return float(lib().tco_kiss_adaptive_threshold(_p(_f32(init).reshape(7)), voxel_size))
 
 
 def voxel_grid_filter(points, voxel_size):

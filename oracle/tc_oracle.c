@@ -1391,3 +1391,122 @@ int tco_voxel_grid_filter(const float *xyz, size_t n, float voxel, float *out, s
     *n_out = o;
     return TCO_OK;
 }
+
+
+/* ---- KISS-ICP (threecrate-algorithms/src/kiss_icp.rs) ---------------------------------------
+ * range_filter :56-70, adaptive_threshold :82-95, svd_transform :102-162 (= compute_transformation
+ * plus the |H|_F < 1e-10 rejection), kiss_icp :183-300 (mse AFTER applying delta, fixed 1e-6 rule,
+ * not converged -> prev_mse).  The downsampled source comes from tco_voxel_grid_filter, whose output
+ * order (sorted by voxel key) stands in for the reference's unspecified HashMap order: correspondence
+ * source indices refer to that order. */
+static int kiss_svd_transform(const float *vs, const float *vq, size_t n, float out[7]) {
+    if (n < 3) return TCO_ALGORITHM;
+    float nf = (float)n;
+    float cs[3] = { 0, 0, 0 }, cq[3] = { 0, 0, 0 };
+    for (size_t i = 0; i < n; ++i) { cs[0] = cs[0] + vs[3 * i]; cs[1] = cs[1] + vs[3 * i + 1]; cs[2] = cs[2] + vs[3 * i + 2]; }
+    cs[0] /= nf; cs[1] /= nf; cs[2] /= nf;
+    for (size_t i = 0; i < n; ++i) { cq[0] = cq[0] + vq[3 * i]; cq[1] = cq[1] + vq[3 * i + 1]; cq[2] = cq[2] + vq[3 * i + 2]; }
+    cq[0] /= nf; cq[1] /= nf; cq[2] /= nf;
+    float h[3][3] = { {0, 0, 0}, {0, 0, 0}, {0, 0, 0} };
+    for (size_t i = 0; i < n; ++i) {
+        float p[3] = { vs[3 * i] - cs[0], vs[3 * i + 1] - cs[1], vs[3 * i + 2] - cs[2] };
+        float q[3] = { vq[3 * i] - cq[0], vq[3 * i + 1] - cq[1], vq[3 * i + 2] - cq[2] };
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) h[r][c] += p[r] * q[c];
+    }
+    float hn = 0.0f;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) hn += h[r][c] * h[r][c];
+    if (sqrtf(hn) < 1e-10f) return TCO_ALGORITHM;                       /* :130-136 */
+    float U[3][3], w[3], Vt[3][3];
+    svd3(h, U, w, Vt);
+    float V[3][3], Ut[3][3], R[3][3];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { V[r][c] = Vt[c][r]; Ut[r][c] = U[c][r]; }
+    mat3_mul(V, Ut, R);
+    if (mat3_det(R) < 0.0f) {
+        for (int c = 0; c < 3; ++c) Vt[2][c] = -Vt[2][c];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) V[r][c] = Vt[c][r];
+        mat3_mul(V, Ut, R);
+    }
+    float q[4]; quat_from_matrix(R, q);
+    float rc[3]; quat_rotate(q, cs, rc);
+    out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
+    out[4] = cq[0] - rc[0]; out[5] = cq[1] - rc[1]; out[6] = cq[2] - rc[2];
+    return TCO_OK;
+}
+
+float tco_kiss_adaptive_threshold(const float init[7], float voxel_size) {      /* :82-95 */
+    float trans = sqrtf(init[4] * init[4] + init[5] * init[5] + init[6] * init[6]);
+    float imag = sqrtf(init[0] * init[0] + init[1] * init[1] + init[2] * init[2]);
+    float rot_disp = 2.0f * imag * voxel_size;
+    float motion = trans + rot_disp;
+    return fminf(fmaxf(3.0f * motion, 3.0f * voxel_size), 10.0f * voxel_size);
+}
+
+int tco_kiss_icp(const float *src, size_t ns, const float *tgt, size_t nt, const float init[7],
+                 float voxel_size, float max_range, float min_range, size_t max_iters,
+                 tco_icp_result *res, size_t *n_source_down, int threads) {
+    if (ns == 0 || nt == 0) return TCO_INVALID_DATA;        /* :189-193 */
+    if (max_iters == 0) return TCO_INVALID_DATA;            /* :194-198 */
+    if (voxel_size <= 0.0f) return TCO_INVALID_DATA;        /* :199-203 */
+    float min_sq = min_range * min_range, max_sq = max_range * max_range;
+    float *ranged = (float *)malloc(ns * 3 * sizeof(float));
+    size_t nr = 0;
+    for (size_t j = 0; j < ns; ++j) {                        /* range_filter :56-70 */
+        const float *p = &src[3 * j];
+        float r2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+        if (r2 >= min_sq && r2 <= max_sq) { memcpy(&ranged[3 * nr], p, 12); ++nr; }
+    }
+    if (nr == 0) { free(ranged); return TCO_INVALID_DATA; }  /* :207-213 */
+    float *down = (float *)malloc(nr * 3 * sizeof(float));
+    size_t nd = 0;
+    int vrc = tco_voxel_grid_filter(ranged, nr, voxel_size, down, &nd);
+    free(ranged);
+    if (vrc != TCO_OK || nd == 0) { free(down); return TCO_INVALID_DATA; }
+    if (n_source_down) *n_source_down = nd;
+    float sigma = tco_kiss_adaptive_threshold(init, voxel_size);
+    tco_kdtree *tree = tco_kdtree_new(tgt, nt);
+    float cur[7]; memcpy(cur, init, sizeof(cur));
+    float prev_mse = INFINITY;
+    float *ts = (float *)malloc(nd * 3 * sizeof(float));
+    float *vs = (float *)malloc(nd * 3 * sizeof(float));
+    float *vq = (float *)malloc(nd * 3 * sizeof(float));
+    uint64_t *ti = (uint64_t *)malloc(nd * sizeof(uint64_t));
+    uint64_t *pcs = (uint64_t *)malloc(nd * sizeof(uint64_t)), *pct = (uint64_t *)malloc(nd * sizeof(uint64_t));
+    uint64_t *fcs = (uint64_t *)malloc(nd * sizeof(uint64_t)), *fct = (uint64_t *)malloc(nd * sizeof(uint64_t));
+    size_t nfinal = 0;
+    int rc = TCO_OK, done = 0;
+    for (size_t it = 0; it < max_iters && !done; ++it) {
+        for (size_t j = 0; j < nd; ++j) tco_isometry_apply(cur, &down[3 * j], &ts[3 * j]);
+        find_correspondences(ts, nd, tree, sigma, ti, threads);          /* dist > sigma -> skip :244-250 */
+        size_t nv = 0;
+        for (size_t j = 0; j < nd; ++j) if (ti[j] != UINT64_MAX) {
+            memcpy(&vs[3 * nv], &ts[3 * j], 12); memcpy(&vq[3 * nv], &tgt[3 * ti[j]], 12);
+            pcs[nv] = j; pct[nv] = ti[j]; ++nv;
+        }
+        if (nv < 3) { rc = TCO_ALGORITHM; break; }                       /* :256-262 */
+        float delta[7], nxt[7];
+        rc = kiss_svd_transform(vs, vq, nv, delta);
+        if (rc != TCO_OK) break;
+        tco_isometry_mul(delta, cur, nxt); memcpy(cur, nxt, sizeof(cur));
+        float sum = 0.0f;                                                /* mse after delta :270-276 */
+        for (size_t i = 0; i < nv; ++i) {
+            float d[3]; tco_isometry_apply(delta, &vs[3 * i], d);
+            float dx = d[0] - vq[3 * i], dy = d[1] - vq[3 * i + 1], dz = d[2] - vq[3 * i + 2];
+            sum += dx * dx + dy * dy + dz * dz;
+        }
+        float mse = sum / (float)nv;
+        if (fabsf(prev_mse - mse) < 1e-6f) {                             /* :278-286 */
+            memcpy(res->transform, cur, sizeof(cur)); res->mse = mse; res->iterations = it + 1; res->converged = 1;
+            result_store_corr(res, pcs, pct, nv);
+            done = 1; break;
+        }
+        prev_mse = mse;
+        uint64_t *t1 = fcs; fcs = pcs; pcs = t1; t1 = fct; fct = pct; pct = t1; nfinal = nv;
+    }
+    if (rc == TCO_OK && !done) {                                         /* :292-299 */
+        memcpy(res->transform, cur, sizeof(cur)); res->mse = prev_mse; res->iterations = max_iters; res->converged = 0;
+        result_store_corr(res, fcs, fct, nfinal);
+    }
+    free(down); free(ts); free(vs); free(vq); free(ti); free(pcs); free(pct); free(fcs); free(fct);
+    tco_kdtree_free(tree);
+    return rc;
+}

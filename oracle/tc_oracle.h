@@ -121,4 +121,10 @@ int  tco_num_threads(void);
 #ifdef __cplusplus
 }
 #endif
+/* KISS-ICP (threecrate-algorithms/src/kiss_icp.rs:183-300); correspondences index the voxel-downsampled source */
+float tco_kiss_adaptive_threshold(const float init[7], float voxel_size);
+int tco_kiss_icp(const float *src, size_t ns, const float *tgt, size_t nt, const float init[7],
+                 float voxel_size, float max_range, float min_range, size_t max_iters,
+                 tco_icp_result *res, size_t *n_source_down, int threads);
+
 #endif

@@ -391,3 +391,39 @@ def test_frame_stream_matches_per_frame_calls(ctx):
     res, m = fs.finish()
     assert m.items_queued == accepted and m.items_dropped == 12 - accepted and m.items_processed == accepted
     assert len(res) == max(accepted - 1, 0)
+
+
+def test_kiss_icp_matches_oracle(ctx):
+    """kiss_icp (kiss_icp.rs:183-300): range filter + voxel down-sampling + adaptive threshold + mse after the
+    update.  LiDAR-shaped frame pair, ego motion 1 m + 0.5 deg; then the reference's own error cases."""
+    f = synth.kitti_shaped_cloud(seed=1)
+    ego = synth.yaw_isometry((-1.0, 0.0, 0.0), -np.deg2rad(0.5))
+    cur = synth.apply_isometry(ego, f)
+    cfg = tc.KissIcpConfig(voxel_size=0.5, max_range=100.0, min_range=0.5, max_iterations=50)
+    g = ctx.kiss_icp(cur, f, None, cfg)
+    r, nd = O.kiss_icp(cur, f, None, 0.5, 100.0, 0.5, 50)
+    assert g.iterations == r.iterations and g.converged == r.converged
+    assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= 1e-4
+    assert abs(g.mse - r.mse) <= 1e-3 * max(r.mse, 1e-6)
+    assert len(g.corr_target) == nd
+    assert len(g.correspondences) == len(r.correspondences)
+    assert (g.correspondences != r.correspondences).any(axis=1).mean() < 1e-3
+    # with a prior (init) the adaptive threshold widens: 3 * motion, clamped to [3, 10] voxels (kiss_icp.rs:82-95)
+    init = synth.yaw_isometry((0.9, 0.0, 0.0), np.deg2rad(0.4))
+    g2 = ctx.kiss_icp(cur, f, init, cfg)
+    r2, _ = O.kiss_icp(cur, f, init, 0.5, 100.0, 0.5, 50)
+    assert g2.iterations == r2.iterations and g2.converged == r2.converged
+    assert frob(g2.transformation, r2.transformation, O.isometry_to_matrix) <= 1e-4
+    # device-resident inputs give the same answer
+    import torch
+    gd = ctx.kiss_icp(torch.from_numpy(cur).cuda(), torch.from_numpy(f).cuda(), None, cfg)
+    assert np.array_equal(gd.transformation, g.transformation) and gd.iterations == g.iterations
+    # error behaviour (kiss_icp.rs:189-213)
+    with pytest.raises(tc.InvalidData):
+        ctx.kiss_icp(cur[:0], f, None, cfg)
+    with pytest.raises(tc.InvalidData):
+        ctx.kiss_icp(cur, f, None, tc.KissIcpConfig(voxel_size=0.0))
+    with pytest.raises(tc.InvalidData):
+        ctx.kiss_icp(cur, f, None, tc.KissIcpConfig(max_iterations=0))
+    with pytest.raises(tc.InvalidData):
+        ctx.kiss_icp(cur, f, None, tc.KissIcpConfig(voxel_size=0.5, min_range=500.0, max_range=600.0))   # nothing in range

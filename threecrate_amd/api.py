@@ -74,6 +74,15 @@ class MultiScaleIcpConfig:
 
 
 @dataclass
+class KissIcpConfig:
+    """kiss_icp.rs:28-49"""
+    voxel_size: float = 1.0
+    max_range: float = 100.0
+    min_range: float = 0.5
+    max_iterations: int = 50
+
+
+@dataclass
 class ICPResult:
     """registration.rs:13-24; `transformation` is the 7-float Isometry3 (qi qj qk qw tx ty tz)."""
     transformation: np.ndarray
@@ -270,6 +279,31 @@ class GpuContext:
         self._check(fn(self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], i7.ctypes.data, max_iters, a, b, C.byref(r)))
         return self._result(r, s.shape[0], None if corr is None else corr[: s.shape[0]], correspondences)
 
+    def kiss_icp(self, source, target, init=None, config: "KissIcpConfig" = None, correspondences=True):
+        """kiss_icp.rs:183-300.  `correspondences` pairs (index into the voxel-downsampled source, target index)."""
+        cfg = config or KissIcpConfig()
+        c = _lib.KissIcpConfigC(cfg.voxel_size, cfg.max_range, cfg.min_range, cfg.max_iterations)
+        i7 = np.ascontiguousarray(IDENTITY if init is None else np.asarray(init, np.float32).reshape(7))
+        r = _lib.IcpResultC()
+        nd = C.c_size_t(0)
+        if _is_torch(source):
+            import torch
+            s = source.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            t = target.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
+            r.corr_target = corr.data_ptr() if corr is not None else None
+            self._check(self._L.tc_kiss_icp_device(self._h, s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], i7.ctypes.data,
+                                                   C.byref(c), C.byref(r), C.byref(nd)))
+            if corr is not None:
+                corr = corr[: nd.value].to(torch.int64) & 0xFFFFFFFF
+            return self._result(r, nd.value, corr, correspondences)
+        s, t = _as_host(source), _as_host(target)
+        corr = np.empty(max(1, s.shape[0]), np.uint32) if correspondences else None
+        r.corr_target = corr.ctypes.data if corr is not None else None
+        self._check(self._L.tc_kiss_icp(self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], i7.ctypes.data,
+                                        C.byref(c), C.byref(r), C.byref(nd)))
+        return self._result(r, nd.value, None if corr is None else corr[: nd.value], correspondences)
+
     def icp_point_to_point(self, source, target, init=None, max_iterations=50, convergence_threshold=1e-6,
                            max_correspondence_distance=None, correspondences=True):
         """registration.rs:644-680 (adds the threshold > 0 check)"""
@@ -394,6 +428,11 @@ def icp_point_to_point(source, target, init, max_iterations, convergence_thresho
                        max_correspondence_distance=None, ctx=None):
     return (ctx or default_context()).icp_point_to_point(source, target, init, max_iterations, convergence_threshold,
                                                          max_correspondence_distance)
+
+
+def kiss_icp(source, target, init, config=None, ctx=None):
+    """kiss_icp.rs:183-188"""
+    return (ctx or default_context()).kiss_icp(source, target, init, config)
 
 
 def icp_point_to_point_default(source, target, init, max_iterations, ctx=None):

@@ -374,6 +374,67 @@ tc_status tc_multiscale_icp_point_to_point(tc_context *ctx, const float *source,
     return st;
 }
 
+// ---- KISS-ICP (kiss_icp.rs:183-300) ----------------------------------------------------------------
+// range filter -> voxel down-sampling of the source -> point-to-point ICP against the full target with the
+// adaptive correspondence threshold, mse measured after every update, fixed 1e-6 convergence rule
+static float kiss_adaptive_threshold(const float init[7], float voxel_size) {        // :82-95, f32 like the reference
+    const float trans = std::sqrt(init[4] * init[4] + init[5] * init[5] + init[6] * init[6]);
+    const float imag = std::sqrt(init[0] * init[0] + init[1] * init[1] + init[2] * init[2]);
+    const float motion = trans + 2.0f * imag * voxel_size;
+    return std::fmin(std::fmax(3.0f * motion, 3.0f * voxel_size), 10.0f * voxel_size);
+}
+
+tc_status tc_kiss_icp_device(tc_context *ctx, const float *d_source, size_t ns, const float *d_target, size_t nt, const float init[7],
+                             const tc_kiss_icp_config *cfg, tc_icp_result *result, size_t *n_source_down) {
+    if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
+    if (n_source_down) *n_source_down = 0;
+    if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "KISS-ICP: source or target point cloud is empty");     // :189-193
+    if (cfg->max_iterations == 0) return fail(ctx, TC_INVALID_DATA, "KISS-ICP: max_iterations must be > 0");          // :194-198
+    if (!(cfg->voxel_size > 0.0f)) return fail(ctx, TC_INVALID_DATA, "KISS-ICP: voxel_size must be > 0");             // :199-203
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf ranged, down;
+    auto cleanup = [&]() { for (DevBuf *b : {&ranged, &down}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } };
+    tc_status st = TC_OK;
+    if ((st = ensure(ctx, ranged, ns * 12)) || (st = ensure(ctx, down, ns * 12))) { cleanup(); return st; }
+    size_t nr = 0, nd = 0;
+    if ((st = range_filter_device(ctx, d_source, ns, cfg->min_range, cfg->max_range, (float *)ranged.p, &nr))) { cleanup(); return st; }
+    if (nr == 0) { cleanup(); return fail(ctx, TC_INVALID_DATA, "KISS-ICP: no source points remain after range filtering"); }   // :207-213
+    if ((st = voxel_filter_device(ctx, (const float *)ranged.p, nr, cfg->voxel_size, (float *)down.p, &nd))) { cleanup(); return st; }
+    if (nd == 0) { cleanup(); return fail(ctx, TC_INVALID_DATA, "KISS-ICP: no source points remain after voxel downsampling"); }
+    if (n_source_down) *n_source_down = nd;
+    const float sigma = kiss_adaptive_threshold(init, cfg->voxel_size);
+    st = icp_run(ctx, false, (const float *)down.p, nd, d_target, nt, nullptr, 0, init, cfg->max_iterations, sigma, 1e-6f, result, true, 1);
+    cleanup();
+    return st;
+}
+
+tc_status tc_kiss_icp(tc_context *ctx, const float *source, size_t ns, const float *target, size_t nt, const float init[7],
+                      const tc_kiss_icp_config *cfg, tc_icp_result *result, size_t *n_source_down) {
+    if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
+    if (n_source_down) *n_source_down = 0;
+    if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "KISS-ICP: source or target point cloud is empty");
+    if (cfg->max_iterations == 0) return fail(ctx, TC_INVALID_DATA, "KISS-ICP: max_iterations must be > 0");
+    if (!(cfg->voxel_size > 0.0f)) return fail(ctx, TC_INVALID_DATA, "KISS-ICP: voxel_size must be > 0");
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = ensure(ctx, ctx->in_a, ns * 12)) return s;
+    if (tc_status s = ensure(ctx, ctx->in_b, nt * 12)) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, source, ns * 12, hipMemcpyHostToDevice, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_b.p, target, nt * 12, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *host_corr = result->corr_target;
+    DevBuf dcorr;
+    if (host_corr) {
+        if (tc_status s = ensure(ctx, dcorr, ns * 4)) return s;
+        result->corr_target = (uint32_t *)dcorr.p;
+    }
+    size_t nd = 0;
+    tc_status st = tc_kiss_icp_device(ctx, (const float *)ctx->in_a.p, ns, (const float *)ctx->in_b.p, nt, init, cfg, result, &nd);
+    result->corr_target = host_corr;
+    if (st == TC_OK && host_corr) (void)hipMemcpy(host_corr, dcorr.p, nd * 4, hipMemcpyDeviceToHost);
+    if (dcorr.p) (void)hipFree(dcorr.p);
+    if (n_source_down) *n_source_down = nd;
+    return st;
+}
+
 // ---- batch k-NN (nearest_neighbor.rs:177-251; gpu/nearest_neighbor.rs:332-355) ----------------
 tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, size_t k,
                         uint32_t *d_idx, float *d_dist, uint32_t *d_count) {

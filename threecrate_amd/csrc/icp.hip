@@ -1065,6 +1065,11 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
         const double ms[3] = {S[0] / cnt, S[1] / cnt, S[2] / cnt}, mq[3] = {S[3] / cnt, S[4] / cnt, S[5] / cnt};
         double H[3][3], R[3][3];
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] = S[6 + 3 * r + c] - cnt * ms[r] * mq[c];
+        if (st->kiss) {         // svd_transform: |H|_F < 1e-10 -> Algorithm (kiss_icp.rs:130-136)
+            double hn = 0.0;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) hn += H[r][c] * H[r][c];
+            if (sqrt(hn) < 1e-10) { st->status = TC_ALGORITHM; st->done = 1; return; }
+        }
         kabsch_rotation(H, R);
         const double cs[3] = {ms[0] + (double)g.cx, ms[1] + (double)g.cy, ms[2] + (double)g.cz};
         const double cq[3] = {mq[0] + (double)g.cx, mq[1] + (double)g.cy, mq[2] + (double)g.cz};
@@ -1073,7 +1078,17 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
         float dt[3];
         for (int r = 0; r < 3; ++r) dt[r] = (float)(cq[r] - (R[r][0] * cs[0] + R[r][1] * cs[1] + R[r][2] * cs[2]));
         compose(st, dq, dt);
-        finish_iteration(st, (float)(S[15] / cnt), (uint32_t)cnt);
+        double nmse = S[15];                               // sum |s - q|^2 before the update (registration.rs:214)
+        if (st->kiss) {
+            // KISS-ICP measures AFTER applying delta (kiss_icp.rs:270-276).  With the optimal translation the
+            // residual is R (s - c_s) - (q - c_q):  sum = sum|s-q|^2 - n |c_s - c_q|^2 + 2 tr H - 2 sum_ij R_ij H_ji
+            const double d0 = ms[0] - mq[0], d1 = ms[1] - mq[1], d2 = ms[2] - mq[2];
+            double rh = 0.0;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) rh += R[i][j] * H[j][i];
+            nmse = S[15] - cnt * (d0 * d0 + d1 * d1 + d2 * d2) + 2.0 * (H[0][0] + H[1][1] + H[2][2]) - 2.0 * rh;
+            nmse = fmax(nmse, 0.0);
+        }
+        finish_iteration(st, (float)(nmse / cnt), (uint32_t)cnt);
     }
 }
 
@@ -1089,7 +1104,7 @@ __global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restr
 __global__ void icp_finish_kernel(IcpState *__restrict__ st, const double *__restrict__ partials, uint32_t nblocks, int p2plane) {
     if (threadIdx.x != 0 || st->done) return;
     st->converged = 0;
-    if (p2plane) {
+    if (p2plane || st->kiss) {         // point-to-plane :595-601 and kiss_icp.rs:292-299 return the last measured mse
         st->mse = st->prev_mse;
     } else {
         double s = 0.0, c = 0.0;
@@ -1179,7 +1194,7 @@ struct IcpSetup {
 
 static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                            const float *d_nrm, size_t nstride, const float init[7], float max_dist, float conv_thr,
-                           IcpSetup &out) {
+                           IcpSetup &out, int kiss = 0) {
     // the search addresses target records by 32-bit byte offsets (16 B each)
     if (nt >= (1ull << 28)) return fail(ctx, TC_UNSUPPORTED, "ICP target clouds are limited to 2^28 - 1 points");
     if (tc_status s = build_index(ctx, ctx->tgt_index, d_tgt, nt, icp_cell_factor(), nullptr, nullptr, nullptr, 0.0f, 2.5f)) return s;
@@ -1193,6 +1208,7 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     hs->prev_mse = INFINITY;
     hs->conv_thr = conv_thr;
     hs->max_dist = max_dist;
+    hs->kiss = kiss;
     hs->status = TC_OK;
     TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, hs, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
     // order the source by the (tile-major) target cell of its initially transformed position
@@ -1208,9 +1224,9 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
 
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
-                  float conv_thr, tc_icp_result *res, bool corr_on_device) {
+                  float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss) {
     IcpSetup su;
-    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su)) return s;
+    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, kiss)) return s;
     hipStream_t st = ctx->stream;
     IcpState *dstate = (IcpState *)ctx->state.p;
     uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns;

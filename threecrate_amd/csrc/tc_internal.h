@@ -56,6 +56,7 @@ struct IcpState {
     uint32_t n_corr;        // valid pairs of the last executed iteration
     float    conv_thr;
     float    max_dist;      // < 0 : none
+    int32_t  kiss;          // KISS-ICP rules (kiss_icp.rs): mse after the update, |H| check, last mse when not converged
     uint32_t refine_total;  // statistics: queries served by the refine pass (sum / max over iterations)
     uint32_t refine_max;
     uint32_t refine_ring_hist[8];   // TC_REFINE_STATS builds only: exit ring of the refine queries
@@ -177,6 +178,7 @@ tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3],
 
 // voxel.hip
 tc_status voxel_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float voxel, float *d_out, size_t *n_out);
+tc_status range_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float min_range, float max_range, float *d_out, size_t *n_out);
 
 // normals.hip
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg,
@@ -188,6 +190,6 @@ tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_quer
 // icp.hip
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters,
-                  float max_dist, float conv_thr, tc_icp_result *res, bool corr_on_device);
+                  float max_dist, float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss = 0);
 
 }  // namespace tc

@@ -130,3 +130,48 @@ tc_status voxel_filter_device(tc_context *ctx, const float *d_xyz, size_t n, flo
 }
 
 }  // namespace tc
+
+
+// ---- range_filter (kiss_icp.rs:56-70): keep points with min_r^2 <= |p|^2 <= max_r^2, order preserved ----
+namespace tc {
+
+__global__ void __launch_bounds__(256) range_flag_kernel(const float *__restrict__ xyz, uint32_t n, float min_sq, float max_sq,
+                                                        uint32_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    const float r2 = x * x + y * y + z * z;                 // magnitude_squared, no FMA (-ffp-contract=off)
+    flag[i] = (r2 >= min_sq && r2 <= max_sq) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) range_compact_kernel(const float *__restrict__ xyz, uint32_t n, const uint32_t *__restrict__ flag,
+                                                           const uint32_t *__restrict__ off, float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const uint32_t o = off[i];
+    out[3 * (size_t)o] = xyz[3 * (size_t)i]; out[3 * (size_t)o + 1] = xyz[3 * (size_t)i + 1]; out[3 * (size_t)o + 2] = xyz[3 * (size_t)i + 2];
+}
+
+tc_status range_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float min_range, float max_range, float *d_out, size_t *n_out) {
+    *n_out = 0;
+    if (n == 0) return TC_OK;
+    if (n >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    DeviceIndex &ix = ctx->vox_index;
+    if (tc_status s = ensure(ctx, ix.fill, n * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, ix.cell_start, (n + 1) * sizeof(uint32_t))) return s;
+    hipStream_t st = ctx->stream;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    ProfScope ps(ctx, "range_filter");
+    hipLaunchKernelGGL(range_flag_kernel, dim3(nb), dim3(256), 0, st, d_xyz, (uint32_t)n, min_range * min_range, max_range * max_range,
+                       (uint32_t *)ix.fill.p);
+    if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, (uint32_t)n, (uint32_t *)ix.cell_start.p, ix.blocksum)) return s;
+    hipLaunchKernelGGL(range_compact_kernel, dim3(nb), dim3(256), 0, st, d_xyz, (uint32_t)n, (const uint32_t *)ix.fill.p,
+                       (const uint32_t *)ix.cell_start.p, d_out);
+    uint32_t *hcount = (uint32_t *)((char *)ctx->pinned + 1024);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(hcount, (const uint32_t *)ix.cell_start.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *n_out = *hcount;
+    return TC_OK;
+}
+
+}   // namespace tc
