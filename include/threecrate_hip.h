@@ -218,6 +218,23 @@ tc_status tc_multiscale_icp_point_to_point(tc_context *ctx, const float *source,
                           const float *target, size_t n_target, const float init[7],
                           const tc_multiscale_icp_config *config, tc_icp_result *result);
 
+/* ---- GICP ----
+ * gicp(source, target, init, GicpConfig) -> Result<ICPResult>  (threecrate-algorithms/src/gicp.rs:100-305; config
+ * :25-40, defaults 50 iterations, max distance 1.0, threshold 1e-6, k = 20): per-point covariances from the k
+ * nearest points (:52-86), per pair M = C_t + R C_s R^T, 6x6 Gauss-Newton system H dx = g, Cholesky then LU,
+ * update Rz Ry Rx + t, mse = mean squared correspondence distance before the update.  Clouds smaller than
+ * max(k, 4) points or with a bounding-box side < 1e-4 -> TC_INVALID_DATA; k > 65 -> TC_UNSUPPORTED. */
+typedef struct tc_gicp_config {
+    size_t max_iterations;
+    float  max_correspondence_distance;
+    float  convergence_threshold;
+    size_t k_correspondences;
+} tc_gicp_config;
+tc_status tc_gicp(tc_context *ctx, const float *source, size_t n_source, const float *target, size_t n_target,
+                  const float init[7], const tc_gicp_config *config, tc_icp_result *result);
+tc_status tc_gicp_device(tc_context *ctx, const float *d_source, size_t n_source, const float *d_target, size_t n_target,
+                         const float init[7], const tc_gicp_config *config, tc_icp_result *result);
+
 /* ---- KISS-ICP ----
  * kiss_icp(source, target, init, KissIcpConfig) -> Result<ICPResult>  (threecrate-algorithms/src/kiss_icp.rs:
  * 183-300; config :28-49, defaults voxel 1.0, max_range 100, min_range 0.5, 50 iterations): range filter

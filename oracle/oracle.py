@@ -66,6 +66,10 @@ def lib():
         L.tco_icp.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, f32p, C.c_size_t, f32p, C.c_int]
         L.tco_icp.restype = None
         L.tco_voxel_grid_filter.argtypes = [f32p, C.c_size_t, C.c_float, f32p, C.POINTER(C.c_size_t)]
+        L.tco_gicp_covariances.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_int]
+        L.tco_gicp_covariances.restype = None
+        L.tco_gicp.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, f32p, C.c_size_t, C.c_float, C.c_float, C.c_size_t,
+                               C.POINTER(_IcpResult), C.c_int]
         L.tco_kiss_adaptive_threshold.argtypes = [f32p, C.c_float]
         L.tco_kiss_adaptive_threshold.restype = C.c_float
         L.tco_kiss_icp.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, f32p, C.c_float, C.c_float, C.c_float, C.c_size_t,
@@ -232,6 +236,21 @@ def icp_point_to_plane_detailed(src, tgt, tgt_normals, init, max_iters, max_corr
 def icp_point_to_plane(src, tgt, tgt_normals, init, max_iters, threads=0):
     """registration.rs:488-496"""
     return icp_point_to_plane_detailed(src, tgt, tgt_normals, init, max_iters, None, 1e-6, threads)
+
+
+def gicp(src, tgt, init=None, max_iterations=50, max_correspondence_distance=1.0, convergence_threshold=1e-6,
+         k_correspondences=20, threads=0):
+    """gicp.rs:100-305 (GicpConfig defaults :31-40)"""
+    return _icp_common(lib().tco_gicp, src, tgt, (), init, max_iterations,
+                       (C.c_float(max_correspondence_distance), C.c_float(convergence_threshold), C.c_size_t(k_correspondences)), threads)
+
+
+def gicp_covariances(points, k=20, threads=0):
+    """compute_covariances (gicp.rs:52-86) -> (n, 3, 3) float32"""
+    pts = _f32(points, 3)
+    out = np.zeros((len(pts), 9), np.float32)
+    lib().tco_gicp_covariances(_p(pts), len(pts), k, _p(out), threads)
+    return out.reshape(-1, 3, 3)
 
 
 def kiss_icp(src, tgt, init=None, voxel_size=1.0, max_range=100.0, min_range=0.5, max_iterations=50, threads=0):

@@ -1510,3 +1510,177 @@ int tco_kiss_icp(const float *src, size_t ns, const float *tgt, size_t nt, const
     tco_kdtree_free(tree);
     return rc;
 }
+
+
+/* ---- GICP (threecrate-algorithms/src/gicp.rs) ------------------------------------------------
+ * compute_covariances :52-86 (k = max(k, 4) nearest INCLUDING the point itself, f32 mean / outer products
+ * in neighbour order, / max(n-1, 1), + 1e-4 I; fewer than 3 neighbours -> 1e-3 I), gicp :100-305
+ * (validation, M = C_t + R C_s R^T, nalgebra's closed-form 3x3 try_inverse, sequential f32 sums of the
+ * 6x6 H and g, mse = mean dist^2 before the update, Cholesky then LU, Rz Ry Rx update). */
+static void gicp_covariances(const float *xyz, size_t n, size_t k, float *cov /* n x 9 row-major */, int threads) {
+    if (k < 4) k = 4;
+    tco_kdtree *tree = tco_kdtree_new(xyz, n);
+    int nt = resolve_threads(threads);
+    (void)nt;
+#pragma omp parallel num_threads(nt)
+    {
+        kd_scratch s; scratch_init(&s);
+#pragma omp for schedule(dynamic, 256)
+        for (long long i = 0; i < (long long)n; ++i) {
+            float *c = &cov[9 * i];
+            size_t m = kd_knn_core(tree, &xyz[3 * i], k, &s);      /* ascending distance */
+            if (m < 3) { for (int e = 0; e < 9; ++e) c[e] = 0.0f; c[0] = c[4] = c[8] = 1.0f * 1e-3f; continue; }
+            float nf = (float)m;
+            float mean[3] = { 0, 0, 0 };
+            for (size_t j = 0; j < m; ++j) { const float *p = &xyz[3 * s.heap[j].idx]; mean[0] = mean[0] + p[0]; mean[1] = mean[1] + p[1]; mean[2] = mean[2] + p[2]; }
+            mean[0] /= nf; mean[1] /= nf; mean[2] /= nf;
+            float a[9] = { 0 };
+            for (size_t j = 0; j < m; ++j) {
+                const float *p = &xyz[3 * s.heap[j].idx];
+                float d[3] = { p[0] - mean[0], p[1] - mean[1], p[2] - mean[2] };
+                for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) a[3 * r + cc] += d[r] * d[cc];
+            }
+            float den = fmaxf(nf - 1.0f, 1.0f);
+            for (int e = 0; e < 9; ++e) c[e] = a[e] / den;
+            c[0] += 1e-4f; c[4] += 1e-4f; c[8] += 1e-4f;
+        }
+        scratch_free(&s);
+    }
+    tco_kdtree_free(tree);
+}
+
+void tco_gicp_covariances(const float *xyz, size_t n, size_t k, float *cov9, int threads) { gicp_covariances(xyz, n, k, cov9, threads); }
+
+/* nalgebra Matrix3::try_inverse (linalg/inverse.rs, 3x3 case): adjugate / determinant, 0 -> None */
+static int inv3(const float m[9], float o[9]) {
+    float m11 = m[0], m12 = m[1], m13 = m[2], m21 = m[3], m22 = m[4], m23 = m[5], m31 = m[6], m32 = m[7], m33 = m[8];
+    float minor_m12_m23 = m22 * m33 - m32 * m23;
+    float minor_m11_m23 = m21 * m33 - m31 * m23;
+    float minor_m11_m22 = m21 * m32 - m31 * m22;
+    float det = m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22;
+    if (det == 0.0f) return 0;
+    o[0] = minor_m12_m23 / det; o[1] = (m13 * m32 - m33 * m12) / det; o[2] = (m12 * m23 - m22 * m13) / det;
+    o[3] = -minor_m11_m23 / det; o[4] = (m11 * m33 - m31 * m13) / det; o[5] = (m13 * m21 - m23 * m11) / det;
+    o[6] = minor_m11_m22 / det; o[7] = (m12 * m31 - m32 * m11) / det; o[8] = (m11 * m22 - m21 * m12) / det;
+    return 1;
+}
+
+static void mat3_mul_flat(const float a[9], const float b[9], float c[9]) {
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+        float v = 0.0f;
+        for (int k = 0; k < 3; ++k) v += a[3 * r + k] * b[3 * k + cc];
+        c[3 * r + cc] = v;
+    }
+}
+
+int tco_gicp(const float *src, size_t ns, const float *tgt, size_t nt, const float init[7],
+             size_t max_iters, float max_dist, float conv_thr, size_t k_corr,
+             tco_icp_result *res, int threads) {
+    if (ns == 0 || nt == 0) return TCO_INVALID_DATA;                       /* :107-111 */
+    if (max_iters == 0) return TCO_INVALID_DATA;                           /* :112-116 */
+    size_t min_k = k_corr < 4 ? 4 : k_corr;
+    if (ns < min_k || nt < min_k) return TCO_INVALID_DATA;                 /* :120-131 */
+    const float *clouds[2] = { src, tgt }; size_t sizes[2] = { ns, nt };
+    for (int c = 0; c < 2; ++c) {                                           /* :135-155 */
+        float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (size_t i = 0; i < sizes[c]; ++i) for (int ax = 0; ax < 3; ++ax) {
+            mn[ax] = fminf(mn[ax], clouds[c][3 * i + ax]); mx[ax] = fmaxf(mx[ax], clouds[c][3 * i + ax]);
+        }
+        float me = INFINITY;
+        for (int ax = 0; ax < 3; ++ax) me = fminf(me, mx[ax] - mn[ax]);
+        if (me < 1e-4f) return TCO_INVALID_DATA;
+    }
+    float *cs = (float *)malloc(ns * 9 * sizeof(float)), *ct = (float *)malloc(nt * 9 * sizeof(float));
+    gicp_covariances(src, ns, k_corr, cs, threads);
+    gicp_covariances(tgt, nt, k_corr, ct, threads);
+    tco_kdtree *tree = tco_kdtree_new(tgt, nt);
+    float cur[7]; memcpy(cur, init, sizeof(cur));
+    float prev_mse = INFINITY;
+    float *ts = (float *)malloc(ns * 3 * sizeof(float));
+    uint64_t *ti = (uint64_t *)malloc(ns * sizeof(uint64_t));
+    float *td = (float *)malloc(ns * sizeof(float));
+    uint64_t *pcs = (uint64_t *)malloc(ns * sizeof(uint64_t)), *pct = (uint64_t *)malloc(ns * sizeof(uint64_t));
+    uint64_t *fcs = (uint64_t *)malloc(ns * sizeof(uint64_t)), *fct = (uint64_t *)malloc(ns * sizeof(uint64_t));
+    size_t nfinal = 0;
+    int rc = TCO_OK, done = 0;
+    for (size_t it = 0; it < max_iters; ++it) {
+        for (size_t j = 0; j < ns; ++j) tco_isometry_apply(cur, &src[3 * j], &ts[3 * j]);
+        float m16[16]; tco_isometry_to_matrix(cur, m16);
+        float R[9] = { m16[0], m16[1], m16[2], m16[4], m16[5], m16[6], m16[8], m16[9], m16[10] };
+        float Rt[9] = { R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8] };
+        /* 1-NN and its distance (parallel), then the sequential accumulation in source order */
+        int nthr = resolve_threads(threads);
+        (void)nthr;
+#pragma omp parallel num_threads(nthr)
+        {
+            kd_scratch s; scratch_init(&s);
+#pragma omp for schedule(dynamic, 512)
+            for (long long j = 0; j < (long long)ns; ++j) {
+                size_t m = kd_knn_core(tree, &ts[3 * j], 1, &s);
+                if (m == 0) { ti[j] = UINT64_MAX; continue; }
+                td[j] = sqrtf(s.heap[0].d);
+                ti[j] = (td[j] > max_dist) ? UINT64_MAX : s.heap[0].idx;     /* :211-213 */
+            }
+            scratch_free(&s);
+        }
+        float H[36]; float g[6];
+        memset(H, 0, sizeof(H)); memset(g, 0, sizeof(g));
+        size_t n_corr = 0; float mse_sum = 0.0f;
+        for (size_t j = 0; j < ns; ++j) {
+            if (ti[j] == UINT64_MAX) continue;
+            const float *p = &ts[3 * j];
+            float tmp[9], rcr[9], M[9], Mi[9];
+            mat3_mul_flat(R, &cs[9 * j], tmp); mat3_mul_flat(tmp, Rt, rcr);
+            for (int e = 0; e < 9; ++e) M[e] = ct[9 * ti[j] + e] + rcr[e];    /* :217 */
+            if (!inv3(M, Mi)) continue;                                       /* :218-221 */
+            float r[3] = { tgt[3 * ti[j]] - p[0], tgt[3 * ti[j] + 1] - p[1], tgt[3 * ti[j] + 2] - p[2] };
+            /* a = -skew(ts) */
+            float a[9] = { -0.0f, p[2], -p[1], -p[2], -0.0f, p[0], p[1], -p[0], -0.0f };
+            float at[9] = { a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8] };
+            float mia[9], hrr[9], hrt[9];
+            mat3_mul_flat(Mi, a, mia); mat3_mul_flat(at, mia, hrr); mat3_mul_flat(at, Mi, hrt);
+            float wr[3], gr[3];
+            for (int i = 0; i < 3; ++i) { float v = 0.0f; for (int k = 0; k < 3; ++k) v += Mi[3 * i + k] * r[k]; wr[i] = v; }
+            for (int i = 0; i < 3; ++i) { float v = 0.0f; for (int k = 0; k < 3; ++k) v += at[3 * i + k] * wr[k]; gr[i] = v; }
+            for (int i = 0; i < 3; ++i) {
+                for (int jj = 0; jj < 3; ++jj) {
+                    H[6 * i + jj] += hrr[3 * i + jj];
+                    H[6 * i + jj + 3] += hrt[3 * i + jj];
+                    H[6 * (i + 3) + jj] += hrt[3 * jj + i];
+                    H[6 * (i + 3) + jj + 3] += Mi[3 * i + jj];
+                }
+                g[i] += gr[i];
+                g[i + 3] += wr[i];
+            }
+            pcs[n_corr] = j; pct[n_corr] = ti[j];
+            n_corr += 1;
+            mse_sum += td[j] * td[j];
+        }
+        if (n_corr < 6) { rc = TCO_ALGORITHM; break; }                        /* :253-257 */
+        float mse = mse_sum / (float)n_corr;
+        float x[6];
+        if (!tco_cholesky6_solve(H, g, x)) { if (!tco_lu6_solve(H, g, x)) { rc = TCO_ALGORITHM; break; } }
+        float hx = x[0] / 2.0f, hy = x[1] / 2.0f, hz = x[2] / 2.0f;
+        float qx[4] = { 1.0f * sinf(hx), 0.0f * sinf(hx), 0.0f * sinf(hx), cosf(hx) };
+        float qy[4] = { 0.0f * sinf(hy), 1.0f * sinf(hy), 0.0f * sinf(hy), cosf(hy) };
+        float qz[4] = { 0.0f * sinf(hz), 0.0f * sinf(hz), 1.0f * sinf(hz), cosf(hz) };
+        float zy[4], rot[4], delta[7], nxt[7];
+        quat_mul(qz, qy, zy); quat_mul(zy, qx, rot);
+        delta[0] = rot[0]; delta[1] = rot[1]; delta[2] = rot[2]; delta[3] = rot[3]; delta[4] = x[3]; delta[5] = x[4]; delta[6] = x[5];
+        tco_isometry_mul(delta, cur, nxt); memcpy(cur, nxt, sizeof(cur));
+        if (fabsf(prev_mse - mse) < conv_thr) {                               /* :284-292 */
+            memcpy(res->transform, cur, sizeof(cur)); res->mse = mse; res->iterations = it + 1; res->converged = 1;
+            result_store_corr(res, pcs, pct, n_corr);
+            done = 1; break;
+        }
+        prev_mse = mse;
+        uint64_t *t1 = fcs; fcs = pcs; pcs = t1; t1 = fct; fct = pct; pct = t1; nfinal = n_corr;
+    }
+    if (rc == TCO_OK && !done) {
+        memcpy(res->transform, cur, sizeof(cur)); res->mse = prev_mse; res->iterations = max_iters; res->converged = 0;
+        result_store_corr(res, fcs, fct, nfinal);
+    }
+    free(cs); free(ct); free(ts); free(ti); free(td); free(pcs); free(pct); free(fcs); free(fct);
+    tco_kdtree_free(tree);
+    return rc;
+}

@@ -127,4 +127,10 @@ int tco_kiss_icp(const float *src, size_t ns, const float *tgt, size_t nt, const
                  float voxel_size, float max_range, float min_range, size_t max_iters,
                  tco_icp_result *res, size_t *n_source_down, int threads);
 
+/* GICP (threecrate-algorithms/src/gicp.rs:100-305); cov9 = n x 9 row-major 3x3 covariances (:52-86) */
+void tco_gicp_covariances(const float *xyz, size_t n, size_t k, float *cov9, int threads);
+int tco_gicp(const float *src, size_t ns, const float *tgt, size_t nt, const float init[7],
+             size_t max_iters, float max_dist, float conv_thr, size_t k_corr,
+             tco_icp_result *res, int threads);
+
 #endif

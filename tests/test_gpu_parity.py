@@ -5,6 +5,7 @@ ICP transform within 1e-5 Frobenius (4x4 homogeneous matrix).
 """
 import numpy as np
 import pytest
+import torch
 
 import threecrate_amd as tc
 
@@ -427,3 +428,41 @@ def test_kiss_icp_matches_oracle(ctx):
         ctx.kiss_icp(cur, f, None, tc.KissIcpConfig(max_iterations=0))
     with pytest.raises(tc.InvalidData):
         ctx.kiss_icp(cur, f, None, tc.KissIcpConfig(voxel_size=0.5, min_range=500.0, max_range=600.0))   # nothing in range
+
+
+def test_gicp_matches_oracle(ctx):
+    """gicp (gicp.rs:100-305): per-point covariances from k nearest points, M = C_t + R C_s R^T weighting,
+    6x6 Gauss-Newton steps.  Uniform cloud, LiDAR-shaped frame pair, a run that does not converge, and
+    the reference's error cases."""
+    src, tgt, T = synth.registration_pair(20000, seed=1)
+    g = ctx.gicp(src, tgt, None, tc.GicpConfig(30, 1.0, 1e-6, 20))
+    r = O.gicp(src, tgt, None, 30, 1.0, 1e-6, 20)
+    assert g.iterations == r.iterations and g.converged == r.converged
+    assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= 1e-5
+    assert np.array_equal(g.correspondences, r.correspondences)
+    # 120k-point LiDAR-shaped frames (surface covariances are strongly anisotropic), ego motion 0.3 m + 0.3 deg
+    f = synth.kitti_shaped_cloud(seed=2)
+    cur = synth.apply_isometry(synth.yaw_isometry((-0.3, 0.0, 0.0), -np.deg2rad(0.3)), f)
+    g2 = ctx.gicp(cur, f, None, tc.GicpConfig(12, 1.0, 0.0, 20))           # threshold 0: exactly 12 iterations
+    r2 = O.gicp(cur, f, None, 12, 1.0, 0.0, 20)
+    assert g2.iterations == r2.iterations == 12 and not g2.converged and not r2.converged
+    assert frob(g2.transformation, r2.transformation, O.isometry_to_matrix) <= 1e-4
+    assert abs(g2.mse - r2.mse) <= 1e-3 * max(r2.mse, 1e-9)
+    assert len(g2.correspondences) == len(r2.correspondences)
+    assert (g2.correspondences != r2.correspondences).any(axis=1).mean() < 1e-3
+    # device-resident inputs: same answer
+    gd = ctx.gicp(torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), None, tc.GicpConfig(30, 1.0, 1e-6, 20))
+    assert np.array_equal(gd.transformation, g.transformation) and gd.iterations == g.iterations
+    # error behaviour (gicp.rs:107-155, 253-257)
+    with pytest.raises(tc.InvalidData):
+        ctx.gicp(src[:0], tgt, None)
+    with pytest.raises(tc.InvalidData):
+        ctx.gicp(src, tgt, None, tc.GicpConfig(max_iterations=0))
+    with pytest.raises(tc.InvalidData):
+        ctx.gicp(src[:10], tgt, None, tc.GicpConfig(k_correspondences=20))     # fewer points than k
+    flat = src.copy(); flat[:, 2] = 0.25
+    with pytest.raises(tc.InvalidData):
+        ctx.gicp(flat, tgt, None)                                               # coplanar source
+    far = src + np.float32(50.0)
+    with pytest.raises(tc.AlgorithmError):
+        ctx.gicp(far, tgt, None, tc.GicpConfig(5, 0.5, 1e-6, 20))               # no correspondence within 0.5

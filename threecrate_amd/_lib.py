@@ -45,6 +45,11 @@ class MultiScaleConfigC(C.Structure):
                 ("final_max_correspondence_distance", C.c_float), ("convergence_threshold", C.c_float)]
 
 
+class GicpConfigC(C.Structure):
+    _fields_ = [("max_iterations", C.c_size_t), ("max_correspondence_distance", C.c_float), ("convergence_threshold", C.c_float),
+                ("k_correspondences", C.c_size_t)]
+
+
 class KissIcpConfigC(C.Structure):
     _fields_ = [("voxel_size", C.c_float), ("max_range", C.c_float), ("min_range", C.c_float), ("max_iterations", C.c_size_t)]
 
@@ -78,7 +83,7 @@ EXPORTS = [
     "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
     "tc_icp_shard_reduce", "tc_icp_shard_get_sums", "tc_icp_shard_set_sums", "tc_icp_shard_done",
     "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
-    "tc_multiscale_icp_point_to_point", "tc_kiss_icp", "tc_kiss_icp_device", "tc_knn", "tc_knn_device", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device",
+    "tc_multiscale_icp_point_to_point", "tc_gicp", "tc_gicp_device", "tc_kiss_icp", "tc_kiss_icp_device", "tc_knn", "tc_knn_device", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device",
     "tc_frame_stream_create", "tc_frame_stream_send", "tc_frame_stream_try_send", "tc_frame_stream_finish",
     "tc_frame_stream_destroy", "tc_read_kitti_bin", "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
 ]
@@ -151,6 +156,8 @@ def load():
     L.tc_icp_shard_destroy.argtypes = [vp]
     L.tc_icp_shard_destroy.restype = None
     L.tc_multiscale_icp_point_to_point.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(MultiScaleConfigC), resp]
+    L.tc_gicp.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(GicpConfigC), resp]
+    L.tc_gicp_device.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(GicpConfigC), resp]
     L.tc_kiss_icp.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(KissIcpConfigC), resp, C.POINTER(C.c_size_t)]
     L.tc_kiss_icp_device.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(KissIcpConfigC), resp, C.POINTER(C.c_size_t)]
     L.tc_knn.argtypes = [vp, f32p, sz, f32p, sz, sz, vp, vp, vp]

@@ -74,6 +74,15 @@ class MultiScaleIcpConfig:
 
 
 @dataclass
+class GicpConfig:
+    """gicp.rs:25-40"""
+    max_iterations: int = 50
+    max_correspondence_distance: float = 1.0
+    convergence_threshold: float = 1e-6
+    k_correspondences: int = 20
+
+
+@dataclass
 class KissIcpConfig:
     """kiss_icp.rs:28-49"""
     voxel_size: float = 1.0
@@ -279,6 +288,28 @@ class GpuContext:
         self._check(fn(self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], i7.ctypes.data, max_iters, a, b, C.byref(r)))
         return self._result(r, s.shape[0], None if corr is None else corr[: s.shape[0]], correspondences)
 
+    def gicp(self, source, target, init=None, config: "GicpConfig" = None, correspondences=True):
+        """gicp.rs:100-305"""
+        cfg = config or GicpConfig()
+        c = _lib.GicpConfigC(cfg.max_iterations, cfg.max_correspondence_distance, cfg.convergence_threshold, cfg.k_correspondences)
+        i7 = np.ascontiguousarray(IDENTITY if init is None else np.asarray(init, np.float32).reshape(7))
+        r = _lib.IcpResultC()
+        if _is_torch(source):
+            import torch
+            s = source.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            t = target.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
+            r.corr_target = corr.data_ptr() if corr is not None else None
+            self._check(self._L.tc_gicp_device(self._h, s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], i7.ctypes.data, C.byref(c), C.byref(r)))
+            if corr is not None:
+                corr = corr[: s.shape[0]].to(torch.int64) & 0xFFFFFFFF
+            return self._result(r, s.shape[0], corr, correspondences)
+        s, t = _as_host(source), _as_host(target)
+        corr = np.empty(max(1, s.shape[0]), np.uint32) if correspondences else None
+        r.corr_target = corr.ctypes.data if corr is not None else None
+        self._check(self._L.tc_gicp(self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], i7.ctypes.data, C.byref(c), C.byref(r)))
+        return self._result(r, s.shape[0], None if corr is None else corr[: s.shape[0]], correspondences)
+
     def kiss_icp(self, source, target, init=None, config: "KissIcpConfig" = None, correspondences=True):
         """kiss_icp.rs:183-300.  `correspondences` pairs (index into the voxel-downsampled source, target index)."""
         cfg = config or KissIcpConfig()
@@ -428,6 +459,11 @@ def icp_point_to_point(source, target, init, max_iterations, convergence_thresho
                        max_correspondence_distance=None, ctx=None):
     return (ctx or default_context()).icp_point_to_point(source, target, init, max_iterations, convergence_threshold,
                                                          max_correspondence_distance)
+
+
+def gicp(source, target, init, config=None, ctx=None):
+    """gicp.rs:100-105"""
+    return (ctx or default_context()).gicp(source, target, init, config)
 
 
 def kiss_icp(source, target, init, config=None, ctx=None):

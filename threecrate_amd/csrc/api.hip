@@ -144,7 +144,7 @@ void tc_context_destroy(tc_context *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     free_index(ctx->tgt_index); free_index(ctx->src_index); free_index(ctx->vox_index);
     free_buf(ctx->in_a); free_buf(ctx->in_b); free_buf(ctx->in_c); free_buf(ctx->out_a); free_buf(ctx->bbox);
-    free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->overflow);
+    free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->gicp_src_cov); free_buf(ctx->overflow);
     for (auto &t : ctx->timers) for (auto &p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -432,6 +432,104 @@ tc_status tc_kiss_icp(tc_context *ctx, const float *source, size_t ns, const flo
     if (st == TC_OK && host_corr) (void)hipMemcpy(host_corr, dcorr.p, nd * 4, hipMemcpyDeviceToHost);
     if (dcorr.p) (void)hipFree(dcorr.p);
     if (n_source_down) *n_source_down = nd;
+    return st;
+}
+
+// ---- GICP (gicp.rs:100-305) ----------------------------------------------------------------------
+// compute_covariances (gicp.rs:52-86): the k nearest points INCLUDING the point itself (ascending distance),
+// f32 mean and outer products in that order, / max(n - 1, 1), + 1e-4 I; fewer than 3 neighbours -> 1e-3 I.
+// out: two float4 per point (xx, xy, xz, yy), (yz, zz, 0, 0), original order.
+__global__ void __launch_bounds__(256) gicp_cov_kernel(const float *__restrict__ xyz, uint32_t n, const uint32_t *__restrict__ idx,
+                                                      const uint32_t *__restrict__ count, uint32_t k, float4 *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = count[i];
+    if (m < 3) {
+        out[2 * (size_t)i] = make_float4(1e-3f, 0.f, 0.f, 1e-3f);
+        out[2 * (size_t)i + 1] = make_float4(0.f, 1e-3f, 0.f, 0.f);
+        return;
+    }
+    const uint32_t *nb = idx + (size_t)i * k;
+    const float nf = (float)m;
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    for (uint32_t j = 0; j < m; ++j) { const uint32_t q = nb[j]; mx = mx + xyz[3 * (size_t)q]; my = my + xyz[3 * (size_t)q + 1]; mz = mz + xyz[3 * (size_t)q + 2]; }
+    mx /= nf; my /= nf; mz /= nf;
+    float xx = 0.f, xy = 0.f, xz = 0.f, yy = 0.f, yz = 0.f, zz = 0.f;
+    for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t q = nb[j];
+        const float dx = xyz[3 * (size_t)q] - mx, dy = xyz[3 * (size_t)q + 1] - my, dz = xyz[3 * (size_t)q + 2] - mz;
+        xx += dx * dx; xy += dx * dy; xz += dx * dz; yy += dy * dy; yz += dy * dz; zz += dz * dz;
+    }
+    const float den = fmaxf(nf - 1.0f, 1.0f);
+    out[2 * (size_t)i] = make_float4(xx / den + 1e-4f, xy / den, xz / den, yy / den + 1e-4f);
+    out[2 * (size_t)i + 1] = make_float4(yz / den, zz / den + 1e-4f, 0.f, 0.f);
+}
+
+static tc_status gicp_covariances_device(tc_context *ctx, const float *d_xyz, size_t n, size_t k, DevBuf &idx, DevBuf &dist, DevBuf &cnt,
+                                         float *d_cov8) {
+    k = std::max<size_t>(k, 4);
+    if (k > 65) return fail(ctx, TC_UNSUPPORTED, "GICP: k_correspondences > 65 is not supported by this backend");
+    if (tc_status s = ensure(ctx, idx, n * k * sizeof(uint32_t))) return s;
+    if (tc_status s = ensure(ctx, dist, n * k * sizeof(float))) return s;
+    if (tc_status s = ensure(ctx, cnt, n * sizeof(uint32_t))) return s;
+    // same grid as tc_knn (the point itself is one of its k nearest)
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(k > 1 ? k - 1 : 1) * 2.0f, nullptr, nullptr)) return s;
+    if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_xyz, n, k, (uint32_t *)idx.p, (float *)dist.p, (uint32_t *)cnt.p)) return s;
+    ProfScope ps(ctx, "gicp_covariances");
+    hipLaunchKernelGGL(gicp_cov_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, (const uint32_t *)idx.p,
+                       (const uint32_t *)cnt.p, (uint32_t)k, (float4 *)d_cov8);
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
+tc_status tc_gicp_device(tc_context *ctx, const float *d_source, size_t ns, const float *d_target, size_t nt, const float init[7],
+                         const tc_gicp_config *cfg, tc_icp_result *result) {
+    if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
+    if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "GICP: source or target point cloud is empty");           // :107-111
+    if (cfg->max_iterations == 0) return fail(ctx, TC_INVALID_DATA, "GICP: max_iterations must be > 0");                // :112-116
+    const size_t min_k = std::max<size_t>(cfg->k_correspondences, 4);
+    if (ns < min_k || nt < min_k) return fail(ctx, TC_INVALID_DATA, "GICP: clouds must have at least k_correspondences points");   // :120-131
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const float *clouds[2] = {d_source, d_target};
+    const size_t sizes[2] = {ns, nt};
+    for (int c = 0; c < 2; ++c) {                                                                                       // :135-155
+        float mn[3], mx[3];
+        if (tc_status s = cloud_bbox(ctx, clouds[c], sizes[c], mn, mx)) return s;
+        const float me = std::fmin(std::fmin(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+        if (me < 1e-4f) return fail(ctx, TC_INVALID_DATA, "GICP: point cloud appears to be coplanar or collinear; GICP requires 3-D structure");
+    }
+    DevBuf idx, dist, cnt, cov_s, cov_t;
+    auto cleanup = [&]() { for (DevBuf *b : {&idx, &dist, &cnt, &cov_s, &cov_t}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } };
+    tc_status st = TC_OK;
+    if ((st = ensure(ctx, cov_s, ns * 8 * sizeof(float))) || (st = ensure(ctx, cov_t, nt * 8 * sizeof(float))) ||
+        (st = gicp_covariances_device(ctx, d_source, ns, cfg->k_correspondences, idx, dist, cnt, (float *)cov_s.p)) ||
+        (st = gicp_covariances_device(ctx, d_target, nt, cfg->k_correspondences, idx, dist, cnt, (float *)cov_t.p))) { cleanup(); return st; }
+    st = icp_run_gicp(ctx, d_source, ns, d_target, nt, (const float *)cov_s.p, (const float *)cov_t.p, init, cfg->max_iterations,
+                      cfg->max_correspondence_distance, cfg->convergence_threshold, result, true);
+    cleanup();
+    return st;
+}
+
+tc_status tc_gicp(tc_context *ctx, const float *source, size_t ns, const float *target, size_t nt, const float init[7],
+                  const tc_gicp_config *cfg, tc_icp_result *result) {
+    if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
+    if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "GICP: source or target point cloud is empty");
+    if (cfg->max_iterations == 0) return fail(ctx, TC_INVALID_DATA, "GICP: max_iterations must be > 0");
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = ensure(ctx, ctx->in_a, ns * 12)) return s;
+    if (tc_status s = ensure(ctx, ctx->in_b, nt * 12)) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, source, ns * 12, hipMemcpyHostToDevice, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_b.p, target, nt * 12, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *host_corr = result->corr_target;
+    DevBuf dcorr;
+    if (host_corr) {
+        if (tc_status s = ensure(ctx, dcorr, ns * 4)) return s;
+        result->corr_target = (uint32_t *)dcorr.p;
+    }
+    tc_status st = tc_gicp_device(ctx, (const float *)ctx->in_a.p, ns, (const float *)ctx->in_b.p, nt, init, cfg, result);
+    result->corr_target = host_corr;
+    if (st == TC_OK && host_corr) (void)hipMemcpy(host_corr, dcorr.p, ns * 4, hipMemcpyDeviceToHost);
+    if (dcorr.p) (void)hipFree(dcorr.p);
     return st;
 }
 

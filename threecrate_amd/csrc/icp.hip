@@ -368,6 +368,86 @@ __device__ __forceinline__ void accumulate_pair(const GridGeom &g, float (&acc)[
     }
 }
 
+// ---- GICP pair terms (gicp.rs:205-251), f32 and in the reference's operation order ----------------
+// rotation matrix of a unit quaternion (nalgebra UnitQuaternion::to_rotation_matrix)
+__device__ __forceinline__ void quat_to_rot(const float q[4], float R[9]) {
+    const float i = q[0], j = q[1], k = q[2], w = q[3];
+    const float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+    const float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f, ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
+    R[0] = ww + ii - jj - kk; R[1] = ij - wk; R[2] = wj + ik;
+    R[3] = wk + ij; R[4] = ww - ii + jj - kk; R[5] = jk - wi;
+    R[6] = ik - wj; R[7] = wi + jk; R[8] = ww - ii - jj + kk;
+}
+
+__device__ __forceinline__ void mat3_mul_f(const float a[9], const float b[9], float c[9]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) c[3 * r + cc] = (a[3 * r] * b[cc] + a[3 * r + 1] * b[3 + cc]) + a[3 * r + 2] * b[6 + cc];
+}
+
+// covariances are stored as two float4 per point: (xx, xy, xz, yy), (yz, zz, -, -)
+__device__ __forceinline__ void cov_unpack(const float4 &a, const float4 &b, float c[9]) {
+    c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.y; c[4] = a.w; c[5] = b.x; c[6] = a.z; c[7] = b.x; c[8] = b.y;
+}
+
+// acc layout = the 29 words the point-to-plane finalize step reads: lower triangle of H by columns
+// (entry (row c, col r), r <= c, at the slot of the upper-triangle walk r, c), g, sum dist^2, count
+__device__ __forceinline__ void accumulate_gicp(float (&acc)[TC_ICP_SUMS_P2PLANE], float x, float y, float z, const float4 &c, float d2,
+                                                const float R[9], const float4 &cs0, const float4 &cs1, const float4 &ct0, const float4 &ct1) {
+    float Cs[9], Ct[9], Rt[9], tmp[9], rcr[9], M[9], Mi[9];
+    cov_unpack(cs0, cs1, Cs);
+    cov_unpack(ct0, ct1, Ct);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) Rt[3 * r + cc] = R[3 * cc + r];
+    mat3_mul_f(R, Cs, tmp);
+    mat3_mul_f(tmp, Rt, rcr);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) M[e] = Ct[e] + rcr[e];                            // :217
+    // nalgebra Matrix3::try_inverse: adjugate / determinant; a zero determinant skips the pair (:218-221)
+    const float m11 = M[0], m12 = M[1], m13 = M[2], m21 = M[3], m22 = M[4], m23 = M[5], m31 = M[6], m32 = M[7], m33 = M[8];
+    const float mi_a = m22 * m33 - m32 * m23, mi_b = m21 * m33 - m31 * m23, mi_c = m21 * m32 - m31 * m22;
+    const float det = (m11 * mi_a - m12 * mi_b) + m13 * mi_c;
+    if (det == 0.0f) return;
+    Mi[0] = mi_a / det; Mi[1] = (m13 * m32 - m33 * m12) / det; Mi[2] = (m12 * m23 - m22 * m13) / det;
+    Mi[3] = -mi_b / det; Mi[4] = (m11 * m33 - m31 * m13) / det; Mi[5] = (m13 * m21 - m23 * m11) / det;
+    Mi[6] = mi_c / det; Mi[7] = (m12 * m31 - m32 * m11) / det; Mi[8] = (m11 * m22 - m21 * m12) / det;
+    const float r[3] = {c.x - x, c.y - y, c.z - z};                                // residual t - T s
+    const float a[9] = {-0.0f, z, -y, -z, -0.0f, x, y, -x, -0.0f};                 // A = -skew(T s)
+    float at[9], mia[9], hrr[9], hrt[9];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) at[3 * rr + cc] = a[3 * cc + rr];
+    mat3_mul_f(Mi, a, mia);
+    mat3_mul_f(at, mia, hrr);
+    mat3_mul_f(at, Mi, hrt);
+    float wr[3], gr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wr[i] = (Mi[3 * i] * r[0] + Mi[3 * i + 1] * r[1]) + Mi[3 * i + 2] * r[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gr[i] = (at[3 * i] * wr[0] + at[3 * i + 1] * wr[1]) + at[3 * i + 2] * wr[2];
+    int o = 0;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int cc = rr; cc < 6; ++cc) {           // lower-triangle entry (row cc, column rr) of the reference's H
+            float v;
+            if (cc < 3) v = hrr[3 * cc + rr];
+            else if (rr < 3) v = hrt[3 * rr + (cc - 3)];
+            else v = Mi[3 * (cc - 3) + (rr - 3)];
+            acc[o] += v;
+            ++o;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc[21 + i] += gr[i]; acc[24 + i] += wr[i]; }
+    const float dist = sqrtf(d2);
+    acc[27] += dist * dist;                                                        // :250
+    acc[28] += 1.0f;
+}
+
 // Main pass: ring-1 search (warm-start pruned).  Lanes whose ring-1 answer is not provably exact
 // (Poisson tail, queries outside the target's box) are NOT finished here: they go to a list served
 // by icp_refine_kernel in dense waves.
@@ -381,12 +461,15 @@ __device__ __forceinline__ void accumulate_pair(const GridGeom &g, float (&acc)[
 constexpr int kIcpGroup = 4;
 constexpr int kRefineBlocks = 256;          // blocks of the refine pass = rows handed to the finalize step
 
-template <bool P2PLANE>
+// MODE: 0 point-to-point, 1 point-to-plane (tgt_nrm = target normals in cell order), 2 GICP (tgt_nrm = target
+// covariances, two float4 per cell-sorted position; src_cov = source covariances in the source's sorted order)
+template <int MODE>
 __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
-    double *__restrict__ partials, int dbg) {
-    constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
+    double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov) {
+    constexpr bool P2PLANE = MODE == 1;
+    constexpr int NACC = MODE == 0 ? TC_ICP_SUMS_P2P : TC_ICP_SUMS_P2PLANE;
     if (st->done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
     __shared__ uint2 spans[kSpanRows][kIcpBlock];
@@ -472,11 +555,18 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
             const float4 sv = src[j];
             const uint32_t pj = corr_pos[j];                 // this lane's own store of phase S
             const float4 cv = tgt.pts[pj];
-            float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (P2PLANE) nv = tgt_nrm[pj];
             float x, y, z;
             iso_apply(q, t, sv.x, sv.y, sv.z, x, y, z);
-            accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, cv, nv);
+            if constexpr (MODE == 2) {
+                float R[9];
+                quat_to_rot(q, R);
+                accumulate_gicp(acc, x, y, z, cv, d2_nc(cv.x, cv.y, cv.z, x, y, z), R, src_cov[2 * (size_t)j], src_cov[2 * (size_t)j + 1],
+                                tgt_nrm[2 * (size_t)pj], tgt_nrm[2 * (size_t)pj + 1]);
+            } else {
+                float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (P2PLANE) nv = tgt_nrm[pj];
+                accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, cv, nv);
+            }
         }
         // per-group fold: DPP wave sum (f32, fixed tree) -> this wave's f64 row
 #pragma unroll
@@ -607,16 +697,18 @@ __device__ __forceinline__ unsigned long long refine_shell(const GridView &tgt, 
     return group_min_u64(lk);
 }
 
-template <bool P2PLANE>
+template <int MODE>
 __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
                               int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE]);
 
-template <bool P2PLANE>
+template <int MODE>
 __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src,
     IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
-    const double *__restrict__ main_rows, uint32_t n_main_rows, uint32_t seg_stride, double *__restrict__ partial_rows) {
-    constexpr int NACC = P2PLANE ? TC_ICP_SUMS_P2PLANE : TC_ICP_SUMS_P2P;
+    const double *__restrict__ main_rows, uint32_t n_main_rows, uint32_t seg_stride, double *__restrict__ partial_rows,
+    const float4 *__restrict__ src_cov) {
+    constexpr bool P2PLANE = MODE == 1;
+    constexpr int NACC = MODE == 0 ? TC_ICP_SUMS_P2P : TC_ICP_SUMS_P2PLANE;
     if (st->done) return;
     __shared__ float lacc[kRefineThreads / kRG][TC_ICP_SUMS_STRIDE];
     // every refine block also folds its share of the main pass's per-block rows (written by the
@@ -736,12 +828,19 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
             corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
             if (valid) {
                 const float4 c = tgt.pts[bestg];
-                float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (P2PLANE) n = tgt_nrm[bestg];
                 float a[NACC];
 #pragma unroll
                 for (int k = 0; k < NACC; ++k) a[k] = acc[k];
-                accumulate_pair<P2PLANE, NACC>(g, a, x, y, z, c, n);
+                if constexpr (MODE == 2) {
+                    float R[9];
+                    quat_to_rot(q, R);
+                    accumulate_gicp(a, x, y, z, c, best, R, src_cov[2 * (size_t)j], src_cov[2 * (size_t)j + 1], tgt_nrm[2 * (size_t)bestg],
+                                    tgt_nrm[2 * (size_t)bestg + 1]);
+                } else {
+                    float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (P2PLANE) n = tgt_nrm[bestg];
+                    accumulate_pair<P2PLANE, NACC>(g, a, x, y, z, c, n);
+                }
 #pragma unroll
                 for (int k = 0; k < NACC; ++k) acc[k] = a[k];
             }
@@ -986,9 +1085,10 @@ __device__ void finish_iteration(IcpState *st, float mse, uint32_t n) {
 }
 
 // the first 256 threads of the calling block: fixed-order sum of the rows, solve, compose, bookkeeping
-template <bool P2PLANE>
+template <int MODE>
 __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
                               int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE]) {
+    constexpr bool P2PLANE = MODE != 0;        // GICP solves the same 6x6 system from the same 29 words (gicp.rs:258-281)
     if (do_sum) {
         // 8 row groups x 32 columns (threads 0..255; a larger block's other threads only take part in
         // the barriers); every group folds its rows in a fixed order with 4 independent loads in
@@ -1092,12 +1192,12 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
     }
 }
 
-template <bool P2PLANE>
+template <int MODE>
 __global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
                                                            IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply) {
     if (st->done) return;
     __shared__ double sm[8][TC_ICP_SUMS_STRIDE];
-    finalize_body<P2PLANE>(partials, nblocks, st, g, do_sum, do_apply, sm);
+    finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm);
 }
 
 // after the last iteration: not-converged epilogue (registration.rs:343-369 / :595-601)
@@ -1148,39 +1248,29 @@ static TileGeom plan_tiles(const GridGeom &g, size_t ns) {
     return make_tiles(g, cand[best][0], cand[best][1], cand[best][2]);
 }
 
-static void launch_iteration(tc_context *ctx, bool p2plane, const GridView &tv, const float4 *nrm, const float4 *src,
+// mode: 0 point-to-point, 1 point-to-plane (nrm = target normals), 2 GICP (nrm = target covariances, src_cov)
+static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, const float4 *nrm, const float4 *src,
                              uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr_pos, uint32_t *rlist,
-                             double *partials, bool do_sum, bool do_apply, bool do_reduce) {
+                             double *partials, bool do_sum, bool do_apply, bool do_reduce, const float4 *src_cov = nullptr) {
     hipStream_t s = ctx->stream;
     static const int dbg = getenv("TC_DEBUG") ? atoi(getenv("TC_DEBUG")) : 0;
     double *refine_rows = partials + (size_t)l.nblocks * TC_ICP_SUMS_STRIDE;
     if (do_reduce) {
         {
-            ProfScope ps(ctx, p2plane ? "icp_correspond_reduce_p2plane" : "icp_correspond_reduce_p2p", true);
-            if (p2plane)
-                hipLaunchKernelGGL(icp_correspond_reduce_kernel<true>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st,
-                                   corr_pos, rlist, partials, dbg);
-            else
-                hipLaunchKernelGGL(icp_correspond_reduce_kernel<false>, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st,
-                                   corr_pos, rlist, partials, dbg);
+            ProfScope ps(ctx, mode == 1 ? "icp_correspond_reduce_p2plane" : mode == 2 ? "icp_correspond_reduce_gicp" : "icp_correspond_reduce_p2p", true);
+            auto kern = mode == 1 ? icp_correspond_reduce_kernel<1> : mode == 2 ? icp_correspond_reduce_kernel<2> : icp_correspond_reduce_kernel<0>;
+            hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st, corr_pos, rlist, partials, dbg, src_cov);
         }
         ProfScope ps(ctx, "icp_refine");
-        if (p2plane)
-            hipLaunchKernelGGL(icp_refine_kernel<true>, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist,
-                               partials, l.nblocks, l.chunk, refine_rows);
-        else
-            hipLaunchKernelGGL(icp_refine_kernel<false>, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist,
-                               partials, l.nblocks, l.chunk, refine_rows);
+        auto kern = mode == 1 ? icp_refine_kernel<1> : mode == 2 ? icp_refine_kernel<2> : icp_refine_kernel<0>;
+        hipLaunchKernelGGL(kern, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist, partials, l.nblocks, l.chunk,
+                           refine_rows, src_cov);
     }
     if (do_sum || do_apply) {
         ProfScope ps(ctx, "icp_finalize");
         const uint32_t rows = kRefineBlocks;      // the refine pass folded the main pass's rows into its own
-        if (p2plane)
-            hipLaunchKernelGGL(icp_finalize_kernel<true>, dim3(1), dim3(256), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
-                               (do_apply && !(dbg & 32)) ? 1 : 0);
-        else
-            hipLaunchKernelGGL(icp_finalize_kernel<false>, dim3(1), dim3(256), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0,
-                               (do_apply && !(dbg & 32)) ? 1 : 0);
+        auto kern = mode == 0 ? icp_finalize_kernel<0> : icp_finalize_kernel<1>;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0, (do_apply && !(dbg & 32)) ? 1 : 0);
     }
 }
 
@@ -1222,9 +1312,42 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     return TC_OK;
 }
 
+// per-point covariances (8 floats per point in ORIGINAL order: xx xy xz yy yz zz - -) into the order of the
+// sorted records, two float4 per position
+__global__ void __launch_bounds__(256) gather_cov_kernel(const float4 *__restrict__ pts_sorted, uint32_t n, const float4 *__restrict__ cov_orig,
+                                                        float4 *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t o = __float_as_uint(pts_sorted[i].w);
+    out[2 * (size_t)i] = cov_orig[2 * (size_t)o];
+    out[2 * (size_t)i + 1] = cov_orig[2 * (size_t)o + 1];
+}
+
+static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
+                              const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
+                              float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, const float *d_cov_src,
+                              const float *d_cov_tgt);
+
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
                   float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss) {
+    return icp_run_mode(ctx, p2plane ? 1 : 0, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_iters, max_dist, conv_thr, res, corr_on_device,
+                        kiss, nullptr, nullptr);
+}
+
+// gicp.rs:157-305 once the covariances exist (d_cov_*: 8 floats per point, original order)
+tc_status icp_run_gicp(tc_context *ctx, const float *d_src, size_t ns, const float *d_tgt, size_t nt, const float *d_cov_src,
+                       const float *d_cov_tgt, const float init[7], size_t max_iters, float max_dist, float conv_thr,
+                       tc_icp_result *res, bool corr_on_device) {
+    return icp_run_mode(ctx, 2, d_src, ns, d_tgt, nt, nullptr, 0, init, max_iters, max_dist, conv_thr, res, corr_on_device, 0, d_cov_src,
+                        d_cov_tgt);
+}
+
+static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
+                              const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
+                              float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, const float *d_cov_src,
+                              const float *d_cov_tgt) {
+    const bool p2plane = mode == 1;
     IcpSetup su;
     if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, kiss)) return s;
     hipStream_t st = ctx->stream;
@@ -1232,6 +1355,16 @@ tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, 
     uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns;
     double *partials = (double *)ctx->partials.p;
     const float4 *src = (const float4 *)ctx->src_index.pts.p;
+    const float4 *src_cov = nullptr;
+    if (mode == 2) {
+        if (tc_status s = ensure(ctx, ctx->tgt_index.normals, nt * 2 * sizeof(float4))) return s;
+        if (tc_status s = ensure(ctx, ctx->gicp_src_cov, ns * 2 * sizeof(float4))) return s;
+        hipLaunchKernelGGL(gather_cov_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const float4 *)ctx->tgt_index.pts.p,
+                           (uint32_t)nt, (const float4 *)d_cov_tgt, (float4 *)ctx->tgt_index.normals.p);
+        hipLaunchKernelGGL(gather_cov_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, src, (uint32_t)ns,
+                           (const float4 *)d_cov_src, (float4 *)ctx->gicp_src_cov.p);
+        src_cov = (const float4 *)ctx->gicp_src_cov.p;
+    }
     const float4 *nrm = (const float4 *)ctx->tgt_index.normals.p;
 
     // iterations are enqueued in chunks; the `done` flag of chunk c is polled (pinned copy +
@@ -1249,7 +1382,7 @@ tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, 
             if (flags[c - 2]) { stopped = true; break; }
         }
         for (size_t k = 0; k < kChunk && it < max_iters; ++k, ++it)
-            launch_iteration(ctx, p2plane, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true);
+            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov);
         if (c < max_flags) {
             flags[c] = 0;
             TC_HIP_TRY(ctx, hipMemcpyAsync(&flags[c], &dstate->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1259,12 +1392,12 @@ tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, 
         TC_HIP_TRY(ctx, hipEventRecord(ev, st));
         evs.push_back(ev);
     }
-    if (!p2plane) {
+    if (mode == 0) {
         ProfScope ps(ctx, "icp_final_mse");
         hipLaunchKernelGGL(icp_final_mse_kernel, dim3(su.l.mse_blocks), dim3(kIcpBlock), 0, st, su.tv, src, (uint32_t)ns,
                            su.l.mse_chunk, dstate, corr_pos, partials);
     }
-    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, su.l.mse_blocks, p2plane ? 1 : 0);
+    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, su.l.mse_blocks, mode != 0 ? 1 : 0);
     IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
     TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
     if (res->corr_target) {
@@ -1282,7 +1415,8 @@ tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, 
                 hs->refine_ring_hist[4], hs->refine_ring_hist[5], hs->refine_ring_hist[6], hs->refine_ring_hist[7]);
     if (hs->status != TC_OK) {
         return fail(ctx, (tc_status)hs->status,
-                    p2plane ? "Insufficient correspondences for point-to-plane ICP (need >= 6) or ill-conditioned system"
+                    mode == 2 ? "GICP: insufficient correspondences (need >= 6) or ill-conditioned Gauss-Newton system"
+                    : p2plane ? "Insufficient correspondences for point-to-plane ICP (need >= 6) or ill-conditioned system"
                             : "Insufficient correspondences found");
     }
     for (int i = 0; i < 4; ++i) res->transformation[i] = hs->q[i];

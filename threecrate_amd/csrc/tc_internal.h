@@ -138,6 +138,7 @@ struct tc_context {
     tc::DevBuf state;               // IcpState
     tc::DevBuf partials;            // double * kMaxPartialBlocks * TC_ICP_SUMS_STRIDE
     tc::DevBuf corr;                // u32 * n_source
+    tc::DevBuf gicp_src_cov;        // GICP: source covariances in the sorted source order (2 float4 per point)
     tc::DevBuf overflow;            // scratch (voxel filter: occupied-cell flags / output slots)
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
@@ -191,5 +192,8 @@ tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_quer
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters,
                   float max_dist, float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss = 0);
+tc_status icp_run_gicp(tc_context *ctx, const float *d_src, size_t ns, const float *d_tgt, size_t nt, const float *d_cov_src,
+                       const float *d_cov_tgt, const float init[7], size_t max_iters, float max_dist, float conv_thr,
+                       tc_icp_result *res, bool corr_on_device);
 
 }  // namespace tc
