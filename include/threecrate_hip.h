@@ -265,6 +265,17 @@ tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *que
 tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, size_t k,
                         uint32_t *d_idx, float *d_dist, uint32_t *d_count);
 
+/* ---- radius search export ----
+ * NearestNeighborSearch::find_radius_neighbors(&query, radius) -> Vec<(usize, f32)> (traits.rs:6-12,
+ * nearest_neighbor.rs:254-298: every point with d2 <= radius^2, ascending distance) for many queries, capped at
+ * k_max nearest per query like gpu_find_radius_neighbors (threecrate-gpu/src/nearest_neighbor.rs:357-367,
+ * k_max = 32 there).  Row q of idx / dist (nq x k_max) holds count[q] entries; count[q] == k_max may be a
+ * truncated neighbourhood.  radius <= 0 -> empty results.  k_max <= 65. */
+tc_status tc_radius_search(tc_context *ctx, const float *cloud, size_t n, const float *queries, size_t nq, float radius, size_t k_max,
+                           uint32_t *idx, float *dist, uint32_t *count);
+tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, float radius,
+                                  size_t k_max, uint32_t *d_idx, float *d_dist, uint32_t *d_count);
+
 /* ---- voxel_grid_filter ----
  * voxel_grid_filter(&PointCloud<Point3f>, voxel_size) -> Result<PointCloud<Point3f>>
  * (threecrate-algorithms/src/filtering.rs:38-133): one f32 centroid per occupied voxel, keys

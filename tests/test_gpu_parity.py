@@ -466,3 +466,25 @@ def test_gicp_matches_oracle(ctx):
     far = src + np.float32(50.0)
     with pytest.raises(tc.AlgorithmError):
         ctx.gicp(far, tgt, None, tc.GicpConfig(5, 0.5, 1e-6, 20))               # no correspondence within 0.5
+
+
+def test_radius_search_export_matches_kdtree(ctx):
+    """find_radius_neighbors (nearest_neighbor.rs:254-298; kd-tree KAT :485-539): every point with d2 <= r^2, ascending,
+    capped at the k_max nearest like gpu_find_radius_neighbors (threecrate-gpu/src/nearest_neighbor.rs:357-367)."""
+    pts = synth.uniform_cloud(30000, seed=2)
+    qs = np.concatenate([synth.uniform_cloud(400, seed=12), (synth.uniform_cloud(100, seed=13) * 3.0 - 1.0).astype(np.float32), pts[:100]])
+    tree = O.KdTree(pts)
+    for radius, k_max in ((0.03, 32), (0.06, 32), (0.05, 64)):
+        gi, gd, gc = ctx.find_radius_neighbors_batch(pts, qs, radius, k_max)
+        for q in range(len(qs)):
+            oi, od = tree.find_radius_neighbors(qs[q], radius)
+            m = min(len(oi), k_max)
+            assert gc[q] == m, (q, gc[q], len(oi))
+            assert np.array_equal(gd[q, :m], od[:m])                      # bit-identical distances
+            if len(oi) <= k_max:
+                assert set(gi[q, :m].tolist()) == set(int(v) for v in oi)
+    # radius <= 0 and the single-query form
+    _, _, gc = ctx.find_radius_neighbors_batch(pts, qs[:5], 0.0, 32)
+    assert (gc == 0).all()
+    res = ctx.find_radius_neighbors(pts, pts[7], 0.02)
+    assert res[0] == (7, 0.0) and all(d <= 0.02 for _, d in res)

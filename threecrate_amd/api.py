@@ -235,6 +235,23 @@ class GpuContext:
         idx, dist, cnt = self.find_k_nearest_batch(cloud, np.asarray(query, np.float32).reshape(1, 3), k)
         return [(int(idx[0, i]), float(dist[0, i])) for i in range(int(cnt[0]))]
 
+    def find_radius_neighbors_batch(self, cloud, queries, radius: float, k_max: int = 32):
+        """find_radius_neighbors (nearest_neighbor.rs:254-298) for many queries, capped at the k_max nearest like
+        gpu_find_radius_neighbors (threecrate-gpu/src/nearest_neighbor.rs:357-367): (idx, dist, count)."""
+        c, q = _as_host(cloud), _as_host(queries)
+        kk = max(int(k_max), 1)
+        idx = np.zeros((len(q), kk), np.uint32)
+        dist = np.zeros((len(q), kk), np.float32)
+        cnt = np.zeros(len(q), np.uint32)
+        self._check(self._L.tc_radius_search(self._h, c.ctypes.data, c.shape[0], q.ctypes.data, q.shape[0], float(radius), int(k_max),
+                                             idx.ctypes.data, dist.ctypes.data, cnt.ctypes.data))
+        return idx.astype(np.int64), dist, cnt
+
+    def find_radius_neighbors(self, cloud, query, radius: float, k_max: int = 32):
+        """gpu_find_radius_neighbors (threecrate-gpu/src/nearest_neighbor.rs:357-367): [(index, distance), ...]"""
+        idx, dist, cnt = self.find_radius_neighbors_batch(cloud, np.asarray(query, np.float32).reshape(1, 3), radius, k_max)
+        return [(int(idx[0, i]), float(dist[0, i])) for i in range(int(cnt[0]))]
+
     # ---- voxel grid filter ----
     def voxel_grid_filter(self, cloud, voxel_size: float):
         """filtering.rs:38-133 -> (M, 3) centroids, sorted by voxel key (kx, ky, kz)."""

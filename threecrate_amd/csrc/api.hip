@@ -551,6 +551,48 @@ tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const f
     return TC_OK;
 }
 
+// ---- radius search export (nearest_neighbor.rs:254-298; gpu_find_radius_neighbors gpu/nearest_neighbor.rs:357-367) ----
+tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, float radius, size_t k_max,
+                                  uint32_t *d_idx, float *d_dist, uint32_t *d_count) {
+    if (!ctx) return TC_INVALID_DATA;
+    if (nq == 0) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!(radius > 0.0f) || n == 0 || k_max == 0) {      // nearest_neighbor.rs:255-257: empty result
+        TC_HIP_TRY(ctx, hipMemsetAsync(d_count, 0, nq * sizeof(uint32_t), ctx->stream));
+        TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return TC_OK;
+    }
+    if (n >= 0xFFFFFFF0ull || nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k_max > 1 ? k_max - 1 : 1) * 2.0f, nullptr, nullptr)) return s;
+    if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k_max, d_idx, d_dist, d_count, radius * radius)) return s;
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+tc_status tc_radius_search(tc_context *ctx, const float *cloud, size_t n, const float *queries, size_t nq, float radius, size_t k_max,
+                           uint32_t *idx, float *dist, uint32_t *count) {
+    if (!ctx) return TC_INVALID_DATA;
+    if (nq == 0) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!(radius > 0.0f) || n == 0 || k_max == 0) { std::memset(count, 0, nq * sizeof(uint32_t)); return TC_OK; }
+    if (k_max > 65) return fail(ctx, TC_UNSUPPORTED, "k_max > 65 is not supported by the HIP radius search");
+    DevBuf dc, dq, di, dd, dn;
+    auto cleanup = [&]() { for (DevBuf *b : {&dc, &dq, &di, &dd, &dn}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } };
+    tc_status st = TC_OK;
+    if ((st = ensure(ctx, dc, n * 12)) || (st = ensure(ctx, dq, nq * 12)) || (st = ensure(ctx, di, nq * k_max * 4)) ||
+        (st = ensure(ctx, dd, nq * k_max * 4)) || (st = ensure(ctx, dn, nq * 4))) { cleanup(); return st; }
+    (void)hipMemcpyAsync(dc.p, cloud, n * 12, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(dq.p, queries, nq * 12, hipMemcpyHostToDevice, ctx->stream);
+    st = tc_radius_search_device(ctx, (const float *)dc.p, n, (const float *)dq.p, nq, radius, k_max, (uint32_t *)di.p, (float *)dd.p, (uint32_t *)dn.p);
+    if (st == TC_OK) {
+        (void)hipMemcpy(idx, di.p, nq * k_max * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(dist, dd.p, nq * k_max * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(count, dn.p, nq * 4, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    return st;
+}
+
 tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *queries, size_t nq, size_t k,
                  uint32_t *idx, float *dist, uint32_t *count) {
     if (!ctx) return TC_INVALID_DATA;

@@ -361,7 +361,7 @@ static void launch_variant(hipStream_t st, const GridView &gv, const NormalParam
 template <int L, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__restrict__ queries, uint32_t nq, uint32_t k,
                                                     uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
-                                                    uint32_t *__restrict__ out_count) {
+                                                    uint32_t *__restrict__ out_count, float radius_sq) {
     __shared__ uint32_t ldsA_[L * BLOCK];
     __shared__ uint32_t ldsB_[L * BLOCK];
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
@@ -424,22 +424,25 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
         if (r < 64) taken_lo |= 1ull << r; else taken_hi |= 1ull << (r - 64);
         ldsB[r * BLOCK] = j;
     }
+    uint32_t within = 0;          // radius search: the entries with d2 <= radius^2 (nearest_neighbor.rs:271), a prefix
     for (uint32_t r = 0; r < cnt; ++r) {
         const float4 c = gv.pts[ldsB[r * BLOCK]];
+        const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
         out_idx[(size_t)t * k + r] = __float_as_uint(c.w);
-        out_dist[(size_t)t * k + r] = sqrtf(d2_nc(c.x, c.y, c.z, q.x, q.y, q.z));     // nearest_neighbor.rs:249
+        out_dist[(size_t)t * k + r] = sqrtf(v);                                       // nearest_neighbor.rs:249
+        within += (v <= radius_sq) ? 1u : 0u;
     }
-    out_count[t] = cnt;
+    out_count[t] = within;
 }
 
 tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, size_t k,
-                     uint32_t *d_idx, float *d_dist, uint32_t *d_count) {
+                     uint32_t *d_idx, float *d_dist, uint32_t *d_count, float radius_sq) {
     if (k > 65) return fail(ctx, TC_UNSUPPORTED, "k > 65 is not supported by the HIP k-NN export");
     const GridView gv = view_of(ix);
     ProfScope ps(ctx, "knn_batch");
     hipStream_t st = ctx->stream;
 #define TC_KNN(LL, BB) hipLaunchKernelGGL((knn_kernel<LL, BB>), dim3((unsigned)((nq + BB - 1) / BB)), dim3(BB), 0, st, gv, d_queries, \
-                                          (uint32_t)nq, (uint32_t)k, d_idx, d_dist, d_count)
+                                          (uint32_t)nq, (uint32_t)k, d_idx, d_dist, d_count, radius_sq)
     if (k <= 9) TC_KNN(9, 256);
     else if (k <= 17) TC_KNN(17, 256);
     else if (k <= 33) TC_KNN(33, 128);

@@ -186,7 +186,7 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal
                          const float vp[3], float *d_out6);
 
 tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, size_t k,
-                     uint32_t *d_idx, float *d_dist, uint32_t *d_count);
+                     uint32_t *d_idx, float *d_dist, uint32_t *d_count, float radius_sq = INFINITY);
 
 // icp.hip
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
