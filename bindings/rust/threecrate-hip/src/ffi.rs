@@ -1,0 +1,103 @@
+//! Raw declarations of include/threecrate_hip.h (keep in sync with the header; tc_abi_version() == 1).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)] pub struct tc_context { _private: [u8; 0] }
+#[repr(C)] pub struct tc_frame_stream { _private: [u8; 0] }
+
+pub const TC_OK: c_int = 0;
+pub const TC_INVALID_DATA: c_int = 1;
+pub const TC_ALGORITHM: c_int = 2;
+pub const TC_GPU: c_int = 3;
+pub const TC_UNSUPPORTED: c_int = 4;
+
+#[repr(C)] #[derive(Clone, Copy, Debug)]
+pub struct tc_normal_config {                 // NormalEstimationConfig, normals.rs:17-37
+    pub k_neighbors: u64,
+    pub radius: f32,
+    pub has_radius: i32,
+    pub consistent_orientation: i32,
+    pub has_viewpoint: i32,
+    pub viewpoint: [f32; 3],
+}
+
+#[repr(C)] #[derive(Debug)]
+pub struct tc_icp_result {                    // ICPResult, registration.rs:13-24
+    pub transformation: [f32; 7],             // qi qj qk qw tx ty tz (nalgebra Isometry3 storage order)
+    pub mse: f32,
+    pub iterations: u64,
+    pub converged: i32,
+    pub n_correspondences: u64,
+    pub corr_target: *mut u32,                // caller-allocated, n_source entries, u32::MAX = no match
+}
+
+#[repr(C)] #[derive(Clone, Copy, Debug)]
+pub struct tc_gicp_config { pub max_iterations: usize, pub max_correspondence_distance: f32, pub convergence_threshold: f32, pub k_correspondences: usize }
+
+#[repr(C)] #[derive(Clone, Copy, Debug)]
+pub struct tc_kiss_icp_config { pub voxel_size: f32, pub max_range: f32, pub min_range: f32, pub max_iterations: usize }
+
+#[repr(C)] #[derive(Clone, Copy, Debug)]
+pub struct tc_icp_scale_level { pub voxel_size: f32, pub max_iterations: usize, pub max_correspondence_distance: f32 }
+
+#[repr(C)] #[derive(Debug)]
+pub struct tc_multiscale_icp_config {
+    pub levels: *const tc_icp_scale_level,
+    pub n_levels: usize,
+    pub final_refinement_iterations: usize,
+    pub final_max_correspondence_distance: f32,
+    pub convergence_threshold: f32,
+}
+
+#[repr(C)] #[derive(Clone, Copy, Debug)]
+pub struct tc_frame_stream_config {
+    pub max_points: usize, pub max_queue_depth: usize, pub voxel_size: f32, pub k_neighbors: usize,
+    pub max_iterations: usize, pub max_correspondence_distance: f32, pub convergence_threshold: f32,
+}
+
+#[repr(C)] #[derive(Clone, Copy, Debug)]
+pub struct tc_frame_result {
+    pub transformation: [f32; 7], pub mse: f32, pub iterations: u64, pub converged: i32, pub status: i32,
+    pub n_points_in: u64, pub n_points: u64,
+}
+
+#[repr(C)] #[derive(Clone, Copy, Debug, Default)]
+pub struct tc_frame_stream_metrics { pub items_queued: u64, pub items_processed: u64, pub items_dropped: u64, pub max_depth_seen: u64 }
+
+extern "C" {
+    pub fn tc_abi_version() -> c_int;
+    pub fn tc_device_count() -> c_int;
+    pub fn tc_context_create(device: c_int, out: *mut *mut tc_context) -> c_int;
+    pub fn tc_context_create_on_stream(device: c_int, hip_stream: *mut c_void, out: *mut *mut tc_context) -> c_int;
+    pub fn tc_context_destroy(ctx: *mut tc_context);
+    pub fn tc_last_error_message(ctx: *const tc_context) -> *const c_char;
+    pub fn tc_normal_config_default(cfg: *mut tc_normal_config);
+    pub fn tc_estimate_normals(ctx: *mut tc_context, xyz: *const f32, n: usize, cfg: *const tc_normal_config, out: *mut f32) -> c_int;
+    pub fn tc_icp_detailed(ctx: *mut tc_context, src: *const f32, ns: usize, tgt: *const f32, nt: usize, init: *const f32,
+                           max_iters: usize, max_dist: f32, conv_thr: f32, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_icp_point_to_point(ctx: *mut tc_context, src: *const f32, ns: usize, tgt: *const f32, nt: usize, init: *const f32,
+                                 max_iters: usize, conv_thr: f32, max_dist: f32, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_icp(ctx: *mut tc_context, src: *const f32, ns: usize, tgt: *const f32, nt: usize, init: *const f32, max_iters: usize,
+                  out: *mut f32) -> c_int;
+    pub fn tc_icp_point_to_plane_detailed(ctx: *mut tc_context, src: *const f32, ns: usize, tgt: *const f32, nt: usize,
+                                          normals: *const f32, n_normals: usize, stride: usize, init: *const f32, max_iters: usize,
+                                          max_dist: f32, conv_thr: f32, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_multiscale_icp_point_to_point(ctx: *mut tc_context, src: *const f32, ns: usize, tgt: *const f32, nt: usize,
+                                            init: *const f32, cfg: *const tc_multiscale_icp_config, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_gicp(ctx: *mut tc_context, src: *const f32, ns: usize, tgt: *const f32, nt: usize, init: *const f32,
+                   cfg: *const tc_gicp_config, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_kiss_icp(ctx: *mut tc_context, src: *const f32, ns: usize, tgt: *const f32, nt: usize, init: *const f32,
+                       cfg: *const tc_kiss_icp_config, res: *mut tc_icp_result, n_source_down: *mut usize) -> c_int;
+    pub fn tc_knn(ctx: *mut tc_context, cloud: *const f32, n: usize, queries: *const f32, nq: usize, k: usize,
+                  idx: *mut u32, dist: *mut f32, count: *mut u32) -> c_int;
+    pub fn tc_radius_search(ctx: *mut tc_context, cloud: *const f32, n: usize, queries: *const f32, nq: usize, radius: f32, k_max: usize,
+                            idx: *mut u32, dist: *mut f32, count: *mut u32) -> c_int;
+    pub fn tc_voxel_grid_filter(ctx: *mut tc_context, xyz: *const f32, n: usize, voxel_size: f32, out: *mut f32, n_out: *mut usize) -> c_int;
+    pub fn tc_frame_stream_create(ctx: *mut tc_context, cfg: *const tc_frame_stream_config, out: *mut *mut tc_frame_stream) -> c_int;
+    pub fn tc_frame_stream_send(s: *mut tc_frame_stream, frame: *const f32, n: usize, stride_floats: usize) -> c_int;
+    pub fn tc_frame_stream_try_send(s: *mut tc_frame_stream, frame: *const f32, n: usize, stride_floats: usize, accepted: *mut c_int) -> c_int;
+    pub fn tc_frame_stream_finish(s: *mut tc_frame_stream, results: *mut tc_frame_result, capacity: usize, n_results: *mut usize,
+                                  metrics: *mut tc_frame_stream_metrics) -> c_int;
+    pub fn tc_frame_stream_destroy(s: *mut tc_frame_stream);
+    pub fn tc_read_kitti_bin(path: *const c_char, out_xyz: *mut f32, capacity_points: usize, n_points: *mut usize) -> c_int;
+}

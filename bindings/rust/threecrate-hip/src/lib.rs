@@ -1,0 +1,248 @@
+//! threecrate-hip: the normals + ICP path of threecrate on an AMD MI355X, behind the signatures of
+//! threecrate-algorithms (`estimate_normals*`, `icp*`, `icp_point_to_plane*`, `multiscale_icp_point_to_point`,
+//! `gicp`, `kiss_icp`, `voxel_grid_filter`) and of the `threecrate-gpu` facade (`gpu_estimate_normals`, `gpu_icp`,
+//! `gpu_icp_point_to_plane`).  Every function takes a [`HipContext`] (the role `GpuContext` plays in
+//! threecrate-gpu: one device + one stream; not thread-safe, one context per thread / GPU).
+//!
+//! Layout facts the zero-copy calls rely on: `Point3f` = `nalgebra::Point3<f32>` is three contiguous f32
+//! (threecrate-core/src/point.rs:8), `NormalPoint3f` is `#[repr(C)] { position, normal }` (point.rs:31-36),
+//! `Isometry3<f32>` is passed as (qi, qj, qk, qw, tx, ty, tz).
+pub mod ffi;
+
+use nalgebra::{Isometry3, Quaternion, Translation3, UnitQuaternion};
+use std::ffi::CStr;
+use threecrate_algorithms::{GicpConfig, ICPResult, KissIcpConfig, NormalEstimationConfig};
+use threecrate_core::{Error, NormalPoint3f, Point3f, PointCloud, Result, Vector3f};
+
+/// One HIP device + stream + the library's grow-only device buffers (`tc_context`).
+pub struct HipContext(*mut ffi::tc_context);
+
+// the context is only ever used from the thread that owns the value
+unsafe impl Send for HipContext {}
+
+impl HipContext {
+    /// `GpuContext::new` (threecrate-gpu/src/device.rs:16-50).  `Error::Gpu` when no MI355X is usable.
+    pub fn new(device: i32) -> Result<Self> {
+        let mut h: *mut ffi::tc_context = std::ptr::null_mut();
+        let rc = unsafe { ffi::tc_context_create(device, &mut h) };
+        if rc != ffi::TC_OK || h.is_null() {
+            return Err(Error::Gpu(format!("no usable HIP device {device} (tc_status {rc})")));
+        }
+        Ok(HipContext(h))
+    }
+
+    fn check(&self, rc: i32) -> Result<()> {
+        if rc == ffi::TC_OK {
+            return Ok(());
+        }
+        let msg = unsafe {
+            let p = ffi::tc_last_error_message(self.0);
+            if p.is_null() { String::new() } else { CStr::from_ptr(p).to_string_lossy().into_owned() }
+        };
+        Err(match rc {                                   // threecrate-core/src/error.rs:7-28
+            ffi::TC_INVALID_DATA => Error::InvalidData(msg),
+            ffi::TC_ALGORITHM => Error::Algorithm(msg),
+            ffi::TC_UNSUPPORTED => Error::Unsupported(msg),
+            _ => Error::Gpu(msg),
+        })
+    }
+}
+
+impl Drop for HipContext {
+    fn drop(&mut self) {
+        unsafe { ffi::tc_context_destroy(self.0) }
+    }
+}
+
+fn iso_to7(t: &Isometry3<f32>) -> [f32; 7] {
+    let q = t.rotation.quaternion().coords;              // (i, j, k, w)
+    [q[0], q[1], q[2], q[3], t.translation.x, t.translation.y, t.translation.z]
+}
+
+fn iso_from7(t: &[f32; 7]) -> Isometry3<f32> {
+    Isometry3::from_parts(
+        Translation3::new(t[4], t[5], t[6]),
+        UnitQuaternion::new_unchecked(Quaternion::new(t[3], t[0], t[1], t[2])),   // Quaternion::new(w, i, j, k)
+    )
+}
+
+fn xyz(cloud: &PointCloud<Point3f>) -> *const f32 {
+    cloud.points.as_ptr() as *const f32
+}
+
+fn result_from(r: &ffi::tc_icp_result, corr: &[u32], n_valid: usize) -> ICPResult {
+    ICPResult {
+        transformation: iso_from7(&r.transformation),
+        mse: r.mse,
+        iterations: r.iterations as usize,
+        converged: r.converged != 0,
+        correspondences: corr[..n_valid].iter().enumerate().filter(|(_, &t)| t != u32::MAX).map(|(s, &t)| (s, t as usize)).collect(),
+    }
+}
+
+fn empty_result(corr: &mut Vec<u32>) -> ffi::tc_icp_result {
+    ffi::tc_icp_result { transformation: [0.0; 7], mse: 0.0, iterations: 0, converged: 0, n_correspondences: 0, corr_target: corr.as_mut_ptr() }
+}
+
+// ---- normals (threecrate-algorithms/src/normals.rs:238-380) ------------------------------------------------
+
+/// `estimate_normals_with_config` (normals.rs:257-260)
+pub fn estimate_normals_with_config(ctx: &HipContext, cloud: &PointCloud<Point3f>, config: &NormalEstimationConfig)
+    -> Result<PointCloud<NormalPoint3f>> {
+    let n = cloud.points.len();
+    let cfg = ffi::tc_normal_config {
+        k_neighbors: config.k_neighbors as u64,
+        radius: config.radius.unwrap_or(0.0),
+        has_radius: config.radius.is_some() as i32,
+        consistent_orientation: config.consistent_orientation as i32,
+        has_viewpoint: config.viewpoint.is_some() as i32,
+        viewpoint: config.viewpoint.map(|p| [p.x, p.y, p.z]).unwrap_or([0.0; 3]),
+    };
+    let mut out: Vec<NormalPoint3f> = Vec::with_capacity(n);
+    ctx.check(unsafe { ffi::tc_estimate_normals(ctx.0, xyz(cloud), n, &cfg, out.as_mut_ptr() as *mut f32) })?;
+    unsafe { out.set_len(n) };
+    Ok(PointCloud::from_points(out))
+}
+
+/// `estimate_normals` (normals.rs:238-241)
+pub fn estimate_normals(ctx: &HipContext, cloud: &PointCloud<Point3f>, k: usize) -> Result<PointCloud<NormalPoint3f>> {
+    let config = NormalEstimationConfig { k_neighbors: k, ..Default::default() };
+    estimate_normals_with_config(ctx, cloud, &config)
+}
+
+/// `estimate_normals_radius` (normals.rs:368-380)
+pub fn estimate_normals_radius(ctx: &HipContext, cloud: &PointCloud<Point3f>, radius: f32, consistent_orientation: bool)
+    -> Result<PointCloud<NormalPoint3f>> {
+    let config = NormalEstimationConfig { k_neighbors: 10, radius: Some(radius), consistent_orientation, viewpoint: None };
+    estimate_normals_with_config(ctx, cloud, &config)
+}
+
+// ---- ICP (threecrate-algorithms/src/registration.rs) ---------------------------------------------------------
+
+/// `icp_detailed` (registration.rs:258-265)
+pub fn icp_detailed(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, init: Isometry3<f32>,
+                    max_iters: usize, max_correspondence_distance: Option<f32>, convergence_threshold: f32) -> Result<ICPResult> {
+    let ns = source.points.len();
+    let mut corr = vec![u32::MAX; ns.max(1)];
+    let mut r = empty_result(&mut corr);
+    let i7 = iso_to7(&init);
+    ctx.check(unsafe {
+        ffi::tc_icp_detailed(ctx.0, xyz(source), ns, xyz(target), target.points.len(), i7.as_ptr(), max_iters,
+                             max_correspondence_distance.unwrap_or(-1.0), convergence_threshold, &mut r)
+    })?;
+    Ok(result_from(&r, &corr, ns))
+}
+
+/// `icp` (registration.rs:232-242): any error returns `init`
+pub fn icp(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, init: Isometry3<f32>, max_iters: usize)
+    -> Isometry3<f32> {
+    match icp_detailed(ctx, source, target, init, max_iters, None, 1e-6) {
+        Ok(r) => r.transformation,
+        Err(_) => init,
+    }
+}
+
+/// `icp_point_to_point` (registration.rs:644-680)
+pub fn icp_point_to_point(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, init: Isometry3<f32>,
+                          max_iterations: usize, convergence_threshold: f32, max_correspondence_distance: Option<f32>) -> Result<ICPResult> {
+    let ns = source.points.len();
+    let mut corr = vec![u32::MAX; ns.max(1)];
+    let mut r = empty_result(&mut corr);
+    let i7 = iso_to7(&init);
+    ctx.check(unsafe {
+        ffi::tc_icp_point_to_point(ctx.0, xyz(source), ns, xyz(target), target.points.len(), i7.as_ptr(), max_iterations,
+                                   convergence_threshold, max_correspondence_distance.unwrap_or(-1.0), &mut r)
+    })?;
+    Ok(result_from(&r, &corr, ns))
+}
+
+/// `icp_point_to_plane_detailed` (registration.rs:508-516)
+pub fn icp_point_to_plane_detailed(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>,
+                                   target_normals: &[Vector3f], init: Isometry3<f32>, max_iters: usize,
+                                   max_correspondence_distance: Option<f32>, convergence_threshold: f32) -> Result<ICPResult> {
+    let ns = source.points.len();
+    let mut corr = vec![u32::MAX; ns.max(1)];
+    let mut r = empty_result(&mut corr);
+    let i7 = iso_to7(&init);
+    ctx.check(unsafe {
+        ffi::tc_icp_point_to_plane_detailed(ctx.0, xyz(source), ns, xyz(target), target.points.len(),
+                                            target_normals.as_ptr() as *const f32, target_normals.len(), 3, i7.as_ptr(), max_iters,
+                                            max_correspondence_distance.unwrap_or(-1.0), convergence_threshold, &mut r)
+    })?;
+    Ok(result_from(&r, &corr, ns))
+}
+
+/// `icp_point_to_plane` (registration.rs:488-494)
+pub fn icp_point_to_plane(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, target_normals: &[Vector3f],
+                          init: Isometry3<f32>, max_iters: usize) -> Result<ICPResult> {
+    icp_point_to_plane_detailed(ctx, source, target, target_normals, init, max_iters, None, 1e-6)
+}
+
+/// `gicp` (gicp.rs:100-105)
+pub fn gicp(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, init: Isometry3<f32>, config: GicpConfig)
+    -> Result<ICPResult> {
+    let ns = source.points.len();
+    let mut corr = vec![u32::MAX; ns.max(1)];
+    let mut r = empty_result(&mut corr);
+    let i7 = iso_to7(&init);
+    let cfg = ffi::tc_gicp_config {
+        max_iterations: config.max_iterations,
+        max_correspondence_distance: config.max_correspondence_distance,
+        convergence_threshold: config.convergence_threshold,
+        k_correspondences: config.k_correspondences,
+    };
+    ctx.check(unsafe { ffi::tc_gicp(ctx.0, xyz(source), ns, xyz(target), target.points.len(), i7.as_ptr(), &cfg, &mut r) })?;
+    Ok(result_from(&r, &corr, ns))
+}
+
+/// `kiss_icp` (kiss_icp.rs:183-188).  Correspondence source indices refer to the voxel-downsampled source.
+pub fn kiss_icp(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, init: Isometry3<f32>, config: KissIcpConfig)
+    -> Result<ICPResult> {
+    let ns = source.points.len();
+    let mut corr = vec![u32::MAX; ns.max(1)];
+    let mut r = empty_result(&mut corr);
+    let i7 = iso_to7(&init);
+    let cfg = ffi::tc_kiss_icp_config { voxel_size: config.voxel_size, max_range: config.max_range, min_range: config.min_range,
+                                        max_iterations: config.max_iterations };
+    let mut n_down = 0usize;
+    ctx.check(unsafe { ffi::tc_kiss_icp(ctx.0, xyz(source), ns, xyz(target), target.points.len(), i7.as_ptr(), &cfg, &mut r, &mut n_down) })?;
+    Ok(result_from(&r, &corr, n_down))
+}
+
+// ---- filters / neighbour search ----------------------------------------------------------------------------
+
+/// `voxel_grid_filter` (filtering.rs:38-133); voxels come out sorted by (kx, ky, kz)
+pub fn voxel_grid_filter(ctx: &HipContext, cloud: &PointCloud<Point3f>, voxel_size: f32) -> Result<PointCloud<Point3f>> {
+    let n = cloud.points.len();
+    let mut out: Vec<Point3f> = Vec::with_capacity(n.max(1));
+    let mut n_out = 0usize;
+    ctx.check(unsafe { ffi::tc_voxel_grid_filter(ctx.0, xyz(cloud), n, voxel_size, out.as_mut_ptr() as *mut f32, &mut n_out) })?;
+    unsafe { out.set_len(n_out) };
+    Ok(PointCloud::from_points(out))
+}
+
+/// `gpu_find_k_nearest_batch` (threecrate-gpu/src/nearest_neighbor.rs:345-355)
+pub fn find_k_nearest_batch(ctx: &HipContext, points: &[Point3f], queries: &[Point3f], k: usize) -> Result<Vec<Vec<(usize, f32)>>> {
+    let nq = queries.len();
+    let kk = k.max(1);
+    let (mut idx, mut dist, mut cnt) = (vec![0u32; nq * kk], vec![0f32; nq * kk], vec![0u32; nq.max(1)]);
+    ctx.check(unsafe {
+        ffi::tc_knn(ctx.0, points.as_ptr() as *const f32, points.len(), queries.as_ptr() as *const f32, nq, k, idx.as_mut_ptr(),
+                    dist.as_mut_ptr(), cnt.as_mut_ptr())
+    })?;
+    Ok((0..nq).map(|q| (0..cnt[q] as usize).map(|j| (idx[q * kk + j] as usize, dist[q * kk + j])).collect()).collect())
+}
+
+// ---- threecrate-gpu facade (gpu/normals.rs:443-447, gpu/icp.rs:977-1025) ---------------------------------------
+
+/// `gpu_icp(&ctx, source, target, max_iterations, convergence_threshold, max_correspondence_distance)`
+pub fn gpu_icp(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, max_iterations: usize,
+               convergence_threshold: f32, max_correspondence_distance: f32) -> Result<Isometry3<f32>> {
+    Ok(icp_point_to_point(ctx, source, target, Isometry3::identity(), max_iterations, convergence_threshold,
+                          Some(max_correspondence_distance))?.transformation)
+}
+
+/// `gpu_estimate_normals(&ctx, &mut cloud, k)`
+pub fn gpu_estimate_normals(ctx: &HipContext, cloud: &mut PointCloud<Point3f>, k: usize) -> Result<PointCloud<NormalPoint3f>> {
+    estimate_normals(ctx, cloud, k)
+}
