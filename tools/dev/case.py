@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import json, numpy as np, threecrate_amd as tc
 from oracle import oracle as O
 from tests.helpers import sphere_cloud

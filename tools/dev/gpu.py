@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 """dev script: quick timing of the hot path on the GPU box (not part of the product)."""
 import sys, time
 import numpy as np

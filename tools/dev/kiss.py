@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import faulthandler, sys, time
 faulthandler.dump_traceback_later(40, exit=True)
 import numpy as np, threecrate_amd as tc

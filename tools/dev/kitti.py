@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 """dev: per-kernel profile of one KITTI-shaped frame pipeline (voxel + normals + icp)."""
 import time, numpy as np, torch, threecrate_amd as tc
 from threecrate_amd import synth

@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, threecrate_amd as tc
 from threecrate_amd import synth
 ctx = tc.GpuContext(0)

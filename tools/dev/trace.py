@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 """dev: one ICP call under rocprofv3 --kernel-trace to see per-iteration kernel durations."""
 import numpy as np, torch, threecrate_amd as tc
 from threecrate_amd import synth

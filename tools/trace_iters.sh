@@ -6,7 +6,7 @@ TAG=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/trace_$TAG
 mkdir -p $OUT
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 scripts_dev_trace.py > $OUT/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 tools/dev/trace.py > $OUT/log.txt 2>&1
 python3 - "$OUT" <<'PY'
 import sys, glob, csv
 out = sys.argv[1]
