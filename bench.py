@@ -233,7 +233,7 @@ def main():
         traffic, traffic_note = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            tk = tj["kernels"]["icp_correspond_reduce_kernel<true>"]
+            tk = tj["kernels"].get("icp_correspond_reduce_kernel<1>") or tj["kernels"]["icp_correspond_reduce_kernel<true>"]   # MODE 1 = point-to-plane
             if n == N_POINTS:
                 traffic = tk["traffic_bytes_corrected"]
                 traffic_note = {"raw_bytes": tk["traffic_bytes_raw"], "corrected_bytes": tk["traffic_bytes_corrected"],

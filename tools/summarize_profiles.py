@@ -22,8 +22,9 @@ def load(sub, pat):
 
 
 def short(name):
-    for k in ["icp_correspond_reduce_kernel<true>", "icp_correspond_reduce_kernel<false>", "icp_refine_kernel<true>",
-              "icp_refine_kernel<false>", "icp_finalize_kernel", "knn_kernel", "vox_hist_kernel", "vox_scatter_kernel",
+    # template argument = ICP mode: 0 point-to-point, 1 point-to-plane, 2 GICP
+    for k in ["icp_correspond_reduce_kernel<1>", "icp_correspond_reduce_kernel<0>", "icp_correspond_reduce_kernel<2>",
+              "icp_refine_kernel<1>", "icp_refine_kernel<0>", "icp_refine_kernel<2>", "icp_finalize_kernel", "knn_kernel", "vox_hist_kernel", "vox_scatter_kernel",
               "vox_rank_kernel", "vox_flag_kernel", "vox_centroid_kernel",
               "normals_knn_pca_kernel", "normals_overflow_kernel", "cell_hist_kernel", "scatter_kernel",
               "rank_gather_kernel", "scan_apply_kernel", "scan_top_kernel", "scan_reduce_kernel", "bbox_kernel",
