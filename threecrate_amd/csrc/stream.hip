@@ -135,11 +135,12 @@ void worker_main(tc_frame_stream *s) {
 
 tc_status enqueue(tc_frame_stream *s, const float *frame, size_t n, size_t stride, bool block, int *accepted) {
     if (!s || !frame || (stride != 3 && stride != 4)) return TC_INVALID_DATA;
-    if (n == 0 || n > s->cfg.max_points) return tc::fail(s->ctx, TC_INVALID_DATA, "frame is empty or larger than max_points");
+    // plain status codes here: the context's error string belongs to the worker thread while the stream runs
+    if (n == 0 || n > s->cfg.max_points) return TC_INVALID_DATA;          // frame is empty or larger than max_points
     int slot = -1;
     {
         std::unique_lock<std::mutex> lk(s->mu);
-        if (s->closed) return tc::fail(s->ctx, TC_INVALID_DATA, "pipeline already finished");
+        if (s->closed) return TC_INVALID_DATA;                            // pipeline already finished (streaming.rs:583-588)
         if (s->free_slots.empty()) {
             if (!block) {
                 s->metrics.items_dropped += 1;
