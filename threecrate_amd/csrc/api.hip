@@ -68,7 +68,8 @@ static float normals_cell_factor(size_t k, bool large = false) {
     const double lam = K1 + 3.1 * std::sqrt(K1) + 2.0;
     const double c = std::cbrt(lam / 4.18879);
     // multiplier scanned on the 1 M-point uniform cloud (k = 16, whole call): 0.8 -> 0.95 ms, 0.9 -> 0.83, 0.95 -> 0.79,
-    // 1.0 -> 0.75, 1.1 -> 0.75, 1.2 -> 0.79, 1.3 -> 0.84 (the in-place ring continuation made the overflow tail cheap)
+    // 1.0 -> 0.75, 1.1 -> 0.75, 1.2 -> 0.79, 1.3 -> 0.84 (the in-place ring continuation made the overflow tail cheap);
+    // again at 7 waves per SIMD: 0.9 -> 0.70, 0.95 -> 0.67, 1.0 -> 0.655, 1.03 -> 0.65, 1.1 -> 0.71
     // Applied to clouds of >= 2^18 points (those whose edge is also adapted to the measured occupancy); smaller clouds keep
     // 0.95: they are not adapted, and on surface-like frames (24 k-point voxel-filtered LiDAR) the larger edge costs 5 %.
     return (float)((large ? 1.03 : 0.95) * c / 2.0);
