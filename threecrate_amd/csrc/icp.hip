@@ -473,13 +473,14 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     if (st->done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
     __shared__ uint2 spans[kSpanRows][kIcpBlock];
-    // refine entries of the group, one region per wave: (source index, best known position).  Entries
-    // are appended in (trip, lane) order by ballot prefix and the block's segment of the global list is
-    // the concatenation of its waves' regions, so the list -- and with it every sum -- is deterministic.
-    __shared__ uint2 rl_list[kIcpBlock / 64][kIcpGroup * 64];
-    __shared__ uint32_t rl_wcnt[kIcpBlock / 64];
-    uint32_t seg_count = 0;                                // entries this block has written to its segment
-    uint2 *__restrict__ const seg = reinterpret_cast<uint2 *>(rlist + kMaxPartialBlocks) + (size_t)blockIdx.x * chunk;
+    // Refine entries (source index, best known position) go straight to global memory: every wave owns a region
+    // of chunk / 4 entries (it never handles more points than that) and appends in (trip, lane) order by ballot
+    // prefix, so the list -- and with it every sum -- is deterministic, without atomics, LDS or barriers.
+    constexpr int kWavesPerBlock = kIcpBlock / 64;
+    const uint32_t wave_cap = chunk / kWavesPerBlock;
+    uint2 *__restrict__ const wseg = reinterpret_cast<uint2 *>(rlist + kMaxPartialBlocks * kWavesPerBlock) +
+                                     ((size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * wave_cap;
+    uint32_t wcnt = 0;                                     // this wave's entries so far (wave-uniform)
     const GridGeom &g = tgt.g;
     const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
     const float t[3] = {st->t[0], st->t[1], st->t[2]};
@@ -493,7 +494,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     const uint32_t end = min(beg + chunk, ns);
     for (uint32_t gb = beg; gb < end; gb += kIcpGroup * kIcpBlock) {
         // ---- phase S ----
-        uint32_t ok = 0, wcnt = 0;                         // wcnt: this wave's entries of the group (wave-uniform)
+        uint32_t ok = 0;
 #pragma unroll 1
         for (int u = 0; u < kIcpGroup; ++u) {
             const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
                 const unsigned long long kp = pj != 0xFFFFFFFFu ? (((unsigned long long)__float_as_uint(ub2p) << 32) | pj) : ~0ull;
                 const unsigned long long kb = bestg != 0xFFFFFFFFu ? (((unsigned long long)__float_as_uint(best) << 32) | bestg) : ~0ull;
                 const unsigned long long km = kb < kp ? kb : kp;
-                rl_list[w][wcnt + __popcll(rmask & ((1ull << lane) - 1ull))] = make_uint2(j, km != ~0ull ? (uint32_t)km : 0xFFFFFFFFu);
+                wseg[wcnt + __popcll(rmask & ((1ull << lane) - 1ull))] = make_uint2(j, km != ~0ull ? (uint32_t)km : 0xFFFFFFFFu);
             }
             wcnt += __popcll(rmask);
             if (refine) continue;
@@ -528,22 +529,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
             corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
             if (valid) ok |= 1u << u;
         }
-        // flush the group's entries to the block's segment of the global list (no atomics)
         wcnt = __builtin_amdgcn_readfirstlane(wcnt);       // lanes past the chunk's end left the loop early
-        if (lane == 0) rl_wcnt[w] = wcnt;
-        __syncthreads();
-        {
-            uint32_t woff = 0, tot = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < kIcpBlock / 64; ++w2) {
-                const uint32_t c = rl_wcnt[w2];
-                if (w2 < w) woff += c;
-                tot += c;
-            }
-            for (uint32_t i = lane; i < wcnt; i += 64) seg[seg_count + woff + i] = rl_list[w][i];
-            seg_count += tot;
-        }
-        __syncthreads();
         // ---- phase A ----
         float acc[NACC];
 #pragma unroll
@@ -595,7 +581,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
         }
         partials[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = sum;
     }
-    if (threadIdx.x == 0) rlist[blockIdx.x] = seg_count;
+    if (lane == 0) rlist[blockIdx.x * kWavesPerBlock + w] = wcnt;
 }
 
 // Refine pass: the listed queries (a few thousand per iteration: Poisson tail, queries outside the
@@ -725,15 +711,17 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     // refine list = the main blocks' segments; exclusive scan of their counts (every block computes
     // the same scan), then query i -> (segment, local index) by binary search: balanced and
     // deterministic without a global counter
-    __shared__ uint32_t seg_off[kMaxPartialBlocks + 1];
+    constexpr int kSegPerRow = kIcpBlock / 64;                         // one segment per wave of a main block
+    const uint32_t n_segs = n_main_rows * kSegPerRow;
+    __shared__ uint32_t seg_off[kMaxPartialBlocks * kSegPerRow + 1];
     __shared__ uint32_t wave_tot[kRefineThreads / 64];
     {
         // thread t owns the `per` consecutive counts starting at t * per (per = 1 up to 1024 main blocks)
-        const uint32_t per = (n_main_rows + kRefineThreads - 1) / kRefineThreads;
+        const uint32_t per = (n_segs + kRefineThreads - 1) / kRefineThreads;
         uint32_t run = 0;
         for (uint32_t k = 0; k < per; ++k) {
             const uint32_t b = threadIdx.x * per + k;
-            run += b < n_main_rows ? rlist[b] : 0u;
+            run += b < n_segs ? rlist[b] : 0u;
         }
         uint32_t inc = run;                                 // inclusive scan over the block: wave scan + wave totals
 #pragma unroll
@@ -747,14 +735,14 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
         for (int w2 = 0; w2 < (int)(threadIdx.x >> 6); ++w2) ex += wave_tot[w2];
         for (uint32_t k = 0; k < per; ++k) {
             const uint32_t b = threadIdx.x * per + k;
-            if (b <= n_main_rows) seg_off[b] = ex;
-            ex += b < n_main_rows ? rlist[b] : 0u;
+            if (b <= n_segs) seg_off[b] = ex;
+            ex += b < n_segs ? rlist[b] : 0u;
         }
-        if (threadIdx.x == kRefineThreads - 1) seg_off[n_main_rows] = ex;    // total
+        if (threadIdx.x == kRefineThreads - 1) seg_off[n_segs] = ex;    // total
         __syncthreads();
     }
-    const uint32_t count = seg_off[n_main_rows];
-    const uint2 *__restrict__ entries = reinterpret_cast<const uint2 *>(rlist + kMaxPartialBlocks);     // (source index, best known position)
+    const uint32_t count = seg_off[n_segs];
+    const uint2 *__restrict__ entries = reinterpret_cast<const uint2 *>(rlist + kMaxPartialBlocks * kSegPerRow);     // (source index, best known position)
     if (blockIdx.x == 0 && threadIdx.x == 0) {             // statistics
         st->refine_total += count;
         st->refine_max = max(st->refine_max, count);
@@ -776,7 +764,7 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     for (uint32_t i = group; i < count; i += ngroups) {
         // segment of query i: last b with seg_off[b] <= i; kRG-ary search, one pivot per lane of the group
-        uint32_t lo = 0, nleft = n_main_rows;
+        uint32_t lo = 0, nleft = n_segs;
         while (nleft > 1) {
             const uint32_t stride = (nleft + kRG - 1) / kRG;
             const bool le = (uint32_t)lg * stride < nleft && seg_off[lo + lg * stride] <= i;     // true for a prefix of the lanes
@@ -1221,15 +1209,17 @@ struct IcpLaunch {
 };
 static IcpLaunch plan_launch(size_t ns) {
     IcpLaunch l;
-    // one point per lane for small clouds, up to kMaxPartialBlocks blocks; at 1 M points that is 1024
-    // points per block (4 per lane).  More, smaller blocks measured slower (per-block sums: 2048 blocks
-    // +7 %, 4096 +15 %); larger clouds get longer chunks (10 M points: no difference between 1024 and 4096 blocks).
-    uint32_t nb = (uint32_t)std::min<size_t>((ns + kIcpBlock - 1) / kIcpBlock, (size_t)kMaxPartialBlocks);
+    // ONE round of blocks: 4 blocks of 256 lanes per CU = 1024 resident blocks on 256 CUs; 1 M points: 977 blocks of
+    // 1024 points (4 per lane).  Measured alternatives at 1 M points (45 us): 6 blocks per CU x 768 points (80 VGPRs,
+    // 6 waves per SIMD, still one round): 48 us -- more waves do not pay for the extra per-block sums; any grid that
+    // needs a second round of blocks (e.g. 1303 blocks at 5 per CU): 54-62 us, the tail.
+    constexpr size_t kResidentBlocks = 4 * 256;
+    size_t chunk = (ns + kResidentBlocks - 1) / kResidentBlocks;
+    chunk = std::max<size_t>((chunk + kIcpBlock - 1) / kIcpBlock * kIcpBlock, kIcpBlock);
+    uint32_t nb = (uint32_t)((ns + chunk - 1) / chunk);
     nb = std::max<uint32_t>((nb + 7) / 8 * 8, 8);
-    uint32_t chunk = (uint32_t)((ns + nb - 1) / nb);
-    chunk = (chunk + kIcpBlock - 1) / kIcpBlock * kIcpBlock;
-    l.nblocks = nb; l.chunk = chunk;
-    l.mse_blocks = nb; l.mse_chunk = chunk;
+    l.nblocks = nb; l.chunk = (uint32_t)chunk;
+    l.mse_blocks = nb; l.mse_chunk = (uint32_t)chunk;
     return l;
 }
 
@@ -1263,7 +1253,7 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
         }
         ProfScope ps(ctx, "icp_refine");
         auto kern = mode == 1 ? icp_refine_kernel<1> : mode == 2 ? icp_refine_kernel<2> : icp_refine_kernel<0>;
-        hipLaunchKernelGGL(kern, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist, partials, l.nblocks, l.chunk,
+        hipLaunchKernelGGL(kern, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist, partials, l.nblocks, l.chunk / (kIcpBlock / 64),
                            refine_rows, src_cov);
     }
     if (do_sum || do_apply) {
@@ -1308,8 +1298,8 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &ctx->tgt_index.geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
     out.l = plan_launch(ns);
     if (tc_status s = ensure(ctx, ctx->partials, ((size_t)(kMaxPartialBlocks + kRefineBlocks) * TC_ICP_SUMS_STRIDE + 2) * sizeof(double))) return s;
-    // corr | corr_pos | refine counts (one per main block) | refine entries (uint2, one segment of `chunk` per main block)
-    if (tc_status s = ensure(ctx, ctx->corr, (2 * ns + kMaxPartialBlocks + 2 * (size_t)out.l.nblocks * out.l.chunk) * sizeof(uint32_t))) return s;
+    // corr | corr_pos | refine counts (one per wave of a main block) | refine entries (uint2, chunk / 4 per wave)
+    if (tc_status s = ensure(ctx, ctx->corr, (2 * ns + (size_t)kMaxPartialBlocks * (kIcpBlock / 64) + 2 * (size_t)out.l.nblocks * out.l.chunk) * sizeof(uint32_t))) return s;
     out.tv = view_of(ctx->tgt_index);
     return TC_OK;
 }

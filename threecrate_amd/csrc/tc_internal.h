@@ -67,7 +67,7 @@ constexpr int kIcpBlock = 256;
 // padding behind the sorted records / the prefix sums: the ICP search reads a few entries past a
 // span (4-wide steps) and 16-byte windows of cell_start without clamping
 constexpr size_t kPtsPad = 4, kCellStartPad = 4;
-constexpr int kMaxPartialBlocks = 1024;
+constexpr int kMaxPartialBlocks = 1024;         // plan_launch: one round of 4 blocks per CU
 
 // ---- device helpers -----------------------------------------------------------------------
 #if defined(__HIPCC__)
