@@ -47,6 +47,13 @@ class OracleBackend:
         return self._wrap(self.O.icp_point_to_plane_detailed, s, t, n, init, max_iters, max_dist, thr)
 
 
+    def gicp(self, s, t, init, max_iters=50, max_dist=1.0, thr=1e-6, k=20):
+        return self._wrap(self.O.gicp, s, t, init, max_iters, max_dist, thr, k)
+
+    def kiss_icp(self, s, t, init, voxel_size=1.0, max_range=100.0, min_range=0.5, max_iters=50):
+        return self._wrap(lambda: self.O.kiss_icp(s, t, init, voxel_size, max_range, min_range, max_iters)[0])
+
+
 class GpuBackend:
     name = "hip"
 
@@ -87,6 +94,14 @@ class GpuBackend:
 
     def icp_point_to_plane_detailed(self, s, t, n, init, max_iters, max_dist, thr):
         return self._wrap(self.ctx.icp_point_to_plane_detailed, s, t, n, init, max_iters, max_dist, thr)
+
+    def gicp(self, s, t, init, max_iters=50, max_dist=1.0, thr=1e-6, k=20):
+        import threecrate_amd as tc
+        return self._wrap(self.ctx.gicp, s, t, init, tc.GicpConfig(max_iters, max_dist, thr, k))
+
+    def kiss_icp(self, s, t, init, voxel_size=1.0, max_range=100.0, min_range=0.5, max_iters=50):
+        import threecrate_amd as tc
+        return self._wrap(self.ctx.kiss_icp, s, t, init, tc.KissIcpConfig(voxel_size, max_range, min_range, max_iters))
 
 
 def empty_cloud():

@@ -268,6 +268,139 @@ def p2pl_too_few_pairs(b):
     assert e.value.kind == "Algorithm"
 
 
+# ---- gicp.rs:307-583 ----------------------------------------------------------------------------
+def _sphere(n, radius):
+    """make_sphere (gicp.rs:318-333 / kiss_icp.rs tests): Fibonacci sphere of the given radius"""
+    pts, _ = sphere_cloud(n)
+    return (pts / np.float32(3.0) * np.float32(radius)).astype(np.float32)
+
+
+def _quat_axis(axis, angle):
+    h = np.float32(angle) / np.float32(2)
+    q = np.zeros(4, np.float32); q[axis] = np.sin(h); q[3] = np.cos(h)
+    return q
+
+
+def _rotate(q, pts):
+    from oracle import oracle as O            # isometry apply of the checker side: test infrastructure
+    T = np.concatenate([q, np.zeros(3, np.float32)]).astype(np.float32)
+    M = O.isometry_to_matrix(T).astype(np.float64)
+    return (pts.astype(np.float64) @ M[:3, :3].T).astype(np.float32)
+
+
+def _angle_between(qa, qb):
+    d = abs(float(np.dot(np.asarray(qa, np.float64) / np.linalg.norm(qa), np.asarray(qb, np.float64) / np.linalg.norm(qb))))
+    return 2.0 * np.arccos(min(1.0, d))
+
+
+def gicp_identity(b):
+    """gicp.rs test gicp_identity_converges"""
+    c = _sphere(100, 2.0)
+    r = b.gicp(c, c, IDENT, 30)
+    assert r.converged and r.mse < 1e-4
+
+
+def gicp_small_translation(b):
+    """gicp.rs test gicp_recovers_small_translation"""
+    s = _sphere(150, 3.0)
+    shift = np.array([0.1, 0.0, 0.0], np.float32)
+    r = b.gicp(s, s + shift, IDENT, 60, 2.0)
+    assert _mag(r.transformation[4:7] - shift) < 0.05 and r.mse < 0.1
+
+
+def gicp_tiny_rotation(b):
+    """gicp.rs test gicp_recovers_tiny_rotation_from_identity"""
+    s = _sphere(300, 3.0)
+    q = _quat_axis(2, np.deg2rad(2.0))
+    r = b.gicp(s, _rotate(q, s), IDENT, 60, 0.8)
+    assert _angle_between(r.transformation[:4], q) < np.deg2rad(0.5) and r.mse < 0.01
+
+
+def gicp_rotation_from_init(b):
+    """gicp.rs test gicp_refines_rotation_from_near_correct_init"""
+    s = _sphere(200, 3.0)
+    q = _quat_axis(2, np.deg2rad(8.0))
+    init = np.concatenate([_quat_axis(2, np.deg2rad(6.0)), np.zeros(3, np.float32)]).astype(np.float32)
+    r = b.gicp(s, _rotate(q, s), init, 60, 0.8)
+    assert _angle_between(r.transformation[:4], q) < np.deg2rad(0.5)
+
+
+def gicp_noise_and_outliers(b):
+    """gicp.rs tests gicp_robust_to_gaussian_noise / gicp_robust_to_outlier_points"""
+    s = _sphere(200, 3.0)
+    i = np.arange(200, dtype=np.float32)
+    noise = np.stack([np.sin(i * np.float32(1.6180339887)), np.cos(i * np.float32(2.7182818284)), np.sin(i * np.float32(3.1415926535))], 1) * np.float32(0.05)
+    r = b.gicp(s, (s + noise).astype(np.float32), IDENT, 50, 1.0)
+    assert r.mse < 0.05 and _mag(r.transformation[4:7]) < 0.1
+    t = np.arange(20, dtype=np.float32)
+    out = np.stack([t * np.float32(7.3) - 50, t * np.float32(3.1) - 30, t * np.float32(5.7) - 40], 1).astype(np.float32)
+    r = b.gicp(s, np.concatenate([s, out]), IDENT, 40, 0.5)
+    assert _mag(r.transformation[4:7]) < 0.05 and r.mse < 0.01
+
+
+def gicp_validation(b):
+    """gicp.rs tests gicp_empty_source_errors / zero_iterations / too_few_points / coplanar / result_fields_populated"""
+    c = _sphere(30, 1.0)
+    for args in ((empty_cloud(), c, IDENT), (c, c, IDENT, 0), (_sphere(10, 1.0), _sphere(10, 1.0), IDENT)):
+        with pytest.raises(BackendError):
+            b.gicp(*args)
+    flat = np.array([[i * 0.1, j * 0.1, 0.0] for i in range(50) for j in range(50)], np.float32)
+    with pytest.raises(BackendError):
+        b.gicp(flat, flat, IDENT)
+    c = _sphere(60, 2.0)
+    r = b.gicp(c, c, IDENT, 10)
+    assert r.iterations > 0 and len(r.correspondences) > 0
+
+
+# ---- kiss_icp.rs:302-671 ------------------------------------------------------------------------
+def _ring(n, rng_):
+    a = np.float32(2.0) * np.float32(np.pi) * np.arange(n, dtype=np.float32) / np.float32(n)
+    return np.stack([np.cos(a) * np.float32(rng_), np.sin(a) * np.float32(rng_), np.zeros(n, np.float32)], 1).astype(np.float32)
+
+
+def _grid(n, spacing, z):
+    side = int(np.ceil(np.sqrt(np.float32(n))))
+    pts = [[i * spacing, j * spacing, z] for i in range(side) for j in range(side)][:n]
+    return np.array(pts, np.float32)
+
+
+def kiss_identity(b):
+    """kiss_icp.rs test kiss_icp_identity_converges"""
+    c = _ring(200, 5.0)
+    r = b.kiss_icp(c, c, IDENT, 0.2, 50.0, 0.1, 30)
+    assert r.converged or r.mse < 1e-4
+
+
+def kiss_small_translation(b):
+    """kiss_icp.rs test kiss_icp_recovers_small_translation"""
+    s = _grid(100, 0.5, 5.0)
+    shift = np.array([0.1, 0.0, 0.0], np.float32)
+    r = b.kiss_icp(s, s + shift, IDENT, 0.2, 50.0, 0.1, 50)
+    assert _mag(r.transformation[4:7] - shift) < 0.05 and r.mse < 0.1
+
+
+def kiss_tiny_rotation(b):
+    """kiss_icp.rs test kiss_icp_recovers_tiny_rotation_from_identity"""
+    s = _sphere(300, 5.0)
+    q = _quat_axis(2, np.deg2rad(3.0))
+    r = b.kiss_icp(s, _rotate(q, s), IDENT, 0.5, 50.0, 0.1, 60)
+    assert _angle_between(r.transformation[:4], q) < np.deg2rad(1.0)
+
+
+def kiss_validation(b):
+    """kiss_icp.rs tests kiss_icp_empty_source_errors / all_points_outside_range / zero_voxel_size / result_fields_populated"""
+    c = _ring(30, 5.0)
+    with pytest.raises(BackendError):
+        b.kiss_icp(empty_cloud(), c, IDENT)
+    with pytest.raises(BackendError):
+        b.kiss_icp(_ring(50, 0.05), _ring(50, 0.05), IDENT, 1.0, 100.0, 0.5, 50)
+    with pytest.raises(BackendError):
+        b.kiss_icp(c, c, IDENT, 0.0)
+    c = _ring(60, 5.0)
+    r = b.kiss_icp(c, c, IDENT, 0.3, 50.0, 0.1, 10)
+    assert r.iterations > 0 and len(r.correspondences) > 0
+
+
 NORMALS_KATS = [normals_simple, normals_empty, normals_insufficient_k, normals_empty_wins_over_bad_k,
                 normals_cylinder, normals_orientation_consistency]
 NORMALS_RADIUS_KATS = [normals_radius]
@@ -275,4 +408,6 @@ ICP_KATS = [icp_identity, icp_translation, icp_rotation, icp_insufficient_points
             icp_swallows_errors, icp_p2p_basic, icp_p2p_with_noise, icp_p2p_known_transform, icp_p2p_convergence,
             icp_p2p_max_distance, icp_p2p_default, icp_p2p_validation]
 P2PL_KATS = [p2pl_identity, p2pl_translation, p2pl_validation, p2pl_vs_p2pt, p2pl_max_distance, p2pl_too_few_pairs]
-ALL_KATS = NORMALS_KATS + NORMALS_RADIUS_KATS + ICP_KATS + P2PL_KATS
+GICP_KATS = [gicp_identity, gicp_small_translation, gicp_tiny_rotation, gicp_rotation_from_init, gicp_noise_and_outliers, gicp_validation]
+KISS_KATS = [kiss_identity, kiss_small_translation, kiss_tiny_rotation, kiss_validation]
+ALL_KATS = NORMALS_KATS + NORMALS_RADIUS_KATS + ICP_KATS + P2PL_KATS + GICP_KATS + KISS_KATS

@@ -12,7 +12,7 @@ def backend(ctx):
     return GpuBackend(ctx)
 
 
-@pytest.mark.parametrize("kat", kats.NORMALS_KATS + kats.ICP_KATS + kats.P2PL_KATS, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("kat", kats.NORMALS_KATS + kats.ICP_KATS + kats.P2PL_KATS + kats.GICP_KATS + kats.KISS_KATS, ids=lambda f: f.__name__)
 def test_reference_kat(backend, kat):
     kat(backend)
 
