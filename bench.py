@@ -228,6 +228,21 @@ def main():
         wall, tn, ti = [float(v) for v in tw.tolist()]
 
     if rank == 0:
+        # what a plain device-to-device copy reaches on this box (report next to the 8 TB/s vendor peak)
+        copy_gbs = None
+        try:
+            a, b = torch.empty(1 << 28, dtype=torch.float32, device=dev), torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9      # read + write
+            del a, b
+        except Exception:
+            pass
         # HBM traffic of the dominant kernel: measured separately with rocprofv3 --pmc (a PMC pass cannot
         # run inside this process); the committed summary is reported with its provenance
         traffic, traffic_note = None, None
@@ -261,7 +276,8 @@ def main():
             "icp_only_it_per_s": ICP_ITERS * args.steps * world / ti,
             "roofline": {"bound": "hbm", "kernel": k, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_note,
-                         "alg_bytes_per_launch": ALG_BYTES_ICP * n, "avg_launch_us": avg_s * 1e6, "launches": launches},
+                         "alg_bytes_per_launch": ALG_BYTES_ICP * n, "avg_launch_us": avg_s * 1e6, "launches": launches,
+                         "measured_copy_gbs": copy_gbs},
             "kernels_us_avg": {kk: round(1e3 * ms / max(c, 1), 2) for kk, (c, ms) in stats.items()},
             "final_mse": last.mse,
         }

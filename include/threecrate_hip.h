@@ -281,7 +281,8 @@ tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t 
  * (threecrate-algorithms/src/filtering.rs:38-133): one f32 centroid per occupied voxel, keys
  * floor((p - bbox_min) / voxel_size), f64 sums in input order.  The reference's output order is
  * unspecified (HashMap); here voxels come out sorted by (kx, ky, kz).  out: capacity n x 3.
- * n == 0 -> TC_OK; voxel_size <= 0 -> TC_INVALID_DATA; > 2^25 voxels in the bbox -> TC_UNSUPPORTED. */
+ * n == 0 -> TC_OK; voxel_size <= 0 -> TC_INVALID_DATA; 2^21 or more voxels along one
+ * axis of the bbox -> TC_UNSUPPORTED. */
 tc_status tc_voxel_grid_filter(tc_context *ctx, const float *xyz, size_t n, float voxel_size,
                                float *out_xyz, size_t *n_out);
 tc_status tc_voxel_grid_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float voxel_size,

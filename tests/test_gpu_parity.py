@@ -3,6 +3,9 @@
 Tolerances are the ones BASELINE.json's north_star states: normals within 1e-4 cosine,
 ICP transform within 1e-5 Frobenius (4x4 homogeneous matrix).
 """
+import csv
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -306,6 +309,26 @@ def test_voxel_grid_filter_kats_and_errors(ctx):
     assert np.array_equal(d.cpu().numpy(), O.voxel_grid_filter(frame, 0.2))
 
 
+def test_voxel_grid_filter_sorted_path_bit_exact(ctx):
+    """the radix-sort path of voxel_grid_filter: (a) ~1000 points per voxel (depth frame, 0.2 m voxels), (b) a bounding box
+    of > 2^25 voxels (0.05 m voxels on a LiDAR sweep: the finest level of the reference's default multiscale pyramid,
+    registration.rs:54-69), (c) two far-apart clusters: 8000^3 voxels in the box; (d) > 2^21 voxels along an axis"""
+    import threecrate_amd as tc
+    frame = synth.tum_shaped_cloud(seed=3, step=3)
+    frame = (frame + np.random.default_rng(0).normal(0, 1e-4, frame.shape)).astype(np.float32)
+    for cloud, voxel in ((frame, 0.2), (synth.kitti_shaped_cloud(seed=3), 0.05)):
+        g, r = ctx.voxel_grid_filter(cloud, voxel), O.voxel_grid_filter(cloud, voxel)
+        assert g.shape == r.shape and np.array_equal(g, r)
+    a = synth.uniform_cloud(20000, 8)
+    two = np.concatenate([a, a[::-1] + np.float32(400.0)]).astype(np.float32)
+    g, r = ctx.voxel_grid_filter(two, 0.05), O.voxel_grid_filter(two, 0.05)
+    assert g.shape == r.shape and np.array_equal(g, r)
+    d = ctx.voxel_grid_filter(torch.from_numpy(two).cuda(), 0.05)
+    assert np.array_equal(d.cpu().numpy(), r)
+    with pytest.raises(tc.Unsupported):
+        ctx.voxel_grid_filter(np.array([[0, 0, 0], [3e5, 100, 0]], np.float32), 0.1)
+
+
 @pytest.mark.parametrize("k", [1, 3, 8, 17, 32])
 def test_knn_export_matches_kdtree(ctx, k):
     """find_k_nearest (nearest_neighbor.rs:177-251): same neighbour sets, bit-identical distances,
@@ -488,3 +511,25 @@ def test_radius_search_export_matches_kdtree(ctx):
     assert (gc == 0).all()
     res = ctx.find_radius_neighbors(pts, pts[7], 0.02)
     assert res[0] == (7, 0.0) and all(d <= 0.02 for _, d in res)
+
+
+@pytest.mark.gpu
+def test_dataset_bench_emits_reference_csv_row(tmp_path, capsys):
+    """tools/dataset_bench.py: the reference harness' flags and CSV columns (threecrate_dataset_bench.rs:93-113),
+    from a KITTI .bin file written here"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dataset_bench", os.path.join(os.path.dirname(__file__), "..", "tools", "dataset_bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pts = synth.uniform_cloud(3000, 5, (10.0, 10.0, 2.0))
+    rec = np.concatenate([pts, np.zeros((len(pts), 1), np.float32)], axis=1).astype("<f4")
+    path = tmp_path / "000000.bin"
+    rec.tofile(path)
+    for task in ("voxel", "normals", "icp", "multiscale_icp", "knn"):
+        mod.main(["--task", task, "--dataset", "unit,test", "--source", str(path), "--iterations", "2", "--warmups", "1",
+                  "--max-points", "2000", "--max-icp-iters", "5"])
+        out = capsys.readouterr().out.strip().splitlines()
+        assert out[0] == "library,task,dataset,source_points,target_points,output_points,iterations,median_ms,min_ms,mean_ms,detail"
+        row = next(csv.reader([out[1]]))
+        assert row[:5] == ["threecrate-hip", task, "unit,test", "2000", "2000"] and row[6] == "2" and len(row) == 11
+        assert float(row[8]) <= float(row[7]) and int(row[5]) > 0
