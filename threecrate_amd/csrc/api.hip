@@ -85,7 +85,7 @@ static float normals_target_ppo(size_t k) {
 static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, float *d_out) {
     // radius mode: ring 2 must cover the radius ball, so the cell edge is at least radius / 2
     const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
-    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(cfg->k_neighbors, n >= (1u << 18)), nullptr, nullptr, nullptr, min_h,
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(cfg->k_neighbors, n >= kAdaptMinPoints), nullptr, nullptr, nullptr, min_h,
                                   normals_target_ppo(cfg->k_neighbors))) return s;
     float vp[3];
     if (cfg->has_viewpoint) {

@@ -341,7 +341,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     // Only for clouds of >= 2^18 points: the check costs a host synchronisation at the end of the build
     // (~15 us of launch bubble), which a 24 k-point LiDAR frame pipeline feels (-14 % frames/s) and a
     // 1 M-point cloud does not (-0.5 %), while the gain scales with the cloud (TUM-shaped 1 M: 2-3x).
-    const bool adapt = target_ppo > 0.0f && !reuse_geom && !tile_major && n >= (1u << 18) && !(dbg & 512);
+    const bool adapt = target_ppo > 0.0f && !reuse_geom && !tile_major && n >= kAdaptMinPoints && !(dbg & 512);
     for (int attempt = 0;; ++attempt) {
         const GridGeom g = ix.geom;
         TileGeom tg{};
