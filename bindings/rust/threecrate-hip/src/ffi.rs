@@ -4,6 +4,7 @@ use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)] pub struct tc_context { _private: [u8; 0] }
 #[repr(C)] pub struct tc_frame_stream { _private: [u8; 0] }
+#[repr(C)] pub struct tc_search_index { _private: [u8; 0] }
 
 pub const TC_OK: c_int = 0;
 pub const TC_INVALID_DATA: c_int = 1;
@@ -92,6 +93,11 @@ extern "C" {
                   idx: *mut u32, dist: *mut f32, count: *mut u32) -> c_int;
     pub fn tc_radius_search(ctx: *mut tc_context, cloud: *const f32, n: usize, queries: *const f32, nq: usize, radius: f32, k_max: usize,
                             idx: *mut u32, dist: *mut f32, count: *mut u32) -> c_int;
+    pub fn tc_search_index_create(ctx: *mut tc_context, cloud: *const f32, n: usize, k_hint: usize, out: *mut *mut tc_search_index) -> c_int;
+    pub fn tc_search_index_size(index: *const tc_search_index) -> usize;
+    pub fn tc_search_index_query(index: *mut tc_search_index, queries: *const f32, nq: usize, k: usize, radius: f32,
+                                 idx: *mut u32, dist: *mut f32, count: *mut u32) -> c_int;
+    pub fn tc_search_index_destroy(index: *mut tc_search_index);
     pub fn tc_voxel_grid_filter(ctx: *mut tc_context, xyz: *const f32, n: usize, voxel_size: f32, out: *mut f32, n_out: *mut usize) -> c_int;
     pub fn tc_frame_stream_create(ctx: *mut tc_context, cfg: *const tc_frame_stream_config, out: *mut *mut tc_frame_stream) -> c_int;
     pub fn tc_frame_stream_send(s: *mut tc_frame_stream, frame: *const f32, n: usize, stride_floats: usize) -> c_int;

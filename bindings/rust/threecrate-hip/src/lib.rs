@@ -12,7 +12,7 @@ pub mod ffi;
 use nalgebra::{Isometry3, Quaternion, Translation3, UnitQuaternion};
 use std::ffi::CStr;
 use threecrate_algorithms::{GicpConfig, ICPResult, KissIcpConfig, NormalEstimationConfig};
-use threecrate_core::{Error, NormalPoint3f, Point3f, PointCloud, Result, Vector3f};
+use threecrate_core::{Error, NearestNeighborSearch, NormalPoint3f, Point3f, PointCloud, Result, Vector3f};
 
 /// One HIP device + stream + the library's grow-only device buffers (`tc_context`).
 pub struct HipContext(*mut ffi::tc_context);
@@ -231,6 +231,56 @@ pub fn find_k_nearest_batch(ctx: &HipContext, points: &[Point3f], queries: &[Poi
                     dist.as_mut_ptr(), cnt.as_mut_ptr())
     })?;
     Ok((0..nq).map(|q| (0..cnt[q] as usize).map(|j| (idx[q * kk + j] as usize, dist[q * kk + j])).collect()).collect())
+}
+
+/// The `KdTree` of this backend: built once, queried many times (`KdTree::new`, nearest_neighbor.rs:37-58).
+/// Implements `threecrate_core::NearestNeighborSearch` (core/traits.rs:6-12), so it drops into code that is generic
+/// over the trait.  Borrows the context: destroy order is enforced by the lifetime.
+pub struct HipKdTree<'a> {
+    ctx: &'a HipContext,
+    raw: *mut ffi::tc_search_index,
+}
+
+impl<'a> HipKdTree<'a> {
+    pub fn new(ctx: &'a HipContext, points: &[Point3f]) -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        ctx.check(unsafe { ffi::tc_search_index_create(ctx.0, points.as_ptr() as *const f32, points.len(), 16, &mut raw) })?;
+        Ok(Self { ctx, raw })
+    }
+
+    pub fn len(&self) -> usize { unsafe { ffi::tc_search_index_size(self.raw) } }
+    pub fn is_empty(&self) -> bool { self.len() == 0 }
+
+    fn query(&self, queries: &[Point3f], k: usize, radius: f32) -> Result<Vec<Vec<(usize, f32)>>> {
+        let nq = queries.len();
+        let kk = k.max(1);
+        let (mut idx, mut dist, mut cnt) = (vec![0u32; nq * kk], vec![0f32; nq * kk], vec![0u32; nq.max(1)]);
+        self.ctx.check(unsafe {
+            ffi::tc_search_index_query(self.raw, queries.as_ptr() as *const f32, nq, k, radius, idx.as_mut_ptr(), dist.as_mut_ptr(), cnt.as_mut_ptr())
+        })?;
+        Ok((0..nq).map(|q| (0..cnt[q] as usize).map(|j| (idx[q * kk + j] as usize, dist[q * kk + j])).collect()).collect())
+    }
+
+    /// many queries in one launch
+    pub fn find_k_nearest_batch(&self, queries: &[Point3f], k: usize) -> Result<Vec<Vec<(usize, f32)>>> {
+        self.query(queries, k, -1.0)
+    }
+}
+
+impl NearestNeighborSearch for HipKdTree<'_> {
+    fn find_k_nearest(&self, query: &Point3f, k: usize) -> Vec<(usize, f32)> {
+        self.query(std::slice::from_ref(query), k.min(self.len()).min(65), -1.0).map(|mut v| v.remove(0)).unwrap_or_default()
+    }
+
+    /// the neighbours within `radius`, nearest first; at most the 65 nearest (limit of the backend's selection lists)
+    fn find_radius_neighbors(&self, query: &Point3f, radius: f32) -> Vec<(usize, f32)> {
+        if !(radius > 0.0) { return Vec::new(); }
+        self.query(std::slice::from_ref(query), self.len().min(65), radius).map(|mut v| v.remove(0)).unwrap_or_default()
+    }
+}
+
+impl Drop for HipKdTree<'_> {
+    fn drop(&mut self) { unsafe { ffi::tc_search_index_destroy(self.raw) } }
 }
 
 // ---- threecrate-gpu facade (gpu/normals.rs:443-447, gpu/icp.rs:977-1025) ---------------------------------------

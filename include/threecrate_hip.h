@@ -276,6 +276,25 @@ tc_status tc_radius_search(tc_context *ctx, const float *cloud, size_t n, const 
 tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, float radius,
                                   size_t k_max, uint32_t *d_idx, float *d_dist, uint32_t *d_count);
 
+/* ---- persistent search index (the NearestNeighborSearch object) ----
+ * KdTree::new(&points) once (threecrate-algorithms/src/nearest_neighbor.rs:37-58), then any number of
+ * find_k_nearest / find_radius_neighbors calls (threecrate-core/src/traits.rs:6-12; Python `KdTree`
+ * threecrate-python/src/lib.rs:707-776).  The handle owns a cell-sorted copy of the cloud and its grid in device
+ * memory; the caller's buffer is not referenced after create.  k_hint sizes the cells (any k <= 65 is answered
+ * exactly whatever the hint).  An empty cloud gives an empty index (every count = 0), like the reference.
+ * query: radius < 0 -> the k nearest; radius >= 0 -> the neighbours with distance <= radius among the k nearest
+ * (count[q] == k means there may be more).  Rows of idx / dist (nq x k) ascending by distance = sqrt(d2).
+ * A handle belongs to its context (same thread rule); destroy it before the context. */
+typedef struct tc_search_index tc_search_index;
+tc_status tc_search_index_create(tc_context *ctx, const float *cloud, size_t n, size_t k_hint, tc_search_index **out);
+tc_status tc_search_index_create_device(tc_context *ctx, const float *d_cloud, size_t n, size_t k_hint, tc_search_index **out);
+size_t tc_search_index_size(const tc_search_index *index);
+tc_status tc_search_index_query(tc_search_index *index, const float *queries, size_t nq, size_t k, float radius,
+                                uint32_t *idx, float *dist, uint32_t *count);
+tc_status tc_search_index_query_device(tc_search_index *index, const float *d_queries, size_t nq, size_t k, float radius,
+                                       uint32_t *d_idx, float *d_dist, uint32_t *d_count);
+void tc_search_index_destroy(tc_search_index *index);
+
 /* ---- voxel_grid_filter ----
  * voxel_grid_filter(&PointCloud<Point3f>, voxel_size) -> Result<PointCloud<Point3f>>
  * (threecrate-algorithms/src/filtering.rs:38-133): one f32 centroid per occupied voxel, keys

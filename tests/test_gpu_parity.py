@@ -533,3 +533,33 @@ def test_dataset_bench_emits_reference_csv_row(tmp_path, capsys):
         row = next(csv.reader([out[1]]))
         assert row[:5] == ["threecrate-hip", task, "unit,test", "2000", "2000"] and row[6] == "2" and len(row) == 11
         assert float(row[8]) <= float(row[7]) and int(row[5]) > 0
+
+
+def test_search_index_handle_matches_one_shot_calls(ctx):
+    """tc_search_index_*: build once, query many times (NearestNeighborSearch, core/traits.rs:6-12) == the one-shot
+    exports and the kd-tree oracle; host and device queries; empty index; k above the hint"""
+    pts = synth.uniform_cloud(30000, 21, (4.0, 3.0, 1.0))
+    q = np.concatenate([pts[:200], synth.uniform_cloud(100, 22, (6.0, 4.0, 2.0)) - np.float32(0.5)]).astype(np.float32)
+    ix = tc.SearchIndex(ctx, pts, k_hint=8)
+    assert len(ix) == len(pts)
+    for k in (1, 8, 40):
+        i1, d1, c1 = ix.find_k_nearest_batch(q, k)
+        i0, d0, c0 = ctx.find_k_nearest_batch(pts, q, k)
+        assert np.array_equal(c1, c0) and np.array_equal(d1, d0) and np.array_equal(i1, i0)
+    _, rd, _ = O.knn_batch(pts, q, 8)
+    i1, d1, _ = ix.find_k_nearest_batch(q, 8)
+    assert np.array_equal(d1, rd)
+    it, dt, ct = ix.find_k_nearest_batch(torch.from_numpy(q).cuda(), 8)
+    assert np.array_equal(dt.cpu().numpy(), d1) and np.array_equal(it.cpu().numpy().astype(np.int64), i1)
+    ir, dr, cr = ix.find_radius_neighbors_batch(q, 0.15, 32)
+    i0, d0, c0 = ctx.find_radius_neighbors_batch(pts, q, 0.15, 32)
+    assert np.array_equal(cr, c0) and all(np.array_equal(dr[j, :cr[j]], d0[j, :c0[j]]) for j in range(len(q)))
+    assert ix.find_k_nearest(pts[5], 3)[0] == (5, 0.0)
+    dev = tc.SearchIndex(ctx, torch.from_numpy(pts).cuda())
+    assert np.array_equal(dev.find_k_nearest_batch(q, 8)[1], d1)
+    empty = tc.SearchIndex(ctx, np.zeros((0, 3), np.float32))
+    assert len(empty) == 0 and empty.find_k_nearest_batch(q, 4)[2].sum() == 0
+    with pytest.raises(tc.Unsupported):
+        ix.find_k_nearest_batch(q, 66)
+    for h in (ix, dev, empty):
+        h.close()

@@ -652,6 +652,73 @@ class FrameStream:
             pass
 
 
+class SearchIndex:
+    """Persistent neighbour-search object (tc_search_index_*): KdTree::new once (nearest_neighbor.rs:37-58), then
+    find_k_nearest / find_radius_neighbors (core/traits.rs:6-12) for any number of queries against the same cloud.
+    The cloud (numpy or torch-on-device) is copied, cell-sorted, into device memory owned by the handle."""
+
+    def __init__(self, ctx: "GpuContext", cloud, k_hint: int = 16):
+        self._ctx, self._L = ctx, _lib.load()
+        h = C.c_void_p()
+        if _is_torch(cloud):
+            import torch
+            x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            ctx._check(self._L.tc_search_index_create_device(ctx._h, x.data_ptr(), x.shape[0], int(k_hint), C.byref(h)))
+        else:
+            x = _as_host(cloud)
+            ctx._check(self._L.tc_search_index_create(ctx._h, x.ctypes.data, x.shape[0], int(k_hint), C.byref(h)))
+        self._h = h
+
+    def __len__(self):
+        return int(self._L.tc_search_index_size(self._h))
+
+    def _query(self, queries, k, radius):
+        kk = max(int(k), 1)
+        if _is_torch(queries):
+            import torch
+            q = queries.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            idx = torch.zeros((q.shape[0], kk), dtype=torch.int32, device=q.device)
+            dist = torch.zeros((q.shape[0], kk), dtype=torch.float32, device=q.device)
+            cnt = torch.zeros(q.shape[0], dtype=torch.int32, device=q.device)
+            self._ctx._check(self._L.tc_search_index_query_device(self._h, q.data_ptr(), q.shape[0], int(k), float(radius), idx.data_ptr(),
+                                                                  dist.data_ptr(), cnt.data_ptr()))
+            return idx, dist, cnt
+        q = _as_host(queries)
+        idx = np.zeros((len(q), kk), np.uint32)
+        dist = np.zeros((len(q), kk), np.float32)
+        cnt = np.zeros(len(q), np.uint32)
+        self._ctx._check(self._L.tc_search_index_query(self._h, q.ctypes.data, q.shape[0], int(k), float(radius), idx.ctypes.data,
+                                                       dist.ctypes.data, cnt.ctypes.data))
+        return idx.astype(np.int64), dist, cnt
+
+    def find_k_nearest_batch(self, queries, k: int):
+        """(idx (nq, k), dist (nq, k), count (nq,)); rows ascending by distance, entries past count[q] undefined"""
+        return self._query(queries, k, -1.0)
+
+    def find_radius_neighbors_batch(self, queries, radius: float, k_max: int = 32):
+        """the neighbours within radius among the k_max nearest; count[q] == k_max: there may be more"""
+        return self._query(queries, k_max, max(float(radius), 0.0))
+
+    def find_k_nearest(self, query, k: int):
+        idx, dist, cnt = self.find_k_nearest_batch(np.asarray(query, np.float32).reshape(1, 3), k)
+        return [(int(idx[0, i]), float(dist[0, i])) for i in range(int(cnt[0]))]
+
+    def find_radius_neighbors(self, query, radius: float, k_max: int = 32):
+        idx, dist, cnt = self.find_radius_neighbors_batch(np.asarray(query, np.float32).reshape(1, 3), radius, k_max)
+        return [(int(idx[0, i]), float(dist[0, i])) for i in range(int(cnt[0]))]
+
+    def close(self):
+        if self._h:
+            self._L.tc_search_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def read_kitti_bin(path):
     """VelodyneKittiBinReader::read (threecrate-io/src/lidar.rs:310-343) -> (n, 3) float32."""
     L = _lib.load()

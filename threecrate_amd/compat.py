@@ -160,32 +160,31 @@ def _query3(query):
 
 
 class KdTree:
-    """Spatial index over a cloud (lib.rs:707-776).  Every query runs the grid k-NN kernel over the cloud (the index is
-    rebuilt per call: batch queries through GpuContext.find_k_nearest_batch are the efficient form); results as
-    KdTree::find_k_nearest / find_radius_neighbors (nearest_neighbor.rs:177-298), radius results nearest first."""
+    """Spatial index over a cloud (lib.rs:707-776): built once (a device-resident grid index, tc_search_index_*), then
+    queried; results as KdTree::find_k_nearest / find_radius_neighbors (nearest_neighbor.rs:177-298), radius results
+    nearest first."""
 
     _K_MAX = 65            # register-list instantiations of the k-NN kernel
 
     def __init__(self, cloud):
-        self._ctx = _api.default_context()
-        self._p = cloud._p                   # an empty cloud gives an empty tree (nearest_neighbor.rs:38-45)
+        self._n = len(cloud)                 # an empty cloud gives an empty tree (nearest_neighbor.rs:38-45)
+        self._ix = _run(_api.SearchIndex, _api.default_context(), cloud._p)
 
     def knn(self, query, k):
         q = _query3(query)
-        if k == 0 or len(self._p) == 0:      # nearest_neighbor.rs:178-180
+        if k == 0 or self._n == 0:           # nearest_neighbor.rs:178-180
             return [], []
-        idx, dist, cnt = _run(self._ctx.find_k_nearest_batch, self._p, q.reshape(1, 3), min(int(k), len(self._p)))
-        c = int(cnt[0])
-        return [int(v) for v in idx[0, :c]], [float(v) for v in dist[0, :c]]
+        pairs = _run(self._ix.find_k_nearest, q, min(int(k), self._n))
+        return [i for i, _ in pairs], [d for _, d in pairs]
 
     def radius_search(self, query, radius):
         q = _query3(query)
-        if len(self._p) == 0:
+        if self._n == 0:
             return [], []
-        pairs = _run(self._ctx.find_radius_neighbors, self._p, q, float(radius), min(self._K_MAX, len(self._p)))
+        pairs = _run(self._ix.find_radius_neighbors, q, float(radius), min(self._K_MAX, self._n))
         if len(pairs) >= self._K_MAX:
             raise RuntimeError(f"radius_search: {self._K_MAX} or more neighbours within the radius (limit of this backend)")
-        return [int(i) for i, _ in pairs], [float(d) for _, d in pairs]
+        return [i for i, _ in pairs], [d for _, d in pairs]
 
     def __repr__(self):
         return "KdTree"

@@ -620,6 +620,97 @@ tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *que
     return TC_OK;
 }
 
+// ---- persistent search index: KdTree::new once, many find_k_nearest / find_radius_neighbors calls --------------
+// (threecrate-core/src/traits.rs:6-12; nearest_neighbor.rs:37-58, :177-298; Python KdTree lib.rs:707-776)
+}  // extern "C" (reopened below)
+
+struct tc_search_index {
+    tc_context *ctx;
+    tc::DeviceIndex ix;
+    size_t n;
+    tc::DevBuf q, out;          // staged queries / results of the host-buffer calls
+};
+
+extern "C" {
+
+tc_status tc_search_index_create_device(tc_context *ctx, const float *d_cloud, size_t n, size_t k_hint, tc_search_index **out) {
+    if (!ctx || !out) return TC_INVALID_DATA;
+    *out = nullptr;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    tc_search_index *s = new tc_search_index{ctx, {}, n, {}, {}};
+    if (n) {        // an empty cloud is an empty tree (nearest_neighbor.rs:38-45)
+        const size_t k = std::min<size_t>(std::max<size_t>(k_hint, 1), 65);
+        tc_status rc = build_index(ctx, s->ix, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1) * 2.0f, nullptr, nullptr);
+        if (rc == TC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, TC_GPU, "search index build failed");
+        if (rc != TC_OK) { free_index(s->ix); delete s; return rc; }
+    }
+    *out = s;
+    return TC_OK;
+}
+
+tc_status tc_search_index_create(tc_context *ctx, const float *cloud, size_t n, size_t k_hint, tc_search_index **out) {
+    if (!ctx || !out) return TC_INVALID_DATA;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n) {
+        if (tc_status s = ensure(ctx, ctx->in_a, n * 3 * sizeof(float))) return s;
+        TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, cloud, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    return tc_search_index_create_device(ctx, (const float *)ctx->in_a.p, n, k_hint, out);   // the index holds its own sorted copy
+}
+
+size_t tc_search_index_size(const tc_search_index *s) { return s ? s->n : 0; }
+
+// radius < 0: k nearest; radius >= 0: the neighbours within radius among the k nearest
+tc_status tc_search_index_query_device(tc_search_index *s, const float *d_queries, size_t nq, size_t k, float radius,
+                                       uint32_t *d_idx, float *d_dist, uint32_t *d_count) {
+    if (!s) return TC_INVALID_DATA;
+    tc_context *ctx = s->ctx;
+    if (nq == 0) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool by_radius = radius >= 0.0f;
+    if (k == 0 || s->n == 0 || (by_radius && !(radius > 0.0f))) {        // nearest_neighbor.rs:178-180, :255-257
+        TC_HIP_TRY(ctx, hipMemsetAsync(d_count, 0, nq * sizeof(uint32_t), ctx->stream));
+        TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return TC_OK;
+    }
+    if (k > 65) return fail(ctx, TC_UNSUPPORTED, "k > 65 is not supported by the HIP neighbour search");
+    if (nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    if (tc_status rc = launch_knn(ctx, s->ix, d_queries, nq, k, d_idx, d_dist, d_count, by_radius ? radius * radius : INFINITY)) return rc;
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+tc_status tc_search_index_query(tc_search_index *s, const float *queries, size_t nq, size_t k, float radius, uint32_t *idx, float *dist,
+                                uint32_t *count) {
+    if (!s) return TC_INVALID_DATA;
+    tc_context *ctx = s->ctx;
+    if (nq == 0) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (k == 0 || s->n == 0) { std::memset(count, 0, nq * sizeof(uint32_t)); return TC_OK; }
+    if (tc_status rc = ensure(ctx, s->q, nq * 3 * sizeof(float))) return rc;
+    if (tc_status rc = ensure(ctx, s->out, nq * k * 8 + nq * 4)) return rc;
+    uint32_t *d_idx = (uint32_t *)s->out.p;
+    float *d_dist = (float *)(d_idx + nq * k);
+    uint32_t *d_cnt = (uint32_t *)(d_dist + nq * k);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(s->q.p, queries, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (tc_status rc = tc_search_index_query_device(s, (const float *)s->q.p, nq, k, radius, d_idx, d_dist, d_cnt)) return rc;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(idx, d_idx, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(count, d_cnt, nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+void tc_search_index_destroy(tc_search_index *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    free_index(s->ix);
+    free_buf(s->q); free_buf(s->out);
+    delete s;
+}
+
 // ---- voxel_grid_filter (filtering.rs:38-133) --------------------------------------------------
 static tc_status voxel_validate(tc_context *ctx, size_t n, float voxel, size_t *n_out, bool *empty) {
     *empty = false;
