@@ -26,6 +26,8 @@
 // Algorithmic HBM bytes per point: 12 (query) + 12*k (neighbours) + 24 (out).
 #include "tc_internal.h"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -138,9 +140,12 @@ __device__ __forceinline__ float axis_gap_n(float q, float mn, float h, int c) {
 // visit the records of the cells of block [c-R, c+R]^3 that (a) lie outside block [c-Rin, c+Rin]^3
 // (Rin < 0: none excluded) and (b) whose box is within sqrt(lim) of q (ball pruning).  Returns
 // whether any cell qualified.
-template <typename F>
+// `relim` (optional): called after every row that held records; returns the new limit (a growing block scanned
+// with an infinite limit starts pruning as soon as the list is full).
+struct KeepLimit { __device__ float operator()(float lim) const { return lim; } };
+template <typename F, typename U = KeepLimit>
 __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q, int cx, int cy, int cz, int Rin, int R,
-                                            const float lim, F &&f) {
+                                            float lim, F &&f, U &&relim = KeepLimit()) {
     const GridGeom &g = gv.g;
     const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
     const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
@@ -167,6 +172,7 @@ __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q,
             };
             if (!inner_row) span(xa, xb);
             else { span(xa, min(xb, cx - Rin - 1)); span(max(xa, cx + Rin + 1), xb); }   // only the cells outside the inner block
+            if constexpr (!std::is_same<typename std::decay<U>::type, KeepLimit>::value) lim = relim(lim);
         }
     }
     return touched;
@@ -232,9 +238,17 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         // not provably exact (grid-boundary points, Poisson tail): continue IN PLACE with the next
         // shell, visiting only the cells the ball of the current bound can reach.  The ball clipped to
         // the grid box is convex and contains the query, so a shell that misses it ends the search.
-        ++R;
+        // While the list is not full nothing can be pruned anyway, so the block may grow by half its radius at
+        // a time instead of one ring: an isolated point D cells from its neighbours pays ~D^2 row visits, not D^3.
+        const int Rin = R;
+        R += (tau == INFINITY) ? max(1, R / 2) : 1;
         const float need2 = RADIUS ? fmaxf(r2, 0.0f) : 0.0f;     // radius mode must also see the whole radius ball
-        const bool touched = scan_pruned(gv, q, cx, cy, cz, R - 1, R, fmaxf(tau, need2), visit1);
+        // one call site for both cases (lanes of a wave differ): only the growing lanes refresh their limit
+        const bool growing = tau == INFINITY;
+        const bool touched = scan_pruned(gv, q, cx, cy, cz, Rin, R, fmaxf(tau, need2), visit1, [&](float l) {
+            if (growing) { float t_; TC_KTH(t_); l = fmaxf(t_, need2); }
+            return l;
+        });
         if (!touched) { TC_KTH(tau); use_radius = RADIUS && cnt_r >= prm.k; break; }
     }
 
@@ -393,8 +407,18 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
                             (cz - R <= 0) && (cz + R >= g.gz - 1);
         const float bound = ((float)R + mf - 2e-3f) * g.h;
         if (covers || tau <= bound * bound + out2) break;
-        ++R;
-        if (!scan_pruned(gv, q, cx, cy, cz, R - 1, R, tau, visit1)) {
+        const int Rin = R;
+        R += (tau == INFINITY) ? max(1, R / 2) : 1;              // see normals_point
+        const bool growing = tau == INFINITY;
+        const bool touched = scan_pruned(gv, q, cx, cy, cz, Rin, R, tau, visit1, [&](float l) {
+            if (growing) {
+                l = d[0];
+#pragma unroll
+                for (int i = 1; i < L; ++i) l = ((uint32_t)i == K1 - 1) ? d[i] : l;
+            }
+            return l;
+        });
+        if (!touched) {
             tau = d[0];
 #pragma unroll
             for (int i = 1; i < L; ++i) tau = ((uint32_t)i == K1 - 1) ? d[i] : tau;
