@@ -91,9 +91,9 @@ static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, c
     if (cfg->has_viewpoint) {
         vp[0] = cfg->viewpoint[0]; vp[1] = cfg->viewpoint[1]; vp[2] = cfg->viewpoint[2];
     } else {   // normals.rs:275-303 (f32, same operation order; min/max are order independent)
-        const GridGeom &g = ctx->tgt_index.geom;
-        const float cx = (g.minx + g.maxx) / 2.0f, cy = (g.miny + g.maxy) / 2.0f, cz = (g.minz + g.maxz) / 2.0f;
-        const float ex = g.maxx - g.minx, ey = g.maxy - g.miny, ez = g.maxz - g.minz;
+        const float *bmn = ctx->tgt_index.exact_min, *bmx = ctx->tgt_index.exact_max;      // the cloud's exact box (the grid's may be clamped)
+        const float cx = (bmn[0] + bmx[0]) / 2.0f, cy = (bmn[1] + bmx[1]) / 2.0f, cz = (bmn[2] + bmx[2]) / 2.0f;
+        const float ex = bmx[0] - bmn[0], ey = bmx[1] - bmn[1], ez = bmx[2] - bmn[2];
         const float extent = std::sqrt(ex * ex + ey * ey + ez * ez);
         vp[0] = cx + 0.0f; vp[1] = cy + 0.0f; vp[2] = cz + extent;
     }

@@ -35,14 +35,23 @@ __device__ __forceinline__ void isometry_apply(const float q[4], const float t[3
 // per-block bounding box partials (6 floats per block); the host folds the <= 256 rows
 // (min / max are order independent, so the result equals the reference's sequential fold).
 constexpr int kBboxBlocks = 256;
-__global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, float *__restrict__ box) {
+// sbox (optional): four SAMPLE boxes per block -- the private boxes of lanes 0..3 of every wave, i.e. of the points
+// with index = 0..3 mod 64 (the grid stride is a multiple of 64).  A handful of far outliers shows up in the exact box
+// but almost never in three of four 1/64 samples: the host compares them (cloud_bbox_robust).
+__global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, float *__restrict__ box,
+                                                  float *__restrict__ sbox) {
     __shared__ float sm[4][6];
+    __shared__ float ss[4][4][6];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     // each thread reads whole points; consecutive lanes read consecutive 12-B records
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
         mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);   // fminf ignores NaN
         mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    }
+    if (sbox && (threadIdx.x & 63) < 4) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ss[threadIdx.x >> 6][threadIdx.x & 63][c] = mn[c]; ss[threadIdx.x >> 6][threadIdx.x & 63][3 + c] = mx[c]; }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -61,6 +70,12 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
         float v = sm[0][threadIdx.x];
         for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
         box[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+    if (sbox && threadIdx.x < 24) {
+        const int sidx = threadIdx.x / 6, c = threadIdx.x % 6;
+        float v = ss[0][sidx][c];
+        for (int w = 1; w < 4; ++w) v = (c < 3) ? fminf(v, ss[w][sidx][c]) : fmaxf(v, ss[w][sidx][c]);
+        sbox[blockIdx.x * 24 + threadIdx.x] = v;
     }
 }
 
@@ -296,22 +311,53 @@ tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, 
     return TC_OK;
 }
 
-tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3]) {
+// exact box in mn / mx; with `rmn` also the box the grid should span: per axis the exact range unless three of the
+// four sample boxes agree that it is more than 1.3 x wider than the cloud proper (far outliers: a flying pixel, a
+// stray return), in which case the sampled range + 5 % -- points outside are indexed in the boundary cells.
+static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3], float *rmn, float *rmx,
+                                 bool *clamped) {
     hipStream_t st = ctx->stream;
     const int nb = (int)((n + 255) / 256);
     const int bb = std::min(nb, kBboxBlocks);
-    if (tc_status s = ensure(ctx, ctx->bbox, (size_t)kBboxBlocks * 6 * sizeof(float))) return s;
+    const bool robust = rmn != nullptr && n >= 4096;
+    if (tc_status s = ensure(ctx, ctx->bbox, (size_t)kBboxBlocks * 30 * sizeof(float))) return s;
+    float *d_box = (float *)ctx->bbox.p, *d_sbox = d_box + (size_t)kBboxBlocks * 6;
     {
         ProfScope ps(ctx, "bbox");
-        hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, (float *)ctx->bbox.p);
+        hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, d_box, robust ? d_sbox : nullptr);
     }
-    float *hb = (float *)((char *)ctx->pinned + 2048);
-    TC_HIP_TRY(ctx, hipMemcpyAsync(hb, ctx->bbox.p, (size_t)bb * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+    float *hb = (float *)((char *)ctx->pinned + 2048), *hs = (float *)((char *)ctx->pinned + 16384);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(hb, d_box, (size_t)bb * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (robust) TC_HIP_TRY(ctx, hipMemcpyAsync(hs, d_sbox, (size_t)bb * 24 * sizeof(float), hipMemcpyDeviceToHost, st));
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
     for (int c = 0; c < 3; ++c) { mn[c] = INFINITY; mx[c] = -INFINITY; }
     for (int b = 0; b < bb; ++b)
         for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hb[6 * b + c]); mx[c] = std::fmax(mx[c], hb[6 * b + 3 + c]); }
+    if (rmn) {
+        for (int c = 0; c < 3; ++c) { rmn[c] = mn[c]; rmx[c] = mx[c]; }
+        *clamped = false;
+    }
+    if (!robust) return TC_OK;
+    for (int c = 0; c < 3; ++c) {
+        float lo[4], hi[4];
+        for (int k = 0; k < 4; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+        for (int b = 0; b < bb; ++b)
+            for (int k = 0; k < 4; ++k) { lo[k] = std::fmin(lo[k], hs[24 * b + 6 * k + c]); hi[k] = std::fmax(hi[k], hs[24 * b + 6 * k + 3 + c]); }
+        std::sort(lo, lo + 4);                       // ascending: contaminated samples first
+        std::sort(hi, hi + 4, [](float a, float b) { return a > b; });
+        const float slo = lo[2], shi = hi[2];        // tolerate two contaminated samples per side
+        if (!(slo <= shi) || !std::isfinite(slo) || !std::isfinite(shi)) continue;
+        const float ext = shi - slo, full = mx[c] - mn[c];
+        if (!(full > 1.3f * ext) || !(full > 0.0f)) continue;
+        rmn[c] = std::fmax(mn[c], slo - 0.05f * ext);
+        rmx[c] = std::fmin(mx[c], shi + 0.05f * ext);
+        *clamped = true;
+    }
     return TC_OK;
+}
+
+tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3]) {
+    return cloud_bbox_impl(ctx, d_xyz, n, mn, mx, nullptr, nullptr, nullptr);
 }
 
 tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n, float cell_factor,
@@ -327,11 +373,19 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         ix.geom = *reuse_geom;
         ix.geom.n = n32;
     } else {
-        float mn[3], mx[3];
-        if (tc_status s = cloud_bbox(ctx, d_xyz, n, mn, mx)) return s;
-        for (int c = 0; c < 3; ++c)
-            if (!(mn[c] <= mx[c]) || !std::isfinite(mn[c]) || !std::isfinite(mx[c])) { mn[c] = 0.0f; mx[c] = 0.0f; }
-        derive_geom(ix.geom, mn, mx, n, cell_factor, min_cell_edge);
+        float mn[3], mx[3], rmn[3], rmx[3];
+        bool clamped = false;
+        if (tc_status s = cloud_bbox_impl(ctx, d_xyz, n, mn, mx, rmn, rmx, &clamped)) return s;
+        if (dbg & 2048) clamped = false, std::memcpy(rmn, mn, sizeof(mn)), std::memcpy(rmx, mx, sizeof(mx));   // TC_DEBUG & 2048: exact box only
+        for (int c = 0; c < 3; ++c) {
+            if (!(mn[c] <= mx[c]) || !std::isfinite(mn[c]) || !std::isfinite(mx[c])) { mn[c] = 0.0f; mx[c] = 0.0f; rmn[c] = 0.0f; rmx[c] = 0.0f; }
+            ix.exact_min[c] = mn[c]; ix.exact_max[c] = mx[c];
+        }
+        derive_geom(ix.geom, rmn, rmx, n, cell_factor, min_cell_edge);
+        ix.geom.clamped = clamped ? 1 : 0;
+        if ((dbg & 256) && clamped)
+            fprintf(stderr, "[tc] index: box clamped to %g..%g %g..%g %g..%g (exact %g..%g %g..%g %g..%g)\n", rmn[0], rmx[0], rmn[1], rmx[1],
+                    rmn[2], rmx[2], mn[0], mx[0], mn[1], mx[1], mn[2], mx[2]);
     }
     // The volume-based edge assumes the cloud fills its box.  A surface (depth map, LiDAR sweep) or a
     // clustered cloud puts tens of points into every OCCUPIED cell.  The prefix sum counts the occupied

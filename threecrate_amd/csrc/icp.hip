@@ -47,16 +47,24 @@ __device__ __forceinline__ uint32_t xcd_remap_icp(uint32_t b, uint32_t nb) {
 }
 
 // squared distance from a query to its projection onto the grid box, shaved by a safety factor
-__device__ __forceinline__ float outside_d2(float x, float y, float z, float qx, float qy, float qz) {
+// (the bound needs every record inside the box: with a clamped box -- `ext` -- it is dropped)
+__device__ __forceinline__ float outside_d2(float x, float y, float z, float qx, float qy, float qz, int ext) {
     const float ex = x - qx, ey = y - qy, ez = z - qz;
-    return (ex * ex + ey * ey + ez * ez) * 0.9999f;
+    return ext ? 0.0f : (ex * ex + ey * ey + ez * ez) * 0.9999f;
 }
 
 // squared distance from q to the box of cell index c along one axis, shaved by the cell-assignment
 // fuzz (conservative: never larger than the true gap)
-__device__ __forceinline__ float axis_gap(float q, float mn, float h, int c) {
+// `ext`: the grid's box is clamped (GridGeom::clamped): the first / last cell of the axis also holds the records
+// beyond the box, so it has no face on that side
+__device__ __forceinline__ float axis_gap(float q, float mn, float h, int c, int last, int ext) {
     const float lo = mn + (float)c * h, hi = lo + h;
-    return fmaxf(fmaxf(lo - q, q - hi) - 2e-3f * h, 0.0f);
+    float a = lo - q, b = q - hi;
+    if (ext) {
+        a = (c == 0) ? -INFINITY : a;
+        b = (c == last) ? -INFINITY : b;
+    }
+    return fmaxf(fmaxf(a, b) - 2e-3f * h, 0.0f);
 }
 
 // exact nearest record of the target grid to (x, y, z) straight from HBM/L2 (no staging);
@@ -77,7 +85,7 @@ __device__ __forceinline__ void nn_search_global(const GridView &gv, float x, fl
     mf = fmaxf(mf, 0.0f);
     // query outside the grid: q' = clamp(q) is its projection onto the (convex) box, so every
     // record p satisfies |p - q|^2 >= |p - q'|^2 + |q - q'|^2
-    const float out2 = outside_d2(x, y, z, qx, qy, qz);
+    const float out2 = outside_d2(x, y, z, qx, qy, qz, g.clamped);
     auto span = [&](uint32_t row, int xa, int xb) {
         const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
         for (uint32_t j = s; j < e; ++j) {
@@ -95,9 +103,9 @@ __device__ __forceinline__ void nn_search_global(const GridView &gv, float x, fl
         // shell misses it every farther shell does too.
         bool touched = (R == 1);
         for (int zz = z0; zz <= z1; ++zz) {
-            const float gz = axis_gap(z, g.minz, g.h, zz);
+            const float gz = axis_gap(z, g.minz, g.h, zz, g.gz - 1, g.clamped);
             for (int yy = y0; yy <= y1; ++yy) {
-                const float gy = axis_gap(y, g.miny, g.h, yy);
+                const float gy = axis_gap(y, g.miny, g.h, yy, g.gy - 1, g.clamped);
                 const float rg = gy * gy + gz * gz;
                 if (R > 1 && rg > best) continue;
                 const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
@@ -107,16 +115,16 @@ __device__ __forceinline__ void nn_search_global(const GridView &gv, float x, fl
                 } else if (edge) {
                     // tighten the x window to the cells the ball can reach
                     int xa = x0, xb = x1;
-                    while (xa <= xb && rg + axis_gap(x, g.minx, g.h, xa) * axis_gap(x, g.minx, g.h, xa) > best) ++xa;
-                    while (xb >= xa && rg + axis_gap(x, g.minx, g.h, xb) * axis_gap(x, g.minx, g.h, xb) > best) --xb;
+                    while (xa <= xb && rg + axis_gap(x, g.minx, g.h, xa, g.gx - 1, g.clamped) * axis_gap(x, g.minx, g.h, xa, g.gx - 1, g.clamped) > best) ++xa;
+                    while (xb >= xa && rg + axis_gap(x, g.minx, g.h, xb, g.gx - 1, g.clamped) * axis_gap(x, g.minx, g.h, xb, g.gx - 1, g.clamped) > best) --xb;
                     if (xa <= xb) { touched = true; span(row, xa, xb); }
                 } else {   // interior rows of a shell: only the two end cells are new
                     if (cx - R >= 0) {
-                        const float gx = axis_gap(x, g.minx, g.h, cx - R);
+                        const float gx = axis_gap(x, g.minx, g.h, cx - R, g.gx - 1, g.clamped);
                         if (rg + gx * gx <= best) { touched = true; span(row, cx - R, cx - R); }
                     }
                     if (cx + R <= g.gx - 1) {
-                        const float gx = axis_gap(x, g.minx, g.h, cx + R);
+                        const float gx = axis_gap(x, g.minx, g.h, cx + R, g.gx - 1, g.clamped);
                         if (rg + gx * gx <= best) { touched = true; span(row, cx + R, cx + R); }
                     }
                 }
@@ -250,7 +258,7 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     const float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy,
                 fz = (qz - g.minz) * g.inv_h - (float)cz;
     mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
-    out2 = outside_d2(x, y, z, qx, qy, qz);
+    out2 = outside_d2(x, y, z, qx, qy, qz, g.clamped);
     // squared distance (shaved by the cell-assignment fuzz) from q' to the neighbouring slabs
     const float lo_x = fmaxf(fx - 2e-3f, 0.0f) * g.h, hi_x = fmaxf(1.0f - fx - 2e-3f, 0.0f) * g.h;
     const float lo_y = fmaxf(fy - 2e-3f, 0.0f) * g.h, hi_y = fmaxf(1.0f - fy - 2e-3f, 0.0f) * g.h;
@@ -644,8 +652,8 @@ __device__ __forceinline__ unsigned long long refine_shell(const GridView &tgt, 
             const int ccx = cx + ox, ccy = cy + oy, ccz = cz + oz;
             bool in = idx < ncell && ccx >= 0 && ccx < g.gx && ccy >= 0 && ccy < g.gy && ccz >= 0 && ccz < g.gz;
             if (in && have) {
-                const float gx = axis_gap(x, g.minx, g.h, ccx), gy = axis_gap(y, g.miny, g.h, ccy),
-                            gz = axis_gap(z, g.minz, g.h, ccz);
+                const float gx = axis_gap(x, g.minx, g.h, ccx, g.gx - 1, g.clamped), gy = axis_gap(y, g.miny, g.h, ccy, g.gy - 1, g.clamped),
+                            gz = axis_gap(z, g.minz, g.h, ccz, g.gz - 1, g.clamped);
                 in = !(gx * gx + gy * gy + gz * gz > bestd);               // inside the ball
             }
             touched |= in;
@@ -786,7 +794,7 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
         const float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy,
                     fz = (qz - g.minz) * g.inv_h - (float)cz;
         const float mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
-        const float out2 = outside_d2(x, y, z, qx, qy, qz);
+        const float out2 = outside_d2(x, y, z, qx, qy, qz, g.clamped);
         // start: the best real point the main pass knows (previous match or its ring-1 result); ring 1 is done
         unsigned long long bestkey = ~0ull;
         if (pj != 0xFFFFFFFFu) bestkey = ((unsigned long long)__float_as_uint(d2_nc(p.x, p.y, p.z, x, y, z)) << 32) | pj;

@@ -132,9 +132,16 @@ __device__ __forceinline__ void scan_block(const GridView &gv, int cx, int cy, i
 }
 
 // distance from q to the box of cell index c along one axis, shaved by the cell-assignment fuzz
-__device__ __forceinline__ float axis_gap_n(float q, float mn, float h, int c) {
+// `ext`: the grid's box is clamped (GridGeom::clamped): the first / last cell of the axis (c == 0 / c == last) also
+// holds the points beyond the box, so it has no face on that side
+__device__ __forceinline__ float axis_gap_n(float q, float mn, float h, int c, int last, int ext) {
     const float lo = mn + (float)c * h, hi = lo + h;
-    return fmaxf(fmaxf(lo - q, q - hi) - 2e-3f * h, 0.0f);
+    float a = lo - q, b = q - hi;
+    if (ext) {
+        a = (c == 0) ? -INFINITY : a;
+        b = (c == last) ? -INFINITY : b;
+    }
+    return fmaxf(fmaxf(a, b) - 2e-3f * h, 0.0f);
 }
 
 // visit the records of the cells of block [c-R, c+R]^3 that (a) lie outside block [c-Rin, c+Rin]^3
@@ -152,16 +159,25 @@ __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q,
     const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
     bool touched = false;
     for (int z = z0; z <= z1; ++z) {
-        const float gz = axis_gap_n(q.z, g.minz, g.h, z);
+        const float gz = axis_gap_n(q.z, g.minz, g.h, z, g.gz - 1, g.clamped);
         for (int y = y0; y <= y1; ++y) {
-            const float gy = axis_gap_n(q.y, g.miny, g.h, y);
+            const float gy = axis_gap_n(q.y, g.miny, g.h, y, g.gy - 1, g.clamped);
             const float rg = gy * gy + gz * gz;
             if (rg > lim) continue;
             const bool inner_row = (abs(z - cz) <= Rin) && (abs(y - cy) <= Rin);
             // x window reachable by the ball
+            // closed form with a cell of slack on either side, then the exact test (a ball much smaller than the block --
+            // an isolated query, a far outlier -- would otherwise walk the whole row cell by cell)
             int xa = x0, xb = x1;
-            while (xa <= xb) { const float gx = axis_gap_n(q.x, g.minx, g.h, xa); if (rg + gx * gx > lim) ++xa; else break; }
-            while (xb >= xa) { const float gx = axis_gap_n(q.x, g.minx, g.h, xb); if (rg + gx * gx > lim) --xb; else break; }
+            {
+                const float r = sqrtf(lim - rg) + 4e-3f * g.h;
+                const float fa = fminf(fmaxf((q.x - r - g.minx) * g.inv_h - 1.0f, -1.0f), (float)(g.gx - 1));
+                const float fb = fmaxf(fminf((q.x + r - g.minx) * g.inv_h + 1.0f, (float)g.gx), 0.0f);
+                xa = max(xa, (int)fa);
+                xb = min(xb, (int)fb);
+            }
+            while (xa <= xb) { const float gx = axis_gap_n(q.x, g.minx, g.h, xa, g.gx - 1, g.clamped); if (rg + gx * gx > lim) ++xa; else break; }
+            while (xb >= xa) { const float gx = axis_gap_n(q.x, g.minx, g.h, xb, g.gx - 1, g.clamped); if (rg + gx * gx > lim) --xb; else break; }
             if (xa > xb) continue;
             const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
             auto span = [&](int a, int b) {
@@ -240,11 +256,14 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         // the grid box is convex and contains the query, so a shell that misses it ends the search.
         // While the list is not full nothing can be pruned anyway, so the block may grow by half its radius at
         // a time instead of one ring: an isolated point D cells from its neighbours pays ~D^2 row visits, not D^3.
+        // With a full list the block radius that proves it is known: (R' + mf) h >= sqrt(tau).  Going there in one
+        // call visits every row once; ring by ring every call loops over all rows of its block again.
         const int Rin = R;
-        R += (tau == INFINITY) ? max(1, R / 2) : 1;
         const float need2 = RADIUS ? fmaxf(r2, 0.0f) : 0.0f;     // radius mode must also see the whole radius ball
+        if (tau == INFINITY) R += max(1, R / 2);
+        else R = max(R + 1, (int)fminf(ceilf(sqrtf(fmaxf(tau, need2)) * g.inv_h - mf + 0.01f), 1.0e9f));
         // one call site for both cases (lanes of a wave differ): only the growing lanes refresh their limit
-        const bool growing = tau == INFINITY;
+        const bool growing = tau == INFINITY || R > Rin + 1;
         const bool touched = scan_pruned(gv, q, cx, cy, cz, Rin, R, fmaxf(tau, need2), visit1, [&](float l) {
             if (growing) { float t_; TC_KTH(t_); l = fmaxf(t_, need2); }
             return l;
@@ -390,7 +409,8 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
     const float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy, fz = (qz - g.minz) * g.inv_h - (float)cz;
     const float mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
     const float ex = q.x - qx, ey = q.y - qy, ez = q.z - qz;
-    const float out2 = (ex * ex + ey * ey + ez * ez) * 0.9999f;
+    // |p - q|^2 >= |p - q'|^2 + |q - q'|^2 needs every record inside the box: not so when the box is clamped
+    const float out2 = g.clamped ? 0.0f : (ex * ex + ey * ey + ez * ez) * 0.9999f;
     const uint32_t K1 = min(k, g.n);
     float d[L];
 #pragma unroll
@@ -407,9 +427,10 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
                             (cz - R <= 0) && (cz + R >= g.gz - 1);
         const float bound = ((float)R + mf - 2e-3f) * g.h;
         if (covers || tau <= bound * bound + out2) break;
-        const int Rin = R;
-        R += (tau == INFINITY) ? max(1, R / 2) : 1;              // see normals_point
-        const bool growing = tau == INFINITY;
+        const int Rin = R;                                       // see normals_point
+        if (tau == INFINITY) R += max(1, R / 2);
+        else R = max(R + 1, (int)fminf(ceilf(sqrtf(fmaxf(tau - out2, 0.0f)) * g.inv_h - mf + 0.01f), 1.0e9f));
+        const bool growing = tau == INFINITY || R > Rin + 1;
         const bool touched = scan_pruned(gv, q, cx, cy, cz, Rin, R, tau, visit1, [&](float l) {
             if (growing) {
                 l = d[0];

@@ -23,6 +23,8 @@ struct GridGeom {
     uint32_t ncell;             // gx*gy*gz
     uint32_t n;                 // points indexed
     float cx, cy, cz;           // bbox centre (shift origin for the p2p Kabsch sums)
+    int   clamped;              // the box is narrower than the cloud (far outliers): points beyond it live in the
+                                // boundary cells, which then extend to infinity for every distance bound
 };
 
 // Tiles of TX x TY x TZ cells.  A workgroup owns one tile of QUERIES and stages the tile +
@@ -109,6 +111,7 @@ struct KernelTimer {
 struct DeviceIndex {
     GridGeom geom{};
     TileGeom tile{};    // only meaningful for a tile-major (query-side) ordering
+    float exact_min[3] = {0, 0, 0}, exact_max[3] = {0, 0, 0};   // the cloud's exact box (geom may be clamped)
     DevBuf pts;         // float4 * n   (cell-sorted, w = original index bits)
     DevBuf cell_start;  // u32 * (ncell+1)
     DevBuf normals;     // float4 * n   (cell-sorted target normals; optional)

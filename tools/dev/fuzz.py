@@ -22,7 +22,14 @@ def run(budget, seed, ctx, sizes=SMALL, log=print):
         elif kind == 4: t = rng.random(n); p = np.stack([t, 2 * t, -t], 1) + 1e-3 * rng.normal(size=(n, 3))   # near-collinear
         elif kind == 5: p = np.round(rng.random((n, 3)) * 8) / 8 + 1e-5 * rng.normal(size=(n, 3))   # lattice-ish with near duplicates
         else: p = rng.random((n, 3)); p[: n // 4] = p[0]                                        # many exact duplicates
-        return (p * rng.choice([1e-2, 1.0, 50.0])).astype(np.float32)
+        p = p * rng.choice([1e-2, 1.0, 50.0])
+        if n >= 64 and rng.random() < 0.35:            # a few far outliers: the grid's box gets clamped (GridGeom::clamped)
+            m = int(rng.integers(1, 6))
+            ext = p.max(0) - p.min(0) + 1e-9
+            far = p.mean(0) + ext * rng.choice([-1.0, 1.0], (m, 3)) * rng.uniform(3, 200, (m, 3)) * (rng.random((m, 3)) < 0.6)
+            if m >= 2: far[1] = far[0] + ext * 1e-3     # two outliers next to each other: neighbours of one another
+            p[rng.integers(0, n, m)] = far
+        return p.astype(np.float32)
 
     t_end = time.time() + budget
     cases = bad = 0
