@@ -134,10 +134,11 @@ __device__ __forceinline__ void scan_block(const GridView &gv, int cx, int cy, i
 // distance from q to the box of cell index c along one axis, shaved by the cell-assignment fuzz
 // `ext`: the grid's box is clamped (GridGeom::clamped): the first / last cell of the axis (c == 0 / c == last) also
 // holds the points beyond the box, so it has no face on that side
-__device__ __forceinline__ float axis_gap_n(float q, float mn, float h, int c, int last, int ext) {
+template <bool EXT>
+__device__ __forceinline__ float axis_gap_n(float q, float mn, float h, int c, int last) {
     const float lo = mn + (float)c * h, hi = lo + h;
     float a = lo - q, b = q - hi;
-    if (ext) {
+    if (EXT) {
         a = (c == 0) ? -INFINITY : a;
         b = (c == last) ? -INFINITY : b;
     }
@@ -147,21 +148,20 @@ __device__ __forceinline__ float axis_gap_n(float q, float mn, float h, int c, i
 // visit the records of the cells of block [c-R, c+R]^3 that (a) lie outside block [c-Rin, c+Rin]^3
 // (Rin < 0: none excluded) and (b) whose box is within sqrt(lim) of q (ball pruning).  Returns
 // whether any cell qualified.
-// `relim` (optional): called after every row that held records; returns the new limit (a growing block scanned
+// LIVE: after every row the limit is re-read from *live, which the visitor keeps up to date (a growing block scanned
 // with an infinite limit starts pruning as soon as the list is full).
-struct KeepLimit { __device__ float operator()(float lim) const { return lim; } };
-template <typename F, typename U = KeepLimit>
+template <bool EXT, bool LIVE = false, typename F>
 __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q, int cx, int cy, int cz, int Rin, int R,
-                                            float lim, F &&f, U &&relim = KeepLimit()) {
+                                            float lim, F &&f, const float *live = nullptr) {
     const GridGeom &g = gv.g;
     const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
     const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
     const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
     bool touched = false;
     for (int z = z0; z <= z1; ++z) {
-        const float gz = axis_gap_n(q.z, g.minz, g.h, z, g.gz - 1, g.clamped);
+        const float gz = axis_gap_n<EXT>(q.z, g.minz, g.h, z, g.gz - 1);
         for (int y = y0; y <= y1; ++y) {
-            const float gy = axis_gap_n(q.y, g.miny, g.h, y, g.gy - 1, g.clamped);
+            const float gy = axis_gap_n<EXT>(q.y, g.miny, g.h, y, g.gy - 1);
             const float rg = gy * gy + gz * gz;
             if (rg > lim) continue;
             const bool inner_row = (abs(z - cz) <= Rin) && (abs(y - cy) <= Rin);
@@ -169,15 +169,15 @@ __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q,
             // closed form with a cell of slack on either side, then the exact test (a ball much smaller than the block --
             // an isolated query, a far outlier -- would otherwise walk the whole row cell by cell)
             int xa = x0, xb = x1;
-            {
+            if (xb - xa > 8) {                       // the usual 5-7 cell windows are trimmed faster cell by cell
                 const float r = sqrtf(lim - rg) + 4e-3f * g.h;
                 const float fa = fminf(fmaxf((q.x - r - g.minx) * g.inv_h - 1.0f, -1.0f), (float)(g.gx - 1));
                 const float fb = fmaxf(fminf((q.x + r - g.minx) * g.inv_h + 1.0f, (float)g.gx), 0.0f);
                 xa = max(xa, (int)fa);
                 xb = min(xb, (int)fb);
             }
-            while (xa <= xb) { const float gx = axis_gap_n(q.x, g.minx, g.h, xa, g.gx - 1, g.clamped); if (rg + gx * gx > lim) ++xa; else break; }
-            while (xb >= xa) { const float gx = axis_gap_n(q.x, g.minx, g.h, xb, g.gx - 1, g.clamped); if (rg + gx * gx > lim) --xb; else break; }
+            while (xa <= xb) { const float gx = axis_gap_n<EXT>(q.x, g.minx, g.h, xa, g.gx - 1); if (rg + gx * gx > lim) ++xa; else break; }
+            while (xb >= xa) { const float gx = axis_gap_n<EXT>(q.x, g.minx, g.h, xb, g.gx - 1); if (rg + gx * gx > lim) --xb; else break; }
             if (xa > xb) continue;
             const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
             auto span = [&](int a, int b) {
@@ -188,13 +188,13 @@ __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q,
             };
             if (!inner_row) span(xa, xb);
             else { span(xa, min(xb, cx - Rin - 1)); span(max(xa, cx + Rin + 1), xb); }   // only the cells outside the inner block
-            if constexpr (!std::is_same<typename std::decay<U>::type, KeepLimit>::value) lim = relim(lim);
+            if (LIVE) lim = *live;
         }
     }
     return touched;
 }
 
-template <int L, int BLOCK, bool RADIUS>
+template <int L, int BLOCK, bool RADIUS, bool EXT>
 __device__ __forceinline__ void normals_point(const GridView &gv, const NormalParams &prm, uint32_t p,
                                               float *__restrict__ out6, uint32_t *ldsA, uint8_t *ldsB) {
     const GridGeom &g = gv.g;
@@ -263,11 +263,15 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         if (tau == INFINITY) R += max(1, R / 2);
         else R = max(R + 1, (int)fminf(ceilf(sqrtf(fmaxf(tau, need2)) * g.inv_h - mf + 0.01f), 1.0e9f));
         // one call site for both cases (lanes of a wave differ): only the growing lanes refresh their limit
+        // one call site (a second, plain one costs 20 registers and sends the list to scratch)
         const bool growing = tau == INFINITY || R > Rin + 1;
-        const bool touched = scan_pruned(gv, q, cx, cy, cz, Rin, R, fmaxf(tau, need2), visit1, [&](float l) {
-            if (growing) { float t_; TC_KTH(t_); l = fmaxf(t_, need2); }
-            return l;
-        });
+        float live_lim = fmaxf(tau, need2);
+        const bool touched = scan_pruned<EXT, true>(gv, q, cx, cy, cz, Rin, R, live_lim, [&](uint32_t j, const float4 &c) {
+            visit1(j, c);
+            // only the growing lanes tighten their limit; the list's last entry bounds the k-th (no dynamic index: that
+            // sends the list to scratch here)
+            if (growing) live_lim = fmaxf(d[L - 1], need2);
+        }, &live_lim);
         if (!touched) { TC_KTH(tau); use_radius = RADIUS && cnt_r >= prm.k; break; }
     }
 
@@ -290,7 +294,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     const uint32_t quota = K1 - min(n_lt, K1);
     uint32_t cnt = 0, ties = 0;
     // rescan only the cells within sqrt(tau) of the query (same visiting order as phase 1)
-    scan_pruned(gv, q, cx, cy, cz, -1, R, tau, [&](uint32_t j, const float4 &c) {
+    scan_pruned<EXT>(gv, q, cx, cy, cz, -1, R, tau, [&](uint32_t j, const float4 &c) {
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
         bool take = v < tau;
         if (!take && v == tau && ties < quota) { take = true; ++ties; }
@@ -366,14 +370,14 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
     return lb;
 }
 
-template <int L, int BLOCK, bool RADIUS>
+template <int L, int BLOCK, bool RADIUS, bool EXT>
 __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
     __shared__ uint32_t ldsA[L * BLOCK];
     __shared__ uint8_t ldsB[L * BLOCK];       // ranks as bytes: 88 instead of 136 B of LDS per lane -> 7 instead of 4 waves per SIMD
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t p = lb * BLOCK + threadIdx.x;
     if (p >= gv.g.n) return;
-    normals_point<L, BLOCK, RADIUS>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+    normals_point<L, BLOCK, RADIUS, EXT>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
 }
 
 template <int L, int BLOCK, bool RADIUS = false>
@@ -382,7 +386,9 @@ static void launch_variant(hipStream_t st, const GridView &gv, const NormalParam
     uint32_t nb = (n + BLOCK - 1) / BLOCK;
     nb = (nb + 7) / 8 * 8;   // xcd_remap needs a multiple of 8
     ProfScope ps(ctx, "normals_knn_pca");
-    hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
+    // two instantiations: with a clamped box the boundary cells are open on the outer side (costs 4 % on the gap tests)
+    if (gv.g.clamped) hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS, true>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
+    else hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS, false>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
 }
 
 // ---- batch k-NN export -----------------------------------------------------
@@ -391,7 +397,7 @@ static void launch_variant(hipStream_t st, const GridView &gv, const NormalParam
 // nearest cloud points, ascending, as (original index, sqrt(d2)).  Same machinery as the normals
 // kernel: sorted register list for the k-th distance, ball-pruned ring continuation (queries may lie
 // outside the grid: |p - q|^2 >= |p - clamp(q)|^2 + |q - clamp(q)|^2), LDS position lists, ranking.
-template <int L, int BLOCK>
+template <int L, int BLOCK, bool EXT>
 __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__restrict__ queries, uint32_t nq, uint32_t k,
                                                     uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
                                                     uint32_t *__restrict__ out_count, float radius_sq) {
@@ -410,7 +416,7 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
     const float mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
     const float ex = q.x - qx, ey = q.y - qy, ez = q.z - qz;
     // |p - q|^2 >= |p - q'|^2 + |q - q'|^2 needs every record inside the box: not so when the box is clamped
-    const float out2 = g.clamped ? 0.0f : (ex * ex + ey * ey + ez * ez) * 0.9999f;
+    const float out2 = EXT ? 0.0f : (ex * ex + ey * ey + ez * ez) * 0.9999f;
     const uint32_t K1 = min(k, g.n);
     float d[L];
 #pragma unroll
@@ -431,14 +437,11 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
         if (tau == INFINITY) R += max(1, R / 2);
         else R = max(R + 1, (int)fminf(ceilf(sqrtf(fmaxf(tau - out2, 0.0f)) * g.inv_h - mf + 0.01f), 1.0e9f));
         const bool growing = tau == INFINITY || R > Rin + 1;
-        const bool touched = scan_pruned(gv, q, cx, cy, cz, Rin, R, tau, visit1, [&](float l) {
-            if (growing) {
-                l = d[0];
-#pragma unroll
-                for (int i = 1; i < L; ++i) l = ((uint32_t)i == K1 - 1) ? d[i] : l;
-            }
-            return l;
-        });
+        float live_lim = tau;
+        const bool touched = scan_pruned<EXT, true>(gv, q, cx, cy, cz, Rin, R, live_lim, [&](uint32_t j, const float4 &c) {
+            visit1(j, c);
+            if (growing) live_lim = d[L - 1];       // bounds the k-th entry (static index: see normals_point)
+        }, &live_lim);
         if (!touched) {
             tau = d[0];
 #pragma unroll
@@ -451,7 +454,7 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
     for (int i = 0; i < L; ++i) n_lt += (d[i] < tau) ? 1u : 0u;
     const uint32_t quota = K1 - min(n_lt, K1);
     uint32_t cnt = 0, ties = 0;
-    scan_pruned(gv, q, cx, cy, cz, -1, R, tau, [&](uint32_t j, const float4 &c) {
+    scan_pruned<EXT>(gv, q, cx, cy, cz, -1, R, tau, [&](uint32_t j, const float4 &c) {
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
         bool take = v < tau;
         if (!take && v == tau && ties < quota) { take = true; ++ties; }
@@ -487,8 +490,13 @@ tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_quer
     const GridView gv = view_of(ix);
     ProfScope ps(ctx, "knn_batch");
     hipStream_t st = ctx->stream;
-#define TC_KNN(LL, BB) hipLaunchKernelGGL((knn_kernel<LL, BB>), dim3((unsigned)((nq + BB - 1) / BB)), dim3(BB), 0, st, gv, d_queries, \
-                                          (uint32_t)nq, (uint32_t)k, d_idx, d_dist, d_count, radius_sq)
+#define TC_KNN(LL, BB)                                                                                                          \
+    do {                                                                                                                        \
+        if (gv.g.clamped) hipLaunchKernelGGL((knn_kernel<LL, BB, true>), dim3((unsigned)((nq + BB - 1) / BB)), dim3(BB), 0, st, gv, \
+                                             d_queries, (uint32_t)nq, (uint32_t)k, d_idx, d_dist, d_count, radius_sq);          \
+        else hipLaunchKernelGGL((knn_kernel<LL, BB, false>), dim3((unsigned)((nq + BB - 1) / BB)), dim3(BB), 0, st, gv, d_queries, \
+                                (uint32_t)nq, (uint32_t)k, d_idx, d_dist, d_count, radius_sq);                                  \
+    } while (0)
     if (k <= 9) TC_KNN(9, 256);
     else if (k <= 17) TC_KNN(17, 256);
     else if (k <= 33) TC_KNN(33, 128);
