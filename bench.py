@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-copy-probe", action="store_true", help="skip the device-to-device copy bandwidth probe (profile runs)")
     ap.add_argument("--cloud", choices=["uniform", "tum"], default="uniform",
                     help="pairs mode: uniform-random cloud (BASELINE configs[1], the judged line) or a TUM-RGB-D-shaped "
                          "depth-map surface of ~1 M points (configs[2]; auxiliary)")
@@ -231,6 +232,8 @@ def main():
         # what a plain device-to-device copy reaches on this box (report next to the 8 TB/s vendor peak)
         copy_gbs = None
         try:
+            if args.no_copy_probe:
+                raise RuntimeError("skipped")
             a, b = torch.empty(1 << 28, dtype=torch.float32, device=dev), torch.empty(1 << 28, dtype=torch.float32, device=dev)
             b.copy_(a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

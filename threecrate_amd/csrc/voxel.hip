@@ -124,12 +124,16 @@ __global__ void __launch_bounds__(256) vox_starts_kernel(uint32_t n, const uint3
 
 // one lane per voxel folds the voxel's points in sorted = original order (filtering.rs:108-118), eight gathers in
 // flight at a time: the adds stay sequential, only the loads overlap
+constexpr uint32_t kLongVoxel = 96;     // points; longer voxels go to the wave-per-voxel kernel
+
 __global__ void __launch_bounds__(256) vox_centroid_sorted_kernel(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
                                                                  const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ n_vox,
-                                                                 float *__restrict__ out) {
+                                                                 float *__restrict__ out, uint32_t *__restrict__ long_list,
+                                                                 uint32_t *__restrict__ long_count) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= *n_vox) return;
     const uint32_t s = vstart[v], e = vstart[v + 1];
+    if (e - s > kLongVoxel) { long_list[atomicAdd(long_count, 1u)] = v; return; }
     double sx = 0.0, sy = 0.0, sz = 0.0;
     uint32_t j = s;
     for (; j + 8 <= e; j += 8) {
@@ -149,6 +153,41 @@ __global__ void __launch_bounds__(256) vox_centroid_sorted_kernel(const float *_
     const double inv = 1.0 / (double)(e - s);      // filtering.rs:122-128
     float *o = out + 3 * (size_t)v;
     o[0] = (float)(sx * inv); o[1] = (float)(sy * inv); o[2] = (float)(sz * inv);
+}
+
+// Voxels with many points (0.2 m voxels on a depth frame: ~1000 each): one WAVE per voxel.  The 64 lanes gather 64
+// consecutive points of the voxel at once; the f64 adds stay strictly sequential in sorted = original order (every lane
+// runs the same chain on broadcast values), so the centroid has the bits of the reference's fold.
+__global__ void __launch_bounds__(256) vox_centroid_long_kernel(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
+                                                               const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ long_list,
+                                                               const uint32_t *__restrict__ long_count, float *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t total = *long_count;
+    for (uint32_t entry = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); entry < total; entry += nwaves) {
+        const uint32_t v = long_list[entry];
+        const uint32_t s = vstart[v], e = vstart[v + 1];
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (uint32_t base = s; base < e; base += 64) {
+            const uint32_t j = base + lane;
+            float x = 0.0f, y = 0.0f, z = 0.0f;
+            if (j < e) {
+                const size_t i = order[j];
+                x = xyz[3 * i]; y = xyz[3 * i + 1]; z = xyz[3 * i + 2];
+            }
+            const int cnt = (int)min(64u, e - base);
+            for (int l = 0; l < cnt; ++l) {        // l is wave-uniform: v_readlane with a scalar lane select
+                sx += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+                sy += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), l));
+                sz += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), l));
+            }
+        }
+        if (lane == 0) {
+            const double inv = 1.0 / (double)(e - s);      // filtering.rs:122-128
+            float *o = out + 3 * (size_t)v;
+            o[0] = (float)(sx * inv); o[1] = (float)(sy * inv); o[2] = (float)(sz * inv);
+        }
+    }
 }
 
 static int bits_for(double dim) {
@@ -175,7 +214,7 @@ static tc_status voxel_filter_sorted(tc_context *ctx, const float *d_xyz, size_t
     if (tc_status s = ensure(ctx, ix.arrival, n * sizeof(uint32_t))) return s;            // indices
     if (tc_status s = ensure(ctx, ix.pts, n * sizeof(uint32_t))) return s;                // order[] = sorted indices
     if (tc_status s = ensure(ctx, ix.fill, n * sizeof(uint32_t))) return s;               // voxel heads
-    if (tc_status s = ensure(ctx, ix.cell_start, (n + 1) * sizeof(uint32_t))) return s;   // output slot of a head
+    if (tc_status s = ensure(ctx, ix.cell_start, (n + 2) * sizeof(uint32_t))) return s;   // output slot of a head, [n + 1] = long-voxel counter
     if (tc_status s = ensure(ctx, ctx->overflow, (n + 1) * sizeof(uint32_t))) return s;   // first sorted position of a voxel
     uint64_t *keys = (uint64_t *)ix.cell_of.p, *keys_sorted = (uint64_t *)ix.slot.p;
     uint32_t *idx = (uint32_t *)ix.arrival.p, *order = (uint32_t *)ix.pts.p, *head = (uint32_t *)ix.fill.p, *outpos = (uint32_t *)ix.cell_start.p;
@@ -189,8 +228,12 @@ static tc_status voxel_filter_sorted(tc_context *ctx, const float *d_xyz, size_t
     if (tc_status s = exclusive_scan_u32(ctx, head, n32, outpos, ix.blocksum)) return s;
     uint32_t *vstart = (uint32_t *)ctx->overflow.p;
     hipLaunchKernelGGL(vox_starts_kernel, dim3(nb), dim3(256), 0, st, n32, (const uint32_t *)head, (const uint32_t *)outpos, vstart);
+    TC_HIP_TRY(ctx, hipMemsetAsync(outpos + n + 1, 0, sizeof(uint32_t), st));
+    uint32_t *long_list = head;          // the head flags are no longer needed
     hipLaunchKernelGGL(vox_centroid_sorted_kernel, dim3(nb), dim3(256), 0, st, d_xyz, (const uint32_t *)order, (const uint32_t *)vstart,
-                       (const uint32_t *)(outpos + n), d_out);
+                       (const uint32_t *)(outpos + n), d_out, long_list, outpos + n + 1);
+    hipLaunchKernelGGL(vox_centroid_long_kernel, dim3(1024), dim3(256), 0, st, d_xyz, (const uint32_t *)order, (const uint32_t *)vstart,
+                       (const uint32_t *)long_list, (const uint32_t *)(outpos + n + 1), d_out);
     uint32_t *hcount = (uint32_t *)((char *)ctx->pinned + 1024);
     TC_HIP_TRY(ctx, hipMemcpyAsync(hcount, outpos + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
