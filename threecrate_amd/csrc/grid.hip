@@ -338,11 +338,15 @@ static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, 
         *clamped = false;
     }
     if (!robust) return TC_OK;
+    float acc[24];                                   // [sample][min xyz | max xyz], folded over the blocks (plain compares: no NaNs in here)
+    for (int i = 0; i < 24; ++i) acc[i] = (i % 6 < 3) ? INFINITY : -INFINITY;
+    for (int b = 0; b < bb; ++b) {
+        const float *r = hs + 24 * b;
+        for (int i = 0; i < 24; ++i) acc[i] = (i % 6 < 3) ? (r[i] < acc[i] ? r[i] : acc[i]) : (r[i] > acc[i] ? r[i] : acc[i]);
+    }
     for (int c = 0; c < 3; ++c) {
         float lo[4], hi[4];
-        for (int k = 0; k < 4; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-        for (int b = 0; b < bb; ++b)
-            for (int k = 0; k < 4; ++k) { lo[k] = std::fmin(lo[k], hs[24 * b + 6 * k + c]); hi[k] = std::fmax(hi[k], hs[24 * b + 6 * k + 3 + c]); }
+        for (int k = 0; k < 4; ++k) { lo[k] = acc[6 * k + c]; hi[k] = acc[6 * k + 3 + c]; }
         std::sort(lo, lo + 4);                       // ascending: contaminated samples first
         std::sort(hi, hi + 4, [](float a, float b) { return a > b; });
         const float slo = lo[2], shi = hi[2];        // tolerate two contaminated samples per side
