@@ -81,7 +81,14 @@ def aux_modes(args):
         tgt = torch.from_numpy(tgt_h).to(dev)
         lo, hi = D.shard_range(n, rank, world)
         src = torch.from_numpy(src_h[lo:hi]).to(dev)
-        nrm = ctx.estimate_normals(tgt, K_NORMALS)
+        # the normals of the replicated target are sharded too: every rank computes its slice, one all-gather
+        nrm = D.sharded_estimate_normals(ctx, tgt, K_NORMALS)
+        torch.cuda.synchronize()
+        tn0 = time.perf_counter()
+        for _ in range(3):
+            nrm = D.sharded_estimate_normals(ctx, tgt, K_NORMALS)
+        torch.cuda.synchronize()
+        t_normals = (time.perf_counter() - tn0) / 3.0
         def step():
             return D.sharded_icp_point_to_plane(ctx, src, tgt, nrm, None, ICP_ITERS, None, 0.0, source_is_local_slice=True)
         for _ in range(max(args.warmup, 1)):
@@ -104,7 +111,8 @@ def aux_modes(args):
                               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": f"{n}-pt uniform cloud [0,10)x[0,10)x[0,1), 50-iter p2plane ICP, source sharded over ranks",
                                          "points": n, "parallelism": f"shard{world}"},
-                              "transform_frobenius_error": err}))
+                              "transform_frobenius_error": err,
+                              "sharded_normals_ms": 1e3 * t_normals, "sharded_normals_mpts_per_s": n / t_normals / 1e6}))
     else:
         frames = [synth.kitti_shaped_cloud(seed=i) for i in range(4)]
         # ego motion between consecutive frames: 1 m forward + 0.5 deg yaw

@@ -93,6 +93,9 @@ extern "C" {
                   idx: *mut u32, dist: *mut f32, count: *mut u32) -> c_int;
     pub fn tc_radius_search(ctx: *mut tc_context, cloud: *const f32, n: usize, queries: *const f32, nq: usize, radius: f32, k_max: usize,
                             idx: *mut u32, dist: *mut f32, count: *mut u32) -> c_int;
+    pub fn tc_estimate_normals_slice_device(ctx: *mut tc_context, d_xyz: *const f32, n: usize, cfg: *const tc_normal_config, begin: usize, end: usize,
+                                            d_slice_out: *mut f32) -> c_int;
+    pub fn tc_normals_unsort_device(ctx: *mut tc_context, d_sorted_all: *const f32, n: usize, d_out: *mut f32) -> c_int;
     pub fn tc_search_index_create(ctx: *mut tc_context, cloud: *const f32, n: usize, k_hint: usize, out: *mut *mut tc_search_index) -> c_int;
     pub fn tc_search_index_size(index: *const tc_search_index) -> usize;
     pub fn tc_search_index_query(index: *mut tc_search_index, queries: *const f32, nq: usize, k: usize, radius: f32,

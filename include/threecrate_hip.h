@@ -117,6 +117,16 @@ tc_status tc_estimate_normals(tc_context *ctx, const float *xyz, size_t n,
 tc_status tc_estimate_normals_device(tc_context *ctx, const float *d_xyz, size_t n,
                                      const tc_normal_config *cfg, float *d_out_normal_points);
 
+/* Normals of ONE big cloud over several GPUs (the reference has no multi-device code): the cloud is
+ * replicated, every rank builds the same index (the cell-sorted order is deterministic) and computes the normals of the
+ * cell-sorted positions [begin, end) into d_slice_out ((end - begin) x 6 floats: position, normal -- in SORTED order);
+ * after an all-gather of the slices (RCCL; sizes are known: shard r = [r n / W, (r + 1) n / W)) every rank calls
+ * tc_normals_unsort_device to obtain the NormalPoint3f array in input order.  begin == 0, end == n on one GPU followed by
+ * the unsort is tc_estimate_normals_device.  The unsort uses the index the slice call left in the context. */
+tc_status tc_estimate_normals_slice_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *config,
+                                           size_t begin, size_t end, float *d_slice_out);
+tc_status tc_normals_unsort_device(tc_context *ctx, const float *d_sorted_all, size_t n, float *d_out);
+
 /* ---- ICP point-to-point ----
  * icp_detailed(source, target, init, max_iters, max_correspondence_distance: Option<f32>,
  *              convergence_threshold) -> Result<ICPResult>   (registration.rs:258-370)

@@ -75,6 +75,27 @@ class OracleShardBackend:
                     iterations=self.iters if self.converged else max_iters, converged=self.converged)
 
 
+class OracleNormalsBackend:
+    """Checker backend of sharded_normals: a fixed "cell-sorted" order (a permutation every rank derives the same way),
+    records of a slice from the oracle's normals, unsort = the inverse permutation."""
+
+    def __init__(self, pts, k):
+        from oracle import oracle as O
+        self.n = len(pts)
+        self.perm = np.random.default_rng(99).permutation(self.n)          # sorted position -> original index
+        self.full = O.estimate_normals(pts, k, threads=2)                  # (a real rank computes only its slice)
+        self.calls = []
+
+    def slice(self, begin, end):
+        self.calls.append((begin, end))
+        return torch.from_numpy(self.full[self.perm[begin:end]].copy())
+
+    def unsort(self, sorted_all):
+        out = np.empty((self.n, 6), np.float32)
+        out[self.perm] = sorted_all.numpy()
+        return out
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -90,7 +111,9 @@ def _worker(rank, world, port, q):
         res2 = D.sharded_icp_loop(be2, 6)
         jobs = list(range(5))
         got = D.run_independent_jobs(jobs, lambda j: (j * j, rank))
-        q.put((rank, res, res2, got))
+        nb = OracleNormalsBackend(tgt[:5001], 10)                           # odd size: unequal slices, padded gather
+        normals = D.sharded_normals(nb)
+        q.put((rank, res, res2, got, (normals, nb.calls, nb.full)))
     finally:
         dist.destroy_process_group()
 
@@ -117,7 +140,10 @@ def test_sharded_icp_world2_matches_single_process():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, a0, b0, j0), (r1, a1, b1, j1) = outs
+    (r0, a0, b0, j0, n0), (r1, a1, b1, j1, n1) = outs
+    # sharded normals: each rank computed only its slice, both hold the full array in input order
+    assert n0[1] == [(0, 2501)] and n1[1] == [(2501, 5001)]
+    assert np.array_equal(n0[0], n0[2]) and np.array_equal(n1[0], n0[2])
     # every rank ends with the bit-identical state (same reduced buffer, same solve)
     assert np.array_equal(a0["T"], a1["T"]) and a0["iterations"] == a1["iterations"] and a0["converged"] == a1["converged"]
     assert np.array_equal(b0["T"], b1["T"])

@@ -600,3 +600,22 @@ def test_far_outliers_clamped_grid_stays_exact(ctx, n):
     # same pairs; the reference's sequential f32 Kabsch sums over pairs with coordinates of several hundred carry ~1e-5
     assert frob(gg.transformation, rr.transformation, O.isometry_to_matrix) <= 1e-4
     assert time.perf_counter() - t0 < 30.0
+
+
+def test_sharded_normals_slices_reassemble(ctx):
+    """tc_estimate_normals_slice_device + tc_normals_unsort_device (normals of one replicated cloud over W
+    GPUs): the slices of W = 1, 2, 3 ranks, computed one after the other on this GPU and concatenated like the
+    all-gather would, give the bits of the single-call result; the driver function with world 1 too."""
+    from threecrate_amd import distributed as D
+    pts = synth.uniform_cloud(50001, 41, (3.0, 2.0, 1.0))
+    d = torch.from_numpy(pts).cuda()
+    cfg = tc.NormalEstimationConfig(k_neighbors=12)
+    ref = ctx.estimate_normals_with_config(d, cfg)
+    for world in (1, 2, 3):
+        parts = [ctx.estimate_normals_slice(d, cfg, *D.shard_range(len(pts), r, world)) for r in range(world)]
+        assert [len(p) for p in parts] == [b - a for a, b in (D.shard_range(len(pts), r, world) for r in range(world))]
+        out = ctx.normals_unsort(torch.cat(parts))
+        assert torch.equal(out, ref)
+    assert torch.equal(D.sharded_estimate_normals(ctx, d, 12), ref)
+    with pytest.raises(tc.InvalidData):
+        ctx.estimate_normals_slice(d, cfg, 10, len(pts) + 1)

@@ -78,7 +78,7 @@ class KernelStatC(C.Structure):
 EXPORTS = [
     "tc_abi_version", "tc_device_count", "tc_context_create", "tc_context_create_on_stream",
     "tc_context_destroy", "tc_last_error_message", "tc_synchronize", "tc_normal_config_default",
-    "tc_estimate_normals", "tc_estimate_normals_device", "tc_icp_detailed", "tc_icp_detailed_device",
+    "tc_estimate_normals", "tc_estimate_normals_device", "tc_estimate_normals_slice_device", "tc_normals_unsort_device", "tc_icp_detailed", "tc_icp_detailed_device",
     "tc_icp_point_to_point", "tc_icp", "tc_icp_point_to_plane_detailed",
     "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
     "tc_icp_shard_reduce", "tc_icp_shard_get_sums", "tc_icp_shard_set_sums", "tc_icp_shard_done",
@@ -139,6 +139,8 @@ def load():
     L.tc_normal_config_default.restype = None
     L.tc_estimate_normals.argtypes = [vp, f32p, sz, C.POINTER(NormalConfig), f32p]
     L.tc_estimate_normals_device.argtypes = [vp, f32p, sz, C.POINTER(NormalConfig), f32p]
+    L.tc_estimate_normals_slice_device.argtypes = [vp, f32p, sz, C.POINTER(NormalConfig), sz, sz, f32p]
+    L.tc_normals_unsort_device.argtypes = [vp, f32p, sz, f32p]
     L.tc_icp_detailed.argtypes = [vp, f32p, sz, f32p, sz, f32p, sz, f, f, resp]
     L.tc_icp_detailed_device.argtypes = [vp, f32p, sz, f32p, sz, f32p, sz, f, f, resp]
     L.tc_icp_point_to_point.argtypes = [vp, f32p, sz, f32p, sz, f32p, sz, f, f, resp]

@@ -203,6 +203,25 @@ class GpuContext:
         self._check(self._L.tc_estimate_normals(self._h, x.ctypes.data, x.shape[0], C.byref(c), out.ctypes.data))
         return out
 
+    def estimate_normals_slice(self, cloud, config: NormalEstimationConfig, begin: int, end: int):
+        """tc_estimate_normals_slice_device: NormalPoint3f records of the cell-sorted positions [begin, end) of the
+        device-resident cloud, in sorted order (one rank's share of a multi-GPU run, threecrate_amd.distributed)."""
+        import torch
+        c = self._cfg(config)
+        x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
+        out = torch.empty((max(end - begin, 0), 6), dtype=torch.float32, device=x.device)
+        self._check(self._L.tc_estimate_normals_slice_device(self._h, x.data_ptr(), x.shape[0], C.byref(c), int(begin), int(end), out.data_ptr()))
+        return out
+
+    def normals_unsort(self, sorted_all):
+        """tc_normals_unsort_device: the gathered slices (n, 6, sorted order) -> (n, 6) in input order; uses the index the
+        last estimate_normals_slice call left in this context."""
+        import torch
+        srt = sorted_all.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(srt)
+        self._check(self._L.tc_normals_unsort_device(self._h, srt.data_ptr(), srt.shape[0], out.data_ptr()))
+        return out
+
     def estimate_normals(self, cloud, k: int = 10):
         """normals.rs:238-247"""
         return self.estimate_normals_with_config(cloud, NormalEstimationConfig(k_neighbors=k))

@@ -82,7 +82,8 @@ static float normals_target_ppo(size_t k) {
     return (float)((K1 + 3.1 * std::sqrt(K1) + 2.0) / 11.3);
 }
 
-static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, float *d_out) {
+static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, float *d_out,
+                                size_t p_begin = 0, size_t p_end = (size_t)-1, bool slice_out = false) {
     // radius mode: ring 2 must cover the radius ball, so the cell edge is at least radius / 2
     const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
     if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(cfg->k_neighbors, n >= kAdaptMinPoints), nullptr, nullptr, nullptr, min_h,
@@ -97,7 +98,7 @@ static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, c
         const float extent = std::sqrt(ex * ex + ey * ey + ez * ez);
         vp[0] = cx + 0.0f; vp[1] = cy + 0.0f; vp[2] = cz + extent;
     }
-    return launch_normals(ctx, ctx->tgt_index, *cfg, vp, d_out);
+    return launch_normals(ctx, ctx->tgt_index, *cfg, vp, d_out, p_begin, p_end, slice_out);
 }
 
 }  // namespace tc
@@ -190,6 +191,30 @@ tc_status tc_estimate_normals_device(tc_context *ctx, const float *d_xyz, size_t
     if (empty) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (tc_status s = normals_device(ctx, d_xyz, n, cfg, d_out)) return s;
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+// ---- sharded normals of one big cloud over several GPUs ----
+tc_status tc_estimate_normals_slice_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, size_t begin,
+                                           size_t end, float *d_slice_out) {
+    bool empty;
+    if (tc_status s = normals_validate(ctx, n, cfg, &empty)) return s;
+    if (empty) return TC_OK;
+    if (begin > end || end > n) return fail(ctx, TC_INVALID_DATA, "normals slice: need begin <= end <= n");
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = normals_device(ctx, d_xyz, n, cfg, d_slice_out, begin, end, true)) return s;
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+tc_status tc_normals_unsort_device(tc_context *ctx, const float *d_sorted_all, size_t n, float *d_out) {
+    if (!ctx) return TC_INVALID_DATA;
+    if (n == 0) return TC_OK;
+    if (ctx->tgt_index.geom.n != n || !ctx->tgt_index.pts.p)
+        return fail(ctx, TC_INVALID_DATA, "normals unsort: call tc_estimate_normals_slice_device on this context with the same cloud first");
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = launch_normals_unsort(ctx, ctx->tgt_index, d_sorted_all, d_out)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
 }
@@ -644,6 +669,8 @@ tc_status tc_search_index_create_device(tc_context *ctx, const float *d_cloud, s
         tc_status rc = build_index(ctx, s->ix, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1) * 2.0f, nullptr, nullptr);
         if (rc == TC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, TC_GPU, "search index build failed");
         if (rc != TC_OK) { free_index(s->ix); delete s; return rc; }
+        // queries only need the sorted records and the cell starts: drop the build scratch (16 B per point)
+        free_buf(s->ix.cell_of); free_buf(s->ix.slot); free_buf(s->ix.arrival); free_buf(s->ix.fill); free_buf(s->ix.blocksum);
     }
     *out = s;
     return TC_OK;

@@ -42,6 +42,8 @@ struct NormalParams {
     int      R0;            // ring count of the main launch
     int      has_radius;
     float    radius;
+    uint32_t p_begin, p_end;    // cell-sorted positions handled by this launch (a multi-GPU shard: SURVEY 8e)
+    int      slice_out;         // 1: record of position p goes to row p - p_begin (sorted order) instead of its original index
 };
 
 // ---- smallest-eigenvalue eigenvector of a symmetric 3x3 (f64) -------------------------------
@@ -358,7 +360,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         const float dp = nrm_x * ux + nrm_y * uy + nrm_z * uz;
         if (dp < 0.0f) { nrm_x = -nrm_x; nrm_y = -nrm_y; nrm_z = -nrm_z; }
     }
-    float *o = out6 + 6 * (size_t)orig;
+    float *o = out6 + 6 * (size_t)(prm.slice_out ? p - prm.p_begin : orig);
     o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = nrm_x; o[4] = nrm_y; o[5] = nrm_z;
 }
 
@@ -375,14 +377,15 @@ __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, Nor
     __shared__ uint32_t ldsA[L * BLOCK];
     __shared__ uint8_t ldsB[L * BLOCK];       // ranks as bytes: 88 instead of 136 B of LDS per lane -> 7 instead of 4 waves per SIMD
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t p = lb * BLOCK + threadIdx.x;
-    if (p >= gv.g.n) return;
+    const uint32_t p = prm.p_begin + lb * BLOCK + threadIdx.x;
+    if (p >= prm.p_end) return;
     normals_point<L, BLOCK, RADIUS, EXT>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
 }
 
 template <int L, int BLOCK, bool RADIUS = false>
 static void launch_variant(hipStream_t st, const GridView &gv, const NormalParams &prm, float *out6, tc_context *ctx) {
-    const uint32_t n = gv.g.n;
+    const uint32_t n = prm.p_end - prm.p_begin;
+    if (n == 0) return;
     uint32_t nb = (n + BLOCK - 1) / BLOCK;
     nb = (nb + 7) / 8 * 8;   // xcd_remap needs a multiple of 8
     ProfScope ps(ctx, "normals_knn_pca");
@@ -506,8 +509,27 @@ tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_quer
     return TC_OK;
 }
 
+// out[6 * orig(p) ..] = sorted[6 * p ..]: the gathered slices of a sharded run back into input order
+__global__ void __launch_bounds__(256) normals_unsort_kernel(const float4 *__restrict__ pts, uint32_t n, const float *__restrict__ sorted6,
+                                                            float *__restrict__ out6) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t orig = __float_as_uint(pts[p].w);
+    const float *r = sorted6 + 6 * (size_t)p;
+    float *o = out6 + 6 * (size_t)orig;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) o[c] = r[c];
+}
+
+tc_status launch_normals_unsort(tc_context *ctx, const DeviceIndex &ix, const float *d_sorted6, float *d_out6) {
+    const uint32_t n = ix.geom.n;
+    hipLaunchKernelGGL(normals_unsort_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float4 *)ix.pts.p, n, d_sorted6, d_out6);
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg, const float vp[3],
-                         float *d_out6) {
+                         float *d_out6, size_t p_begin, size_t p_end, bool slice_out) {
     if (cfg.k_neighbors + 1 > 65) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 64 is not supported by the HIP backend");
     NormalParams prm;
     prm.k = (uint32_t)cfg.k_neighbors;
@@ -516,6 +538,9 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal
     prm.R0 = 2;
     prm.has_radius = (cfg.has_radius && cfg.radius > 0.0f) ? 1 : 0;
     prm.radius = prm.has_radius ? cfg.radius : 0.0f;
+    prm.p_begin = (uint32_t)p_begin;
+    prm.p_end = (uint32_t)std::min<size_t>(p_end, ix.geom.n);
+    prm.slice_out = slice_out ? 1 : 0;
     const GridView gv = view_of(ix);
     const uint32_t K1 = prm.k + 1;
     if (cfg.has_radius && cfg.radius > 0.0f) {   // radius <= 0 finds nothing (nearest_neighbor.rs:255): pure k-NN fallback

@@ -126,6 +126,54 @@ def sharded_icp_point_to_plane(ctx, source, target, target_normals, init=None, m
     return sharded_icp_loop(be, max_iters, group)
 
 
+class HipNormalsBackend:
+    """One rank's part of the normals of a replicated cloud: slice(begin, end) -> (end - begin, 6) records of the
+    cell-sorted positions [begin, end), unsort(all) -> (n, 6) in input order (tc_estimate_normals_slice_device /
+    tc_normals_unsort_device)."""
+
+    def __init__(self, ctx, cloud, config):
+        self.ctx, self.cloud, self.config = ctx, cloud, config
+        self.n = int(cloud.shape[0])
+
+    def slice(self, begin, end):
+        return self.ctx.estimate_normals_slice(self.cloud, self.config, begin, end)
+
+    def unsort(self, sorted_all):
+        return self.ctx.normals_unsort(sorted_all)
+
+
+def sharded_normals(backend, group=None):
+    """estimate_normals of ONE cloud over all ranks of `group` (BASELINE config [3]): the cloud and its
+    index are replicated, rank r computes the records of the cell-sorted positions shard_range(n, r, W), ONE all-gather
+    (n x 24 bytes in total; RCCL over xGMI with the "nccl" backend) hands every rank all of them, a local kernel puts
+    them back into input order.  Every rank returns the full (n, 6) array."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    n = backend.n
+    lo, hi = shard_range(n, rank, world)
+    mine = backend.slice(lo, hi)
+    if world == 1:
+        return backend.unsort(mine)
+    rows = -(-n // world)                                   # equal-sized parts for all_gather_into_tensor
+    part = torch.zeros((rows, 6), dtype=mine.dtype, device=mine.device)
+    part[: hi - lo] = mine
+    gathered = torch.empty((world * rows, 6), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(gathered, part, group=group)
+    pieces = []
+    for r in range(world):
+        a, b = shard_range(n, r, world)
+        pieces.append(gathered[r * rows: r * rows + (b - a)])
+    return backend.unsort(torch.cat(pieces))
+
+
+def sharded_estimate_normals(ctx, cloud, k=10, config=None, group=None):
+    """estimate_normals(cloud, k) (normals.rs:238-241) of a device-resident cloud replicated on every rank of `group`."""
+    from .api import NormalEstimationConfig
+    return sharded_normals(HipNormalsBackend(ctx, cloud, config or NormalEstimationConfig(k_neighbors=k)), group)
+
+
 def run_independent_jobs(jobs, run_one, group=None):
     """Independent scan pairs: rank r runs jobs[r::world] with `run_one(job)`; results are
     gathered to every rank in job order.  No data-path collective."""
