@@ -30,7 +30,7 @@ ALG_BYTES_NORMALS = 12 + 12 * K_NORMALS + 24   # = 228 B / point
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(n_points, tgt, src):
+def cpu_baseline(n_points, tgt, src, gpu_normals=None):
     """The oracle (CPU restatement of threecrate-algorithms, kind="port") timed on this box's host
     cores on a bounded sample of the same workload: full k=16 normals on the 1M cloud + the kd-tree
     build + 3 of the 50 p2plane iterations, extrapolated to the 50-iteration job."""
@@ -48,7 +48,14 @@ def cpu_baseline(n_points, tgt, src):
     t_iter = max((t4 - t1) / 3.0, 1e-9)
     t_build = max(t1 - t_iter, 0.0)
     job = t_norm + t_build + ICP_ITERS * t_iter
+    parity = None
+    if gpu_normals is not None:      # the oracle's normals of the same cloud are at hand: use them as the checker they are
+        a, b = gpu_normals[:, 3:6].astype(np.float64), nrm[:, 3:6].astype(np.float64)
+        c = np.abs((a * b).sum(1)) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-300)
+        parity = {"normals_max_1_minus_abs_cos": float(1.0 - c.min()), "normals_frac_within_1e-4": float((c >= 1.0 - 1e-4).mean()),
+                  "positions_identical": bool(np.array_equal(gpu_normals[:, :3], nrm[:, :3]))}
     return {
+        "parity": parity,
         "value": ICP_ITERS / job, "unit": "ICP it/s (whole job: normals + 50 it)", "cores": cores, "kind": "port",
         "sample": f"oracle on {n_points} pts: full k={K_NORMALS} normals ({t_norm:.2f} s) + kd-tree build ({t_build:.2f} s) + "
                   f"3 timed p2plane iterations ({t_iter:.3f} s/it) extrapolated to {ICP_ITERS}",
@@ -296,7 +303,11 @@ def main():
             out["roofline"]["traffic"] = None          # PMC passes were collected on the uniform config
             out["roofline"].pop("traffic_detail", None)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, tgt_h, src_h)
+            out["cpu_baseline"] = cpu_baseline(n, tgt_h, src_h, ctx.estimate_normals(tgt, K_NORMALS).cpu().numpy())
+            out["parity"] = out["cpu_baseline"].pop("parity")
+            if args.cloud == "uniform":   # source = T^-1 target: the registration must return the harness transform
+                out["parity"]["icp_T_frobenius_vs_truth"] = float(np.linalg.norm(
+                    tc.isometry_to_matrix(last.transformation).astype(np.float64) - synth.isometry_matrix(synth.harness_transform())))
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     ctx.close()
