@@ -277,7 +277,8 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     // (no per-row integer multiplies: v_mul_lo_u32 is quarter rate)
     const bool oky[3] = {cy > 0, true, cy < g.gy - 1}, okz[3] = {cz > 0, true, cz < g.gz - 1};
     const bool has_l = cx > 0, has_r = cx < g.gx - 1;
-    const int stride_y = g.gx, stride_z = g.gx * g.gy;
+    // (opaque to the optimiser: it otherwise re-associates every row back into ((cz + dz) * gy + cy + dy) * gx)
+    const int stride_y = __builtin_amdgcn_readfirstlane(g.gx), stride_z = __builtin_amdgcn_readfirstlane(g.gx * g.gy);
     const int row_c = (cz * g.gy + cy) * g.gx + wb;        // window start of the centre row
     const bool own1 = cx > 0;                              // window offset of the own cell's start: 1 (0 for cx == 0)
     uint32_t s0[kSpanRows], e0[kSpanRows];
