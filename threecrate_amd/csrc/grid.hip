@@ -246,7 +246,7 @@ GridView view_of(const DeviceIndex &ix) {
     GridView v;
     v.g = ix.geom;
     v.pts = (const float4 *)ix.pts.p;
-    v.cell_start = (const uint32_t *)ix.cell_start.p;
+    v.cell_start = (const uint32_t *)ix.cell_start.p + kCellStartFront;
     return v;
 }
 
@@ -417,12 +417,14 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         if (tc_status s = ensure(ctx, ix.slot, n * sizeof(uint32_t))) return s;
         if (tc_status s = ensure(ctx, ix.arrival, n * sizeof(uint32_t))) return s;
         if (tc_status s = ensure(ctx, ix.fill, (size_t)nkeys * sizeof(uint32_t))) return s;
-        if (tc_status s = ensure(ctx, ix.cell_start, ((size_t)nkeys + 1 + kCellStartPad) * sizeof(uint32_t))) return s;
+        if (tc_status s = ensure(ctx, ix.cell_start, (kCellStartFront + (size_t)nkeys + 1 + kCellStartPad) * sizeof(uint32_t))) return s;
+        uint32_t *const cs = (uint32_t *)ix.cell_start.p + kCellStartFront;       // zeros in front (the ICP window of cell 0 starts at -1)
 
         TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)nkeys * sizeof(uint32_t), st));
         // records past the end: huge finite coordinates -> d2 = +inf, never a match (kernels may read, never select them)
         TC_HIP_TRY(ctx, hipMemsetAsync((float4 *)ix.pts.p + n, 0x7F, kPtsPad * sizeof(float4), st));
-        TC_HIP_TRY(ctx, hipMemsetAsync((uint32_t *)ix.cell_start.p + nkeys + 1, 0, kCellStartPad * sizeof(uint32_t), st));
+        TC_HIP_TRY(ctx, hipMemsetAsync(cs + nkeys + 1, 0, kCellStartPad * sizeof(uint32_t), st));
+        TC_HIP_TRY(ctx, hipMemsetAsync(ix.cell_start.p, 0, kCellStartFront * sizeof(uint32_t), st));
         {
             ProfScope ps(ctx, "cell_hist");
             hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0,
@@ -430,7 +432,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         }
         {
             ProfScope ps(ctx, "cell_scan");
-            if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, nkeys, (uint32_t *)ix.cell_start.p, ix.blocksum)) return s;
+            if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, nkeys, cs, ix.blocksum)) return s;
         }
         const bool check = adapt && attempt < 3;
         uint32_t *h_occ = (uint32_t *)((char *)ctx->pinned + 2048 + 8192);
@@ -441,12 +443,12 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         {
             ProfScope ps(ctx, "cell_scatter");
             hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)ix.cell_of.p, n32,
-                               (const uint32_t *)ix.cell_start.p, (const uint32_t *)ix.arrival.p, (uint32_t *)ix.slot.p);
+                               (const uint32_t *)cs, (const uint32_t *)ix.arrival.p, (uint32_t *)ix.slot.p);
         }
         {
             ProfScope ps(ctx, "cell_rank_gather");
             hipLaunchKernelGGL(rank_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, (const uint32_t *)ix.cell_of.p,
-                               (const uint32_t *)ix.cell_start.p, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p);
+                               (const uint32_t *)cs, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p);
         }
         TC_HIP_TRY(ctx, hipGetLastError());
         if (!check) break;

@@ -271,16 +271,14 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     // nine rows back to back and without branches (one round trip): it holds the start of the left,
     // own and right cell and the end of the right cell.  A row the ball does not reach reads window 0
     // and becomes the empty span.  (cell_start is padded by kCellStartPad entries.)
-    const __amdgpu_buffer_rsrc_t cs_rsrc = raw_rsrc(gv.cell_start);
-    const int wb = max(cx - 1, 0);
+    const __amdgpu_buffer_rsrc_t cs_rsrc = raw_rsrc(gv.cell_start - 1);      // window of cell c starts at entry c - 1 (zeros in front of the array)
     // per-axis facts shared by the nine rows; row starts by adding uniform strides to the centre row
     // (no per-row integer multiplies: v_mul_lo_u32 is quarter rate)
     const bool oky[3] = {cy > 0, true, cy < g.gy - 1}, okz[3] = {cz > 0, true, cz < g.gz - 1};
     const bool has_l = cx > 0, has_r = cx < g.gx - 1;
     // (opaque to the optimiser: it otherwise re-associates every row back into ((cz + dz) * gy + cy + dy) * gx)
     const int stride_y = __builtin_amdgcn_readfirstlane(g.gx), stride_z = __builtin_amdgcn_readfirstlane(g.gx * g.gy);
-    const int row_c = (cz * g.gy + cy) * g.gx + wb;        // window start of the centre row
-    const bool own1 = cx > 0;                              // window offset of the own cell's start: 1 (0 for cx == 0)
+    const int row_c = (cz * g.gy + cy) * g.gx + cx;        // window start (+1) of the centre row
     uint32_t s0[kSpanRows], e0[kSpanRows];
     uint32_t mask = 0;
 #pragma unroll
@@ -292,10 +290,9 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         const bool left = has_l && !(r2 + ax2[0] > ub), right = has_r && !(r2 + ax2[2] > ub);
         const int row = row_c + dz * stride_z + dy * stride_y;
         const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(cs_rsrc, on ? (uint32_t)row << 2 : 0u, 0, 0);
-        // window = starts of the cells wb .. wb+3; span = [start of cell cx - left, start of cell cx + right + 1)
-        const uint32_t lo = own1 ? w.z : w.y, hi = own1 ? w.w : w.z;
-        s0[k] = (left || !own1) ? w.x : w.y;
-        e0[k] = right ? hi : lo;
+        // window = starts of the cells cx-1 .. cx+2; span = [start of cell cx - left, start of cell cx + right + 1)
+        s0[k] = left ? w.x : w.y;
+        e0[k] = right ? w.w : w.z;
         if (on && s0[k] != e0[k]) mask |= 1u << k;         // rows the ball reaches, non-empty spans only
     }
 #pragma unroll

@@ -69,6 +69,7 @@ constexpr int kIcpBlock = 256;
 // padding behind the sorted records / the prefix sums: the ICP search reads a few entries past a
 // span (4-wide steps) and 16-byte windows of cell_start without clamping
 constexpr size_t kPtsPad = 4, kCellStartPad = 4;
+constexpr size_t kCellStartFront = 4;            // zero entries in front of the prefix sums (16-byte aligned start)
 constexpr int kMaxPartialBlocks = 1024;         // plan_launch: one round of 4 blocks per CU
 // clouds from this size on get the occupancy-adapted cell edge (one host round trip + possibly a rebuild)
 constexpr uint32_t kAdaptMinPoints = 1u << 18;   // 2^17: a 230 k-point depth frame gets slower (normals 0.67 -> 0.71 ms, 10 ICP iterations 1.5 -> 2.8 ms)
