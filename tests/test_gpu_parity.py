@@ -619,3 +619,27 @@ def test_sharded_normals_slices_reassemble(ctx):
     assert torch.equal(D.sharded_estimate_normals(ctx, d, 12), ref)
     with pytest.raises(tc.InvalidData):
         ctx.estimate_normals_slice(d, cfg, 10, len(pts) + 1)
+
+
+def test_organised_scan_order_does_not_fool_the_sampled_box(ctx):
+    """The sampled boxes that detect far outliers (grid.hip) must not be periodic in the point index: a 64-beam sweep stored
+    azimuth-major has index mod 64 = beam.  Same cloud in both storage orders: same normals, similar time."""
+    import time
+    beam_major = synth.kitti_shaped_cloud(seed=6)                                  # (64 x 1875) beam-major
+    az_major = np.ascontiguousarray(beam_major.reshape(64, 1875, 3).transpose(1, 0, 2).reshape(-1, 3))
+    t = []
+    outs = []
+    for pts in (beam_major, az_major):
+        d = torch.from_numpy(pts).cuda()
+        ctx.estimate_normals(d, 10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            o = ctx.estimate_normals(d, 10)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter() - t0)
+        outs.append(o.cpu().numpy())
+    back = outs[1].reshape(1875, 64, 6).transpose(1, 0, 2).reshape(-1, 6)
+    assert np.array_equal(back[:, :3], outs[0][:, :3])
+    assert (cos_abs(back[:, 3:], outs[0][:, 3:]) >= 1 - 1e-6).mean() > 0.999       # same neighbour sets, same normals
+    assert t[1] < 3.0 * t[0] + 1e-3

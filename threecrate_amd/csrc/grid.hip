@@ -35,23 +35,40 @@ __device__ __forceinline__ void isometry_apply(const float q[4], const float t[3
 // per-block bounding box partials (6 floats per block); the host folds the <= 256 rows
 // (min / max are order independent, so the result equals the reference's sequential fold).
 constexpr int kBboxBlocks = 256;
-// sbox (optional): four SAMPLE boxes per block -- the private boxes of lanes 0..3 of every wave, i.e. of the points
-// with index = 0..3 mod 64 (the grid stride is a multiple of 64).  A handful of far outliers shows up in the exact box
-// but almost never in three of four 1/64 samples: the host compares them (cloud_bbox_robust).
+// sbox (optional): four SAMPLE boxes per block.  Sample s = the points with index = s mod 4 whose multiplicative hash
+// falls into one sixteenth of its range: ~n/64 points each, pseudo-random in the index (NOT every 64th point: organised
+// scans are periodic in 64 -- beams, image columns -- and a sample must not be one beam).  A handful of far outliers
+// shows up in the exact box but almost never in three of the four samples: the host compares them (cloud_bbox_impl).
 __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, float *__restrict__ box,
                                                   float *__restrict__ sbox) {
     __shared__ float sm[4][6];
     __shared__ float ss[4][4][6];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float smn[3] = {INFINITY, INFINITY, INFINITY}, smx[3] = {-INFINITY, -INFINITY, -INFINITY};     // this thread's share of sample (lane & 3)
     // each thread reads whole points; consecutive lanes read consecutive 12-B records
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
         mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);   // fminf ignores NaN
         mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+        if (sbox && ((i * 2654435761u) >> 28) == 0u) {
+            smn[0] = fminf(smn[0], x); smn[1] = fminf(smn[1], y); smn[2] = fminf(smn[2], z);
+            smx[0] = fmaxf(smx[0], x); smx[1] = fmaxf(smx[1], y); smx[2] = fmaxf(smx[2], z);
+        }
     }
-    if (sbox && (threadIdx.x & 63) < 4) {
+    if (sbox) {
+        // fold the lanes of equal (lane & 3): i = lane mod 4 for every point of the thread (the stride is a multiple of 64)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { ss[threadIdx.x >> 6][threadIdx.x & 63][c] = mn[c]; ss[threadIdx.x >> 6][threadIdx.x & 63][3 + c] = mx[c]; }
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int o = 32; o >= 4; o >>= 1) {
+                smn[c] = fminf(smn[c], __shfl_xor(smn[c], o));
+                smx[c] = fmaxf(smx[c], __shfl_xor(smx[c], o));
+            }
+        }
+        if ((threadIdx.x & 63) < 4) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { ss[threadIdx.x >> 6][threadIdx.x & 63][c] = smn[c]; ss[threadIdx.x >> 6][threadIdx.x & 63][3 + c] = smx[c]; }
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
