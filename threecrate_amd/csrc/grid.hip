@@ -38,7 +38,7 @@ constexpr int kBboxBlocks = 256;
 // sbox (optional): four SAMPLE boxes per block.  Sample s = the points with index = s mod 4 whose multiplicative hash
 // falls into one sixteenth of its range: ~n/64 points each, pseudo-random in the index (NOT every 64th point: organised
 // scans are periodic in 64 -- beams, image columns -- and a sample must not be one beam).  A handful of far outliers
-// shows up in the exact box but almost never in three of the four samples: the host compares them (cloud_bbox_impl).
+// shows up in the exact box but almost never in more than two of the four samples: the host compares them (cloud_bbox_impl).
 __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, float *__restrict__ box,
                                                   float *__restrict__ sbox) {
     __shared__ float sm[4][6];
@@ -328,7 +328,7 @@ tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, 
     return TC_OK;
 }
 
-// exact box in mn / mx; with `rmn` also the box the grid should span: per axis the exact range unless three of the
+// exact box in mn / mx; with `rmn` also the box the grid should span: per axis the exact range unless two of the
 // four sample boxes agree that it is more than 1.3 x wider than the cloud proper (far outliers: a flying pixel, a
 // stray return), in which case the sampled range + 5 % -- points outside are indexed in the boundary cells.
 static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3], float *rmn, float *rmx,
