@@ -100,6 +100,9 @@ extern "C" {
     pub fn tc_search_index_size(index: *const tc_search_index) -> usize;
     pub fn tc_search_index_query(index: *mut tc_search_index, queries: *const f32, nq: usize, k: usize, radius: f32,
                                  idx: *mut u32, dist: *mut f32, count: *mut u32) -> c_int;
+    pub fn tc_search_index_radius_count(index: *mut tc_search_index, queries: *const f32, nq: usize, radius: f32, counts: *mut u32) -> c_int;
+    pub fn tc_search_index_radius_fill(index: *mut tc_search_index, queries: *const f32, nq: usize, radius: f32, offsets: *const u64, total: usize,
+                                       idx: *mut u32, dist: *mut f32) -> c_int;
     pub fn tc_search_index_destroy(index: *mut tc_search_index);
     pub fn tc_voxel_grid_filter(ctx: *mut tc_context, xyz: *const f32, n: usize, voxel_size: f32, out: *mut f32, n_out: *mut usize) -> c_int;
     pub fn tc_frame_stream_create(ctx: *mut tc_context, cfg: *const tc_frame_stream_config, out: *mut *mut tc_frame_stream) -> c_int;

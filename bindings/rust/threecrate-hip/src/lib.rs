@@ -272,10 +272,20 @@ impl NearestNeighborSearch for HipKdTree<'_> {
         self.query(std::slice::from_ref(query), k.min(self.len()).min(65), -1.0).map(|mut v| v.remove(0)).unwrap_or_default()
     }
 
-    /// the neighbours within `radius`, nearest first; at most the 65 nearest (limit of the backend's selection lists)
+    /// every neighbour within `radius`, nearest first (nearest_neighbor.rs:254-298): count, then fill
     fn find_radius_neighbors(&self, query: &Point3f, radius: f32) -> Vec<(usize, f32)> {
-        if !(radius > 0.0) { return Vec::new(); }
-        self.query(std::slice::from_ref(query), self.len().min(65), radius).map(|mut v| v.remove(0)).unwrap_or_default()
+        if !(radius > 0.0) || self.is_empty() { return Vec::new(); }
+        let q = query as *const Point3f as *const f32;
+        let mut count = 0u32;
+        if self.ctx.check(unsafe { ffi::tc_search_index_radius_count(self.raw, q, 1, radius, &mut count) }).is_err() { return Vec::new(); }
+        let total = count as usize;
+        let (mut idx, mut dist, offsets) = (vec![0u32; total], vec![0f32; total], [0u64]);
+        if total > 0 && self.ctx.check(unsafe {
+            ffi::tc_search_index_radius_fill(self.raw, q, 1, radius, offsets.as_ptr(), total, idx.as_mut_ptr(), dist.as_mut_ptr())
+        }).is_err() { return Vec::new(); }
+        let mut out: Vec<(usize, f32)> = idx.into_iter().map(|i| i as usize).zip(dist).collect();
+        out.sort_by(|a, b| a.1.partial_cmp(&b.1).unwrap_or(std::cmp::Ordering::Equal));
+        out
     }
 }
 

@@ -303,6 +303,13 @@ tc_status tc_search_index_query(tc_search_index *index, const float *queries, si
                                 uint32_t *idx, float *dist, uint32_t *count);
 tc_status tc_search_index_query_device(tc_search_index *index, const float *d_queries, size_t nq, size_t k, float radius,
                                        uint32_t *d_idx, float *d_dist, uint32_t *d_count);
+/* find_radius_neighbors without a cap (nearest_neighbor.rs:254-298: every point with d2 <= radius^2): count per query,
+ * then fill -- the caller turns the counts into offsets (exclusive prefix sum, `total` = their sum) and receives
+ * (original index, distance = sqrt(d2)) at [offsets[q], offsets[q] + counts[q]) in the index's scan order; sort a
+ * query's segment by distance to obtain the reference's order.  Host buffers.  radius <= 0 -> all counts 0. */
+tc_status tc_search_index_radius_count(tc_search_index *index, const float *queries, size_t nq, float radius, uint32_t *counts);
+tc_status tc_search_index_radius_fill(tc_search_index *index, const float *queries, size_t nq, float radius, const uint64_t *offsets,
+                                      size_t total, uint32_t *idx, float *dist);
 void tc_search_index_destroy(tc_search_index *index);
 
 /* ---- voxel_grid_filter ----

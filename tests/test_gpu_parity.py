@@ -643,3 +643,29 @@ def test_organised_scan_order_does_not_fool_the_sampled_box(ctx):
     assert np.array_equal(back[:, :3], outs[0][:, :3])
     assert (cos_abs(back[:, 3:], outs[0][:, 3:]) >= 1 - 1e-6).mean() > 0.999       # same neighbour sets, same normals
     assert t[1] < 3.0 * t[0] + 1e-3
+
+
+def test_unbounded_radius_search_matches_brute_force(ctx):
+    """tc_search_index_radius_count / _fill: NearestNeighborSearch::find_radius_neighbors without a cap (hundreds of
+    neighbours per query), inside / outside / far queries, empty results, a clamped box; compat.KdTree.radius_search"""
+    import threecrate_amd.compat as threecrate
+    pts = synth.uniform_cloud(40000, 51, (2.0, 2.0, 1.0))
+    pts[7] = [90.0, 1.0, 0.5]                                   # far outlier: clamped box
+    q = np.concatenate([pts[:50], np.array([[1.0, 1.0, 3.0], [90.0, 1.0, 0.52], [-5.0, -5.0, -5.0]], np.float32)]).astype(np.float32)
+    ix = tc.SearchIndex(ctx, pts)
+    for radius in (0.02, 0.2, 0.0, 2.5):
+        off, idx, dist = ix.find_radius_neighbors_all(q, radius)
+        assert len(off) == len(q) + 1 and off[-1] == len(idx) == len(dist)
+        for j in range(len(q)):
+            d2 = ((pts - q[j]) ** 2).astype(np.float32)
+            d2 = (d2[:, 0] + d2[:, 1]) + d2[:, 2]                # (a - b) per component, left to right like nearest_neighbor.rs:162-167
+            want = np.nonzero(d2 <= np.float32(radius) * np.float32(radius))[0] if radius > 0 else np.zeros(0, np.int64)
+            got = idx[off[j]:off[j + 1]]
+            assert np.array_equal(np.sort(got), want)
+            seg = dist[off[j]:off[j + 1]]
+            assert np.all(np.diff(seg) >= 0) and np.array_equal(seg, np.sqrt(d2[got]))
+    assert (off[1:] - off[:-1]).max() > 500                     # far beyond the 65-entry selection lists
+    tree = threecrate.KdTree(threecrate.PointCloud(pts))
+    ri, rd = tree.radius_search(pts[3], 0.2)
+    assert len(ri) > 65 and ri[0] == 3 and rd[0] == 0.0 and rd == sorted(rd)
+    ix.close()

@@ -85,7 +85,7 @@ EXPORTS = [
     "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
     "tc_multiscale_icp_point_to_point", "tc_gicp", "tc_gicp_device", "tc_kiss_icp", "tc_kiss_icp_device", "tc_knn", "tc_knn_device", "tc_radius_search", "tc_radius_search_device",
     "tc_search_index_create", "tc_search_index_create_device", "tc_search_index_size", "tc_search_index_query",
-    "tc_search_index_query_device", "tc_search_index_destroy", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device",
+    "tc_search_index_query_device", "tc_search_index_radius_count", "tc_search_index_radius_fill", "tc_search_index_destroy", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device",
     "tc_frame_stream_create", "tc_frame_stream_send", "tc_frame_stream_try_send", "tc_frame_stream_finish",
     "tc_frame_stream_destroy", "tc_read_kitti_bin", "tc_profile_enable", "tc_profile_reset", "tc_profile_read",
 ]
@@ -174,6 +174,8 @@ def load():
     L.tc_search_index_size.restype = sz
     L.tc_search_index_query.argtypes = [vp, f32p, sz, sz, f, vp, vp, vp]
     L.tc_search_index_query_device.argtypes = [vp, f32p, sz, sz, f, vp, vp, vp]
+    L.tc_search_index_radius_count.argtypes = [vp, f32p, sz, f, vp]
+    L.tc_search_index_radius_fill.argtypes = [vp, f32p, sz, f, vp, sz, vp, vp]
     L.tc_search_index_destroy.argtypes = [vp]
     L.tc_search_index_destroy.restype = None
     L.tc_voxel_grid_filter.argtypes = [vp, f32p, sz, f, f32p, C.POINTER(C.c_size_t)]

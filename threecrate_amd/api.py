@@ -718,6 +718,25 @@ class SearchIndex:
         """the neighbours within radius among the k_max nearest; count[q] == k_max: there may be more"""
         return self._query(queries, k_max, max(float(radius), 0.0))
 
+    def find_radius_neighbors_all(self, queries, radius: float):
+        """NearestNeighborSearch::find_radius_neighbors (nearest_neighbor.rs:254-298) for many host queries, WITHOUT a cap:
+        (offsets (nq + 1,) int64, idx (total,) int64, dist (total,) f32); query q owns [offsets[q], offsets[q + 1]),
+        ascending by distance like the reference's final sort."""
+        q = _as_host(queries)
+        cnt = np.zeros(len(q), np.uint32)
+        self._ctx._check(self._L.tc_search_index_radius_count(self._h, q.ctypes.data, q.shape[0], float(radius), cnt.ctypes.data))
+        off = np.zeros(len(q) + 1, np.uint64)
+        np.cumsum(cnt, out=off[1:])
+        total = int(off[-1])
+        idx, dist = np.zeros(total, np.uint32), np.zeros(total, np.float32)
+        if total:
+            self._ctx._check(self._L.tc_search_index_radius_fill(self._h, q.ctypes.data, q.shape[0], float(radius), off.ctypes.data, total,
+                                                                 idx.ctypes.data, dist.ctypes.data))
+            seg = np.repeat(np.arange(len(q)), cnt.astype(np.int64))
+            order = np.lexsort((idx, dist, seg))            # per query: by distance, ties by index
+            idx, dist = idx[order], dist[order]
+        return off.astype(np.int64), idx.astype(np.int64), dist
+
     def find_k_nearest(self, query, k: int):
         idx, dist, cnt = self.find_k_nearest_batch(np.asarray(query, np.float32).reshape(1, 3), k)
         return [(int(idx[0, i]), float(dist[0, i])) for i in range(int(cnt[0]))]

@@ -164,8 +164,6 @@ class KdTree:
     queried; results as KdTree::find_k_nearest / find_radius_neighbors (nearest_neighbor.rs:177-298), radius results
     nearest first."""
 
-    _K_MAX = 65            # register-list instantiations of the k-NN kernel
-
     def __init__(self, cloud):
         self._n = len(cloud)                 # an empty cloud gives an empty tree (nearest_neighbor.rs:38-45)
         self._ix = _run(_api.SearchIndex, _api.default_context(), cloud._p)
@@ -181,10 +179,8 @@ class KdTree:
         q = _query3(query)
         if self._n == 0:
             return [], []
-        pairs = _run(self._ix.find_radius_neighbors, q, float(radius), min(self._K_MAX, self._n))
-        if len(pairs) >= self._K_MAX:
-            raise RuntimeError(f"radius_search: {self._K_MAX} or more neighbours within the radius (limit of this backend)")
-        return [i for i, _ in pairs], [d for _, d in pairs]
+        _, idx, dist = _run(self._ix.find_radius_neighbors_all, q.reshape(1, 3), float(radius))
+        return [int(i) for i in idx], [float(d) for d in dist]
 
     def __repr__(self):
         return "KdTree"

@@ -729,6 +729,46 @@ tc_status tc_search_index_query(tc_search_index *s, const float *queries, size_t
     return TC_OK;
 }
 
+// find_radius_neighbors without a cap (nearest_neighbor.rs:254-298): count, then fill at the caller's offsets
+tc_status tc_search_index_radius_count(tc_search_index *s, const float *queries, size_t nq, float radius, uint32_t *counts) {
+    if (!s) return TC_INVALID_DATA;
+    tc_context *ctx = s->ctx;
+    if (nq == 0) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!(radius > 0.0f) || s->n == 0) { std::memset(counts, 0, nq * sizeof(uint32_t)); return TC_OK; }      // :255-257
+    if (nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    if (tc_status rc = ensure(ctx, s->q, nq * 3 * sizeof(float))) return rc;
+    if (tc_status rc = ensure(ctx, s->out, nq * sizeof(uint32_t))) return rc;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(s->q.p, queries, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (tc_status rc = launch_radius_all(ctx, s->ix, (const float *)s->q.p, nq, radius, (uint32_t *)s->out.p, nullptr, nullptr, nullptr)) return rc;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(counts, s->out.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+tc_status tc_search_index_radius_fill(tc_search_index *s, const float *queries, size_t nq, float radius, const uint64_t *offsets, size_t total,
+                                      uint32_t *idx, float *dist) {
+    if (!s) return TC_INVALID_DATA;
+    tc_context *ctx = s->ctx;
+    if (nq == 0 || total == 0) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!(radius > 0.0f) || s->n == 0) return fail(ctx, TC_INVALID_DATA, "radius fill: nothing to fill for this radius (total must be 0)");
+    const size_t q_bytes = (nq * 3 * sizeof(float) + 7) / 8 * 8;
+    if (tc_status rc = ensure(ctx, s->q, q_bytes + nq * sizeof(uint64_t))) return rc;
+    if (tc_status rc = ensure(ctx, s->out, total * 8)) return rc;
+    float *d_q = (float *)s->q.p;
+    unsigned long long *d_off = (unsigned long long *)((char *)s->q.p + q_bytes);
+    uint32_t *d_idx = (uint32_t *)s->out.p;
+    float *d_dist = (float *)(d_idx + total);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(d_q, queries, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(d_off, offsets, nq * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (tc_status rc = launch_radius_all(ctx, s->ix, d_q, nq, radius, nullptr, d_off, d_idx, d_dist)) return rc;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(idx, d_idx, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
 void tc_search_index_destroy(tc_search_index *s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);

@@ -487,6 +487,52 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
     out_count[t] = within;
 }
 
+// ---- unbounded radius search: NearestNeighborSearch::find_radius_neighbors (nearest_neighbor.rs:254-298) ----------
+// every cloud point with d2 <= radius^2, two launches: count per query, then fill at the caller's offsets (grid scan
+// order; the callers sort by distance like the reference's final sort_by).
+template <bool EXT, bool FILL>
+__global__ void __launch_bounds__(128) radius_all_kernel(GridView gv, const float *__restrict__ queries, uint32_t nq, float radius,
+                                                        uint32_t *__restrict__ counts, const unsigned long long *__restrict__ offsets,
+                                                        uint32_t *__restrict__ out_idx, float *__restrict__ out_dist) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq) return;
+    const GridGeom &g = gv.g;
+    float4 q;
+    q.x = queries[3 * (size_t)t]; q.y = queries[3 * (size_t)t + 1]; q.z = queries[3 * (size_t)t + 2]; q.w = 0.0f;
+    const float qx = fminf(fmaxf(q.x, g.minx), g.maxx), qy = fminf(fmaxf(q.y, g.miny), g.maxy), qz = fminf(fmaxf(q.z, g.minz), g.maxz);
+    const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx), cy = cell_coord(qy, g.miny, g.inv_h, g.gy), cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
+    const float r2 = radius * radius;                                                 // nearest_neighbor.rs:259
+    // cells further than this from the query's (clamped) cell cannot hold a point of the ball
+    const int R = (int)fminf(ceilf(radius * g.inv_h) + 1.0f, (float)max(g.gx, max(g.gy, g.gz)));
+    const unsigned long long base = FILL ? offsets[t] : 0ull;
+    uint32_t cnt = 0;
+    scan_pruned<EXT>(gv, q, cx, cy, cz, -1, R, r2, [&](uint32_t, const float4 &c) {
+        const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+        if (v <= r2) {                                                                 // :271
+            if (FILL) { out_idx[base + cnt] = __float_as_uint(c.w); out_dist[base + cnt] = sqrtf(v); }
+            ++cnt;
+        }
+    });
+    if (!FILL) counts[t] = cnt;
+}
+
+tc_status launch_radius_all(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, float radius, uint32_t *d_counts,
+                            const unsigned long long *d_offsets, uint32_t *d_idx, float *d_dist) {
+    const GridView gv = view_of(ix);
+    ProfScope ps(ctx, d_offsets ? "radius_fill" : "radius_count");
+    const dim3 grid((unsigned)((nq + 127) / 128)), block(128);
+    hipStream_t st = ctx->stream;
+    if (!d_offsets) {
+        if (gv.g.clamped) hipLaunchKernelGGL((radius_all_kernel<true, false>), grid, block, 0, st, gv, d_queries, (uint32_t)nq, radius, d_counts, nullptr, nullptr, nullptr);
+        else hipLaunchKernelGGL((radius_all_kernel<false, false>), grid, block, 0, st, gv, d_queries, (uint32_t)nq, radius, d_counts, nullptr, nullptr, nullptr);
+    } else {
+        if (gv.g.clamped) hipLaunchKernelGGL((radius_all_kernel<true, true>), grid, block, 0, st, gv, d_queries, (uint32_t)nq, radius, nullptr, d_offsets, d_idx, d_dist);
+        else hipLaunchKernelGGL((radius_all_kernel<false, true>), grid, block, 0, st, gv, d_queries, (uint32_t)nq, radius, nullptr, d_offsets, d_idx, d_dist);
+    }
+    TC_HIP_TRY(ctx, hipGetLastError());
+    return TC_OK;
+}
+
 tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, size_t k,
                      uint32_t *d_idx, float *d_dist, uint32_t *d_count, float radius_sq) {
     if (k > 65) return fail(ctx, TC_UNSUPPORTED, "k > 65 is not supported by the HIP k-NN export");
