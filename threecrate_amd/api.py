@@ -718,6 +718,13 @@ class SearchIndex:
         """the neighbours within radius among the k_max nearest; count[q] == k_max: there may be more"""
         return self._query(queries, k_max, max(float(radius), 0.0))
 
+    def radius_counts(self, queries, radius: float):
+        """number of cloud points within `radius` of every host query (tc_search_index_radius_count)"""
+        q = _as_host(queries)
+        cnt = np.zeros(len(q), np.uint32)
+        self._ctx._check(self._L.tc_search_index_radius_count(self._h, q.ctypes.data, q.shape[0], float(radius), cnt.ctypes.data))
+        return cnt
+
     def find_radius_neighbors_all(self, queries, radius: float):
         """NearestNeighborSearch::find_radius_neighbors (nearest_neighbor.rs:254-298) for many host queries, WITHOUT a cap:
         (offsets (nq + 1,) int64, idx (total,) int64, dist (total,) f32); query q owns [offsets[q], offsets[q + 1]),
