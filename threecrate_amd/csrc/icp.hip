@@ -172,6 +172,49 @@ __device__ __forceinline__ void wave_sum_f32x7(float (&v)[7]) {
 }
 #undef TC_DPP7
 
+// Sum NACC (<= 32) per-lane values over the 64 lanes of a wave into row[0 .. NACC) (f64, += by one lane per slot).
+// A transposing reduction: at every step a lane keeps one half of its values and sends the other half to its partner, so
+// the work halves with the lane distance (32 -> 16 -> 8 -> 4 -> 2 values per lane; 3 instructions per kept value) instead
+// of six full butterfly steps per value; lane j of row 0 ends with the totals of slots s(j) and s(j) + 16.  The DPP
+// partners are i^1, i^2, i^7 (row_half_mirror) and i^15 (row_mirror); the keep / send choice of a step must agree between
+// the partners of all LATER steps, hence f1 = b0^b2, f2 = b1^b2, f3 = b2^b3, f4 = b3.  Fixed tree: reproducible sums.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int N, int CTRL>
+__device__ __forceinline__ void transpose_step(const float (&in)[2 * N], float (&out)[N], bool f) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const float keep = f ? in[2 * m + 1] : in[2 * m], send = f ? in[2 * m] : in[2 * m + 1];
+        out[m] = keep + dpp_move<CTRL>(send);
+    }
+}
+template <int NACC>
+__device__ __forceinline__ void wave_fold_transposed(const float (&acc)[NACC], double *__restrict__ row, int lane) {
+    static_assert(NACC <= 32, "32 slots");
+    float v[32], w[16], u[8], t4[4], t2[2];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = i < NACC ? acc[i] : 0.0f;
+    const int b = lane;
+    const bool f1 = ((b ^ (b >> 2)) & 1) != 0, f2 = (((b >> 1) ^ (b >> 2)) & 1) != 0, f3 = (((b >> 2) ^ (b >> 3)) & 1) != 0,
+               f4 = ((b >> 3) & 1) != 0;
+    transpose_step<16, 0xB1>(v, w, f1);       // quad_perm [1,0,3,2]
+    transpose_step<8, 0x4E>(w, u, f2);        // quad_perm [2,3,0,1]
+    transpose_step<4, 0x141>(u, t4, f3);      // row_half_mirror
+    transpose_step<2, 0x140>(t4, t2, f4);     // row_mirror
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {             // the four rows hold the same slots lane by lane
+        t2[m] += __shfl_xor(t2[m], 16);
+        t2[m] += __shfl_xor(t2[m], 32);
+    }
+    if (lane < 16) {
+        const int s0 = (f4 ? 8 : 0) + (f3 ? 4 : 0) + (f2 ? 2 : 0) + (f1 ? 1 : 0);
+        if (s0 < NACC) row[s0] += (double)t2[0];
+        if (s0 + 16 < NACC) row[s0 + 16] += (double)t2[1];
+    }
+}
+
 template <int NACC, int NW = kIcpBlock / 64>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double *__restrict__ out_row, double (*sm)[TC_ICP_SUMS_STRIDE],
                                                    double extra = 0.0) {
@@ -560,23 +603,8 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
                 accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, cv, nv);
             }
         }
-        // per-group fold: DPP wave sum (f32, fixed tree) -> this wave's f64 row
-#pragma unroll
-        for (int i0 = 0; i0 + 7 <= NACC; i0 += 7) {
-            float v7[7];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) v7[i] = acc[i0 + i];
-            wave_sum_f32x7(v7);
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < 7; ++i) red[w][i0 + i] += (double)v7[i];
-            }
-        }
-#pragma unroll
-        for (int i = NACC / 7 * 7; i < NACC; ++i) {
-            const float tot = wave_sum_f32(acc[i]);
-            if (lane == 0) red[w][i] += (double)tot;
-        }
+        // per-group fold: transposing wave reduction (f32, fixed tree) -> this wave's f64 row
+        wave_fold_transposed<NACC>(acc, red[w], lane);
     }
     __syncthreads();
     if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
