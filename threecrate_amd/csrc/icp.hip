@@ -67,111 +67,6 @@ __device__ __forceinline__ float axis_gap(float q, float mn, float h, int c, int
     return fmaxf(fmaxf(a, b) - 2e-3f * h, 0.0f);
 }
 
-// exact nearest record of the target grid to (x, y, z) straight from HBM/L2 (no staging);
-// the query may lie outside the grid.  Continues from ring `R` with the best match so far
-// (best, bestj = cell-sorted position); R == 1 scans the full 3x3x3 block, R >= 2 only the shell.
-// Used for queries whose ring-1 answer is not provably exact and for tiles that do not fit LDS.
-__device__ __forceinline__ void nn_search_global(const GridView &gv, float x, float y, float z, float max_dist,
-                                                 int R, float &best, uint32_t &bestj) {
-    const GridGeom &g = gv.g;
-    const float qx = fminf(fmaxf(x, g.minx), g.maxx), qy = fminf(fmaxf(y, g.miny), g.maxy),
-                qz = fminf(fmaxf(z, g.minz), g.maxz);
-    const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx);
-    const int cy = cell_coord(qy, g.miny, g.inv_h, g.gy);
-    const int cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
-    float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy,
-          fz = (qz - g.minz) * g.inv_h - (float)cz;
-    float mf = fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz));
-    mf = fmaxf(mf, 0.0f);
-    // query outside the grid: q' = clamp(q) is its projection onto the (convex) box, so every
-    // record p satisfies |p - q|^2 >= |p - q'|^2 + |q - q'|^2
-    const float out2 = outside_d2(x, y, z, qx, qy, qz, g.clamped);
-    auto span = [&](uint32_t row, int xa, int xb) {
-        const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
-        for (uint32_t j = s; j < e; ++j) {
-            const float4 c = gv.pts[j];
-            const float v = d2_nc(c.x, c.y, c.z, x, y, z);
-            if (v < best || (v == best && j < bestj)) { best = v; bestj = j; }   // ties: lowest position
-        }
-    };
-    for (;; ++R) {
-        const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
-        const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
-        const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
-        // ball pruning: only cells whose box is within sqrt(best) of the query can improve the match.
-        // The ball intersected with the grid box is convex and contains clamp(q), so once a whole
-        // shell misses it every farther shell does too.
-        bool touched = (R == 1);
-        for (int zz = z0; zz <= z1; ++zz) {
-            const float gz = axis_gap(z, g.minz, g.h, zz, g.gz - 1, g.clamped);
-            for (int yy = y0; yy <= y1; ++yy) {
-                const float gy = axis_gap(y, g.miny, g.h, yy, g.gy - 1, g.clamped);
-                const float rg = gy * gy + gz * gz;
-                if (R > 1 && rg > best) continue;
-                const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
-                const bool edge = (zz == cz - R) || (zz == cz + R) || (yy == cy - R) || (yy == cy + R);
-                if (R == 1) {
-                    span(row, x0, x1);
-                } else if (edge) {
-                    // tighten the x window to the cells the ball can reach
-                    int xa = x0, xb = x1;
-                    while (xa <= xb && rg + axis_gap(x, g.minx, g.h, xa, g.gx - 1, g.clamped) * axis_gap(x, g.minx, g.h, xa, g.gx - 1, g.clamped) > best) ++xa;
-                    while (xb >= xa && rg + axis_gap(x, g.minx, g.h, xb, g.gx - 1, g.clamped) * axis_gap(x, g.minx, g.h, xb, g.gx - 1, g.clamped) > best) --xb;
-                    if (xa <= xb) { touched = true; span(row, xa, xb); }
-                } else {   // interior rows of a shell: only the two end cells are new
-                    if (cx - R >= 0) {
-                        const float gx = axis_gap(x, g.minx, g.h, cx - R, g.gx - 1, g.clamped);
-                        if (rg + gx * gx <= best) { touched = true; span(row, cx - R, cx - R); }
-                    }
-                    if (cx + R <= g.gx - 1) {
-                        const float gx = axis_gap(x, g.minx, g.h, cx + R, g.gx - 1, g.clamped);
-                        if (rg + gx * gx <= best) { touched = true; span(row, cx + R, cx + R); }
-                    }
-                }
-            }
-        }
-        const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
-                            (cz - R <= 0) && (cz + R >= g.gz - 1);
-        const float bound = ((float)R + mf - 2e-3f) * g.h;
-        if (covers || !touched || best <= bound * bound + out2) break;
-        if (max_dist >= 0.0f && bound > max_dist) break;   // everything unscanned would be rejected
-    }
-}
-
-// sum over the 64 lanes of a wave, returned in every lane (wave-uniform): four DPP steps inside the
-// rows of 16 lanes, two row broadcasts, total read from lane 63.  One VALU instruction per step
-// (no LDS crossbar traffic); the summation tree is fixed, so results are run-to-run identical.
-__device__ __forceinline__ float wave_sum_f32(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); // row_bcast15 -> rows 1, 3
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)); // row_bcast31 -> rows 2, 3
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-// the same tree for seven values at once: one fused v_add_f32_dpp per value and step (the compiler
-// cannot fold the DPP move into the add without no-signed-zeros).  Seven independent instructions
-// between the write and the DPP read of a register cover the DPP read-after-write hazard; the s_nop
-// covers the first one against whatever the compiler scheduled before the block.
-#define TC_DPP7(ctrl)                                                                                              \
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl  \
-                 "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\tv_add_f32_dpp %4, %4, %4 " ctrl "\n\tv_add_f32_dpp %5, %5, %5 " ctrl \
-                 "\n\tv_add_f32_dpp %6, %6, %6 " ctrl                                                              \
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]))
-__device__ __forceinline__ void wave_sum_f32x7(float (&v)[7]) {
-    TC_DPP7("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    TC_DPP7("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    TC_DPP7("row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    TC_DPP7("row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    TC_DPP7("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    TC_DPP7("row_bcast:31 row_mask:0xc bank_mask:0xf");
-#pragma unroll
-    for (int i = 0; i < 7; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
-}
-#undef TC_DPP7
-
 // Sum NACC (<= 32) per-lane values over the 64 lanes of a wave into row[0 .. NACC) (f64, += by one lane per slot).
 // A transposing reduction: at every step a lane keeps one half of its values and sends the other half to its partner, so
 // the work halves with the lane distance (32 -> 16 -> 8 -> 4 -> 2 values per lane; 3 instructions per kept value) instead
