@@ -101,8 +101,17 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
 __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g,
                                                        const IcpState *__restrict__ st, TileGeom tg, int tile_major,
                                                        uint32_t *__restrict__ cell_of, uint32_t *__restrict__ hist,
-                                                       uint32_t *__restrict__ arrival) {
+                                                       uint32_t *__restrict__ arrival, uint32_t *__restrict__ pts_pad,
+                                                       uint32_t *__restrict__ cs_front, uint32_t *__restrict__ cs_tail) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the paddings the ICP search over-reads (three tiny memsets = three launches otherwise): huge coordinates behind the
+    // sorted records, zeros around the prefix sums
+    if (blockIdx.x == 0 && threadIdx.x < 4 * kPtsPad + kCellStartFront + kCellStartPad) {
+        const uint32_t t = threadIdx.x;
+        if (t < 4 * kPtsPad) pts_pad[t] = 0x7F7F7F7Fu;
+        else if (t < 4 * kPtsPad + kCellStartFront) cs_front[t - 4 * kPtsPad] = 0u;
+        else cs_tail[t - 4 * kPtsPad - kCellStartFront] = 0u;
+    }
     if (i >= n) return;
     float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
     if (st) {
@@ -439,13 +448,11 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
 
         TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)nkeys * sizeof(uint32_t), st));
         // records past the end: huge finite coordinates -> d2 = +inf, never a match (kernels may read, never select them)
-        TC_HIP_TRY(ctx, hipMemsetAsync((float4 *)ix.pts.p + n, 0x7F, kPtsPad * sizeof(float4), st));
-        TC_HIP_TRY(ctx, hipMemsetAsync(cs + nkeys + 1, 0, kCellStartPad * sizeof(uint32_t), st));
-        TC_HIP_TRY(ctx, hipMemsetAsync(ix.cell_start.p, 0, kCellStartFront * sizeof(uint32_t), st));
         {
             ProfScope ps(ctx, "cell_hist");
             hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0,
-                               (uint32_t *)ix.cell_of.p, (uint32_t *)ix.fill.p, (uint32_t *)ix.arrival.p);
+                               (uint32_t *)ix.cell_of.p, (uint32_t *)ix.fill.p, (uint32_t *)ix.arrival.p,
+                               reinterpret_cast<uint32_t *>((float4 *)ix.pts.p + n), (uint32_t *)ix.cell_start.p, cs + nkeys + 1);
         }
         {
             ProfScope ps(ctx, "cell_scan");
