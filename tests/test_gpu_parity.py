@@ -632,17 +632,19 @@ def test_organised_scan_order_does_not_fool_the_sampled_box(ctx):
     for pts in (beam_major, az_major):
         d = torch.from_numpy(pts).cuda()
         ctx.estimate_normals(d, 10)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
+        best = float("inf")
+        for _ in range(6):                      # best of six: a scheduling hiccup must not fail a timing comparison
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             o = ctx.estimate_normals(d, 10)
-        torch.cuda.synchronize()
-        t.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        t.append(best)
         outs.append(o.cpu().numpy())
     back = outs[1].reshape(1875, 64, 6).transpose(1, 0, 2).reshape(-1, 6)
     assert np.array_equal(back[:, :3], outs[0][:, :3])
     assert (cos_abs(back[:, 3:], outs[0][:, 3:]) >= 1 - 1e-6).mean() > 0.999       # same neighbour sets, same normals
-    assert t[1] < 3.0 * t[0] + 1e-3
+    assert t[1] < 3.0 * t[0] + 2e-4
 
 
 def test_unbounded_radius_search_matches_brute_force(ctx):
