@@ -579,12 +579,16 @@ def test_far_outliers_clamped_grid_stays_exact(ctx, n):
     where = rng.integers(0, n, len(out))
     pts[where] = out
     qs = np.concatenate([pts[where], pts[rng.integers(0, n, 40)], np.array([[300, 300, 300], [121, 1.5, 0.5], [2, 1, -40]], np.float32)]).astype(np.float32)
+    gpu_s = 0.0                                   # only the HIP calls are timed (the oracle's share depends on the host)
     t0 = time.perf_counter()
     gi, gd, gc = ctx.find_k_nearest_batch(pts, qs, 8)
+    gpu_s += time.perf_counter() - t0
     _, od, oc = O.knn_batch(pts, qs, 8)
     assert np.array_equal(gc, oc) and np.array_equal(gd, od)
     if n <= 60000:
+        t0 = time.perf_counter()
         g = ctx.estimate_normals(pts, 10)
+        gpu_s += time.perf_counter() - t0
         r = O.estimate_normals(pts, 10)
         assert np.array_equal(g[:, :3], pts)
         keep = np.ones(n, bool)
@@ -594,12 +598,14 @@ def test_far_outliers_clamped_grid_stays_exact(ctx, n):
         assert int((cos_abs(g[keep, 3:6], r[keep, 3:6]) < 1 - COS_TOL).sum()) <= max(1, n // 20000)
     src = synth.apply_isometry(synth.yaw_isometry((0.03, -0.02, 0.01), 0.01), pts[rng.permutation(n)[: n // 2]])
     src[:3] = np.array([[500, 0, 0], [119, 1.4, 0.5], [0, 0, -200]], np.float32)
+    t0 = time.perf_counter()
     gg = ctx.icp_detailed(src, pts, None, 1, None, 0.0)
+    gpu_s += time.perf_counter() - t0
     rr = O.icp_detailed(src, pts, None, 1, None, 0.0)
     assert np.array_equal(gg.correspondences, rr.correspondences)
     # same pairs; the reference's sequential f32 Kabsch sums over pairs with coordinates of several hundred carry ~1e-5
     assert frob(gg.transformation, rr.transformation, O.isometry_to_matrix) <= 1e-4
-    assert time.perf_counter() - t0 < 30.0
+    assert gpu_s < 20.0                            # milliseconds with the clamped box, tens of seconds to minutes without
 
 
 def test_sharded_normals_slices_reassemble(ctx):
