@@ -109,6 +109,219 @@ __device__ __forceinline__ void smallest_eigvec_sym3(double a00, double a01, dou
     nx = vx * s; ny = vy * s; nz = vz * s;
 }
 
+// ---- nalgebra's Matrix3::symmetric_eigen in f32, operation by operation (normals.rs:181) -----------------------
+// Scale by the max-abs entry, Householder tridiagonalisation, implicit symmetric QR with Wilkinson shifts, direct 2x2
+// solve for the last block; eigenvalues unsorted, eigenvectors = columns of q.  The eigenvector of a near-degenerate
+// neighbourhood (two smallest eigenvalues close) is whatever THIS arithmetic produces -- a more accurate solver gives a
+// different, equally valid vector, i.e. no parity on those points -- so the k-NN path runs the reference's algorithm in
+// the reference's precision (the statement of oracle/tc_oracle.c::sym_eigen3, same order of operations; the library is
+// built without FMA contraction).  Only the lower triangle of the input is read.
+__device__ __forceinline__ void e3_to_exp(float x, float &mod, float &sign) {
+    const float n = fabsf(x);
+    if (n != 0.0f) { mod = n; sign = x / n; } else { mod = 0.0f; sign = 1.0f; }
+}
+__device__ __forceinline__ bool e3_givens_cancel_y(float x, float y, float &c, float &s, float &r) {
+    if (y != 0.0f) {
+        float mod0, sign0;
+        e3_to_exp(x, mod0, sign0);
+        const float denom = sqrtf(mod0 * mod0 + y * y);
+        c = mod0 / denom;
+        s = -y / (sign0 * denom);
+        r = sign0 * denom;
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ float e3_wilkinson_shift(float tmm, float tnn, float tmn) {
+    const float sq = tmn * tmn;
+    if (sq != 0.0f) {
+        const float d = (tmm - tnn) * 0.5f;
+        float sg = (d >= 0.0f || d != d) ? 1.0f : -1.0f;
+        if (d == 0.0f && signbit(d)) sg = -1.0f;
+        return tnn - sq / (d + sg * sqrtf(d * d + sq));
+    }
+    return tnn;
+}
+// SymmetricEigen::delimit_subproblem for n = 3 (indices spelled out: no dynamic register indexing)
+__device__ __forceinline__ void e3_delimit(float d0, float d1, float d2, float &o0, float &o1, int end, float eps, int &start_out, int &end_out) {
+    int n = end;
+    if (n == 2 && !(fabsf(o1) > eps * (fabsf(d2) + fabsf(d1)))) n = 1;
+    if (n == 1 && !(fabsf(o0) > eps * (fabsf(d1) + fabsf(d0)))) n = 0;
+    if (n == 0) { start_out = 0; end_out = 0; return; }
+    int ns = n - 1;
+    if (ns == 1) {
+        if (o0 == 0.0f || fabsf(o0) <= eps * (fabsf(d1) + fabsf(d0))) o0 = 0.0f;
+        else ns = 0;
+    }
+    start_out = ns; end_out = n;
+}
+template <int I, int J>
+__device__ __forceinline__ void e3_rot_cols(float (&q)[3][3], float c, float s) {      // q <- q * [[c, s], [-s, c]] on columns (I, J)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float qa = q[r][I], qb = q[r][J];
+        q[r][I] = qa * c - s * qb;
+        q[r][J] = s * qa + qb * c;
+    }
+}
+template <int I, int J>
+__device__ __forceinline__ void e3_rot_cols_t(float (&q)[3][3], float c, float s) {    // the final 2x2 block's rotation
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float qa = q[r][I], qb = q[r][J];
+        q[r][I] = qa * c + s * qb;
+        q[r][J] = -s * qa + qb * c;
+    }
+}
+// one implicit-QR Givens step on (d_i, d_j, o_i)
+__device__ __forceinline__ void e3_qr_update(float &di, float &dj, float &oi, float c, float s) {
+    const float mii = di, mjj = dj, mij = oi;
+    const float cc = c * c, ss = s * s, cs = c * s;
+    const float b = cs * 2.0f * mij;
+    di = (cc * mii + ss * mjj) - b;
+    dj = (ss * mii + cc * mjj) + b;
+    oi = cs * (mii - mjj) + mij * (cc - ss);
+}
+__device__ __forceinline__ void e3_last_block(float &ds, float &ds1, float os, float eps, float &c, float &s, bool &rotate) {
+    const float h00 = ds, h10 = os, h11 = ds1;
+    const float val = (h00 - h11) * 0.5f;
+    const float discr = h10 * h10 + val * val;
+    const float sq = sqrtf(discr);
+    const float half_tra = (h00 + h11) * 0.5f;
+    const float e0 = half_tra + sq, e1 = half_tra - sq;
+    const float bx = e0 - ds1, by = os;
+    ds = e0; ds1 = e1;
+    float mod0, sign0;
+    e3_to_exp(bx, mod0, sign0);
+    const float denom = sqrtf(mod0 * mod0 + by * by);
+    rotate = denom > eps;
+    if (rotate) { c = mod0 / denom; s = by / (sign0 * denom); }
+}
+
+__device__ __forceinline__ void sym_eigen3_f32(float axx, float axy, float axz, float ayy, float ayz, float azz, float (&evals)[3],
+                                               float (&q)[3][3]) {
+    // a[i][j] (lower triangle): a00 = xx, a10 = xy, a20 = xz, a11 = yy, a21 = yz, a22 = zz; the max runs over all nine entries
+    float amax = fmaxf(fmaxf(fmaxf(fabsf(axx), fabsf(axy)), fmaxf(fabsf(axz), fabsf(ayy))), fmaxf(fabsf(ayz), fabsf(azz)));
+    float a00 = axx, a10 = axy, a20 = axz, a11 = ayy, a21 = ayz, a22 = azz;
+    if (amax != 0.0f) { a00 = a00 / amax; a10 = a10 / amax; a20 = a20 / amax; a11 = a11 / amax; a21 = a21 / amax; a22 = a22 / amax; }
+    float offs0, offs1, u0 = 0.0f, u1 = 0.0f;
+    bool refl0 = false, refl1 = false;
+    {   // step 0: reflect (a10, a20) onto e1
+        const float x0 = a10, x1 = a20;
+        const float sq = x0 * x0 + x1 * x1;
+        const float nrm = sqrtf(sq);
+        float mod, sign;
+        e3_to_exp(x0, mod, sign);
+        const float signed_norm = sign * nrm;
+        const float factor = (sq + mod * nrm) * 2.0f;
+        if (factor != 0.0f) {
+            const float f = sqrtf(factor);
+            u0 = (x0 + signed_norm) / f; u1 = x1 / f;
+            const float un = sqrtf(u0 * u0 + u1 * u1);
+            u0 /= un; u1 /= un;
+            offs0 = -signed_norm; refl0 = true;
+            float b00 = a11, b10 = a21, b11 = a22;
+            const float p0 = 2.0f * (b00 * u0 + b10 * u1);
+            const float p1 = 2.0f * (b10 * u0 + b11 * u1);
+            const float dot = u0 * p0 + u1 * p1;
+            b00 = b00 - p0 * u0; b10 = b10 - p1 * u0; b11 = b11 - p1 * u1;
+            b00 = b00 - u0 * p0; b10 = b10 - u1 * p0; b11 = b11 - u1 * p1;
+            const float d2 = dot * 2.0f;
+            b00 = b00 + d2 * u0 * u0; b10 = b10 + d2 * u1 * u0; b11 = b11 + d2 * u1 * u1;
+            a11 = b00; a21 = b10; a22 = b11;
+        } else {
+            offs0 = signed_norm;
+        }
+    }
+    float ax1 = 0.0f;
+    {   // step 1: the 1-vector (a21)
+        const float x0 = a21;
+        const float sq = x0 * x0, nrm = sqrtf(sq);
+        float mod, sign;
+        e3_to_exp(x0, mod, sign);
+        const float signed_norm = sign * nrm;
+        const float factor = (sq + mod * nrm) * 2.0f;
+        if (factor != 0.0f) {
+            const float f = sqrtf(factor);
+            ax1 = (x0 + signed_norm) / f;
+            ax1 = ax1 / fabsf(ax1);
+            offs1 = -signed_norm; refl1 = true;
+            float b = a22;
+            const float pp = 2.0f * (b * ax1);
+            const float dot = ax1 * pp;
+            b = b - pp * ax1; b = b - ax1 * pp; b = b + (dot * 2.0f) * ax1 * ax1;
+            a22 = b;
+        } else {
+            offs1 = signed_norm;
+        }
+    }
+    float d0 = a00, d1 = a11, d2 = a22;
+    float o0 = fabsf(offs0), o1 = fabsf(offs1);
+    // householder::assemble_q with signs = the off-diagonal before the modulus
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) q[i][j] = (i == j) ? 1.0f : 0.0f;
+    {
+        const float sg = (offs1 < 0.0f || (offs1 == 0.0f && signbit(offs1))) ? -1.0f : 1.0f;
+        const float axis = refl1 ? ax1 : 0.0f;
+#pragma unroll
+        for (int c = 1; c < 3; ++c) {
+            const float col = q[2][c];
+            const float factor = (axis * col) * -2.0f;
+            q[2][c] = sg * col + axis * (factor * sg);
+        }
+    }
+    {
+        const float sg = (offs0 < 0.0f || (offs0 == 0.0f && signbit(offs0))) ? -1.0f : 1.0f;
+        const float b0 = refl0 ? u0 : 0.0f, b1 = refl0 ? u1 : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float c0 = q[1][c], c1 = q[2][c];
+            const float factor = (b0 * c0 + b1 * c1) * -2.0f;
+            q[1][c] = sg * c0 + b0 * (factor * sg);
+            q[2][c] = sg * c1 + b1 * (factor * sg);
+        }
+    }
+    // implicit QR iterations (SymmetricEigen::do_decompose)
+    const float eps = 1.1920929e-07f;
+    int start, end;
+    e3_delimit(d0, d1, d2, o0, o1, 2, eps, start, end);
+    for (int guard = 0; end != start && guard < 10000; ++guard) {
+        if (end - start == 2) {                 // the full 3 x 3 problem: start = 0, end = 2
+            float vx = d0 - e3_wilkinson_shift(d1, d2, o1);
+            float vy = o0;
+            float c, s, nrm;
+            if (e3_givens_cancel_y(vx, vy, c, s, nrm)) {
+                e3_qr_update(d0, d1, o0, c, s);
+                vx = o0;
+                vy = -s * o1;
+                o1 *= c;
+                e3_rot_cols<0, 1>(q, c, s);
+                if (e3_givens_cancel_y(vx, vy, c, s, nrm)) {
+                    o0 = nrm;
+                    e3_qr_update(d1, d2, o1, c, s);
+                    e3_rot_cols<1, 2>(q, c, s);
+                }
+            }
+            if (fabsf(o1) <= eps * (fabsf(d1) + fabsf(d2))) end -= 1;
+        } else {                                // a 2 x 2 block: (start, start + 1)
+            float c = 1.0f, s = 0.0f;
+            bool rotate;
+            if (start == 0) {
+                e3_last_block(d0, d1, o0, eps, c, s, rotate);
+                if (rotate) e3_rot_cols_t<0, 1>(q, c, s);
+            } else {
+                e3_last_block(d1, d2, o1, eps, c, s, rotate);
+                if (rotate) e3_rot_cols_t<1, 2>(q, c, s);
+            }
+            end -= 1;
+        }
+        e3_delimit(d0, d1, d2, o0, o1, end, eps, start, end);
+    }
+    evals[0] = d0 * amax; evals[1] = d1 * amax; evals[2] = d2 * amax;
+}
+
 // ---- sorted register list -------------------------------------------------------------------
 template <int L>
 __device__ __forceinline__ void list_insert(float (&d)[L], float v) {
@@ -346,9 +559,12 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
             cxx += dx * dx; cxy += dx * dy; cxz += dx * dz; cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
         }
         cxx /= nf; cxy /= nf; cxz /= nf; cyy /= nf; cyz /= nf; czz /= nf;
-        double ex, ey, ez;
-        smallest_eigvec_sym3((double)cxx, (double)cxy, (double)cxz, (double)cyy, (double)cyz, (double)czz, ex, ey, ez);
-        float vx = (float)ex, vy = (float)ey, vz = (float)ez;
+        float ev[3], qm[3][3];
+        sym_eigen3_f32(cxx, cxy, cxz, cyy, cyz, czz, ev, qm);          // normals.rs:181
+        // first index with the strictly smallest eigenvalue (normals.rs:186-191), its column of q
+        float vx = qm[0][0], vy = qm[1][0], vz = qm[2][0], emin = ev[0];
+        if (ev[1] < emin) { emin = ev[1]; vx = qm[0][1]; vy = qm[1][1]; vz = qm[2][1]; }
+        if (ev[2] < emin) { vx = qm[0][2]; vy = qm[1][2]; vz = qm[2][2]; }
         const float mag = sqrtf(vx * vx + vy * vy + vz * vz);          // normals.rs:197-202
         if (mag > 1e-6f) { nrm_x = vx / mag; nrm_y = vy / mag; nrm_z = vz / mag; }
     }
