@@ -593,9 +593,7 @@ def test_far_outliers_clamped_grid_stays_exact(ctx, n):
         assert np.array_equal(g[:, :3], pts)
         keep = np.ones(n, bool)
         keep[where] = False                       # (the outliers' own neighbourhoods are degenerate lines / pairs)
-        # near-degenerate neighbourhoods (two smallest eigenvalues close) rotate the f32 eigen solve of the reference by
-        # more than the tolerance at a rate of ~1e-5 per point, outliers or not: allow those
-        assert int((cos_abs(g[keep, 3:6], r[keep, 3:6]) < 1 - COS_TOL).sum()) <= max(1, n // 20000)
+        assert int((cos_abs(g[keep, 3:6], r[keep, 3:6]) < 1 - COS_TOL).sum()) == 0
     src = synth.apply_isometry(synth.yaw_isometry((0.03, -0.02, 0.01), 0.01), pts[rng.permutation(n)[: n // 2]])
     src[:3] = np.array([[500, 0, 0], [119, 1.4, 0.5], [0, 0, -200]], np.float32)
     t0 = time.perf_counter()
@@ -677,3 +675,17 @@ def test_unbounded_radius_search_matches_brute_force(ctx):
     ri, rd = tree.radius_search(pts[3], 0.2)
     assert len(ri) > 65 and ri[0] == 3 and rd[0] == 0.0 and rd == sorted(rd)
     ix.close()
+
+
+@pytest.mark.parametrize("n,k,orient", [(60000, 10, True), (120000, 16, True), (40000, 20, False)])
+def test_normals_bit_identical_to_oracle(ctx, n, k, orient):
+    """The k-NN path runs the reference's f32 symmetric_eigen algorithm on the bit-identical covariance, so the normals are
+    not merely within tolerance: all but a few per 10^5 (exact distance ties in the neighbour order) have the oracle's bits,
+    including the near-degenerate neighbourhoods where any other eigen solver lands elsewhere; signs too, orientation or not."""
+    pts = synth.uniform_cloud(n, 33, (4.0, 3.0, 1.0))
+    g = ctx.estimate_normals_with_config(pts, tc.NormalEstimationConfig(k_neighbors=k, consistent_orientation=orient))
+    r = O.estimate_normals(pts, k, None, orient)
+    same = np.all(g == r, axis=1)
+    assert same.mean() >= 0.9999
+    a, b = g[~same, 3:6].astype(np.float64), r[~same, 3:6].astype(np.float64)
+    assert len(a) == 0 or float((1.0 - (a * b).sum(1)).max()) <= 1e-6      # signed cosine: same orientation
