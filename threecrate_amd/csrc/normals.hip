@@ -155,23 +155,17 @@ __device__ __forceinline__ void e3_delimit(float d0, float d1, float d2, float &
     }
     start_out = ns; end_out = n;
 }
-template <int I, int J>
-__device__ __forceinline__ void e3_rot_cols(float (&q)[3][3], float c, float s) {      // q <- q * [[c, s], [-s, c]] on columns (I, J)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const float qa = q[r][I], qb = q[r][J];
-        q[r][I] = qa * c - s * qb;
-        q[r][J] = s * qa + qb * c;
-    }
+// q <- q * [[c, s], [-s, c]] on two columns (scalars, not an array: the final "column of the smallest eigenvalue" select
+// over an array turns into a dynamically indexed scratch load)
+__device__ __forceinline__ void e3_rot_cols(float &a0, float &a1, float &a2, float &b0, float &b1, float &b2, float c, float s) {
+    float qa = a0, qb = b0; a0 = qa * c - s * qb; b0 = s * qa + qb * c;
+    qa = a1; qb = b1; a1 = qa * c - s * qb; b1 = s * qa + qb * c;
+    qa = a2; qb = b2; a2 = qa * c - s * qb; b2 = s * qa + qb * c;
 }
-template <int I, int J>
-__device__ __forceinline__ void e3_rot_cols_t(float (&q)[3][3], float c, float s) {    // the final 2x2 block's rotation
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const float qa = q[r][I], qb = q[r][J];
-        q[r][I] = qa * c + s * qb;
-        q[r][J] = -s * qa + qb * c;
-    }
+__device__ __forceinline__ void e3_rot_cols_t(float &a0, float &a1, float &a2, float &b0, float &b1, float &b2, float c, float s) {   // the final 2x2 block's rotation
+    float qa = a0, qb = b0; a0 = qa * c + s * qb; b0 = -s * qa + qb * c;
+    qa = a1; qb = b1; a1 = qa * c + s * qb; b1 = -s * qa + qb * c;
+    qa = a2; qb = b2; a2 = qa * c + s * qb; b2 = -s * qa + qb * c;
 }
 // one implicit-QR Givens step on (d_i, d_j, o_i)
 __device__ __forceinline__ void e3_qr_update(float &di, float &dj, float &oi, float c, float s) {
@@ -198,8 +192,10 @@ __device__ __forceinline__ void e3_last_block(float &ds, float &ds1, float os, f
     if (rotate) { c = mod0 / denom; s = by / (sign0 * denom); }
 }
 
-__device__ __forceinline__ void sym_eigen3_f32(float axx, float axy, float axz, float ayy, float ayz, float azz, float (&evals)[3],
-                                               float (&q)[3][3]) {
+// out: the three eigenvalues (unsorted) and q column by column: (x0, y0, z0) belongs to e0, ...
+__device__ __forceinline__ void sym_eigen3_f32(float axx, float axy, float axz, float ayy, float ayz, float azz, float &e0, float &e1,
+                                               float &e2, float &q00, float &q10, float &q20, float &q01, float &q11, float &q21,
+                                               float &q02, float &q12, float &q22) {
     // a[i][j] (lower triangle): a00 = xx, a10 = xy, a20 = xz, a11 = yy, a21 = yz, a22 = zz; the max runs over all nine entries
     float amax = fmaxf(fmaxf(fmaxf(fabsf(axx), fabsf(axy)), fmaxf(fabsf(axz), fabsf(ayy))), fmaxf(fabsf(ayz), fabsf(azz)));
     float a00 = axx, a10 = axy, a20 = axz, a11 = ayy, a21 = ayz, a22 = azz;
@@ -258,30 +254,28 @@ __device__ __forceinline__ void sym_eigen3_f32(float axx, float axy, float axz, 
     float d0 = a00, d1 = a11, d2 = a22;
     float o0 = fabsf(offs0), o1 = fabsf(offs1);
     // householder::assemble_q with signs = the off-diagonal before the modulus
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) q[i][j] = (i == j) ? 1.0f : 0.0f;
+    // (q_rc: row r, column c)
+    q00 = 1.0f; q01 = 0.0f; q02 = 0.0f; q10 = 0.0f; q11 = 1.0f; q12 = 0.0f; q20 = 0.0f; q21 = 0.0f; q22 = 1.0f;
     {
         const float sg = (offs1 < 0.0f || (offs1 == 0.0f && signbit(offs1))) ? -1.0f : 1.0f;
         const float axis = refl1 ? ax1 : 0.0f;
-#pragma unroll
-        for (int c = 1; c < 3; ++c) {
-            const float col = q[2][c];
+        auto reflect1 = [&](float &x) {                 // row 2, columns 1 and 2
+            const float col = x;
             const float factor = (axis * col) * -2.0f;
-            q[2][c] = sg * col + axis * (factor * sg);
-        }
+            x = sg * col + axis * (factor * sg);
+        };
+        reflect1(q21); reflect1(q22);
     }
     {
         const float sg = (offs0 < 0.0f || (offs0 == 0.0f && signbit(offs0))) ? -1.0f : 1.0f;
         const float b0 = refl0 ? u0 : 0.0f, b1 = refl0 ? u1 : 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float c0 = q[1][c], c1 = q[2][c];
+        auto reflect0 = [&](float &r1, float &r2) {     // rows 1 and 2 of one column
+            const float c0 = r1, c1 = r2;
             const float factor = (b0 * c0 + b1 * c1) * -2.0f;
-            q[1][c] = sg * c0 + b0 * (factor * sg);
-            q[2][c] = sg * c1 + b1 * (factor * sg);
-        }
+            r1 = sg * c0 + b0 * (factor * sg);
+            r2 = sg * c1 + b1 * (factor * sg);
+        };
+        reflect0(q10, q20); reflect0(q11, q21); reflect0(q12, q22);
     }
     // implicit QR iterations (SymmetricEigen::do_decompose)
     const float eps = 1.1920929e-07f;
@@ -297,29 +291,35 @@ __device__ __forceinline__ void sym_eigen3_f32(float axx, float axy, float axz, 
                 vx = o0;
                 vy = -s * o1;
                 o1 *= c;
-                e3_rot_cols<0, 1>(q, c, s);
+                e3_rot_cols(q00, q10, q20, q01, q11, q21, c, s);
                 if (e3_givens_cancel_y(vx, vy, c, s, nrm)) {
                     o0 = nrm;
                     e3_qr_update(d1, d2, o1, c, s);
-                    e3_rot_cols<1, 2>(q, c, s);
+                    e3_rot_cols(q01, q11, q21, q02, q12, q22, c, s);
                 }
             }
             if (fabsf(o1) <= eps * (fabsf(d1) + fabsf(d2))) end -= 1;
-        } else {                                // a 2 x 2 block: (start, start + 1)
+        } else {                                // a 2 x 2 block: (start, start + 1) -- on selected VALUES (two branches
+            const bool lo = start == 0;         // calling one helper by reference become a dynamically indexed scratch array)
+            float ds = lo ? d0 : d1, ds1 = lo ? d1 : d2;
+            const float os = lo ? o0 : o1;
             float c = 1.0f, s = 0.0f;
             bool rotate;
-            if (start == 0) {
-                e3_last_block(d0, d1, o0, eps, c, s, rotate);
-                if (rotate) e3_rot_cols_t<0, 1>(q, c, s);
-            } else {
-                e3_last_block(d1, d2, o1, eps, c, s, rotate);
-                if (rotate) e3_rot_cols_t<1, 2>(q, c, s);
+            e3_last_block(ds, ds1, os, eps, c, s, rotate);
+            d0 = lo ? ds : d0; d1 = lo ? ds1 : ds; d2 = lo ? d2 : ds1;
+            if (rotate) {
+                float a0 = lo ? q00 : q01, a1 = lo ? q10 : q11, a2 = lo ? q20 : q21;
+                float b0 = lo ? q01 : q02, b1 = lo ? q11 : q12, b2 = lo ? q21 : q22;
+                e3_rot_cols_t(a0, a1, a2, b0, b1, b2, c, s);
+                q00 = lo ? a0 : q00; q10 = lo ? a1 : q10; q20 = lo ? a2 : q20;
+                q01 = lo ? b0 : a0;  q11 = lo ? b1 : a1;  q21 = lo ? b2 : a2;
+                q02 = lo ? q02 : b0; q12 = lo ? q12 : b1; q22 = lo ? q22 : b2;
             }
             end -= 1;
         }
         e3_delimit(d0, d1, d2, o0, o1, end, eps, start, end);
     }
-    evals[0] = d0 * amax; evals[1] = d1 * amax; evals[2] = d2 * amax;
+    e0 = d0 * amax; e1 = d1 * amax; e2 = d2 * amax;
 }
 
 // ---- sorted register list -------------------------------------------------------------------
@@ -559,12 +559,12 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
             cxx += dx * dx; cxy += dx * dy; cxz += dx * dz; cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
         }
         cxx /= nf; cxy /= nf; cxz /= nf; cyy /= nf; cyz /= nf; czz /= nf;
-        float ev[3], qm[3][3];
-        sym_eigen3_f32(cxx, cxy, cxz, cyy, cyz, czz, ev, qm);          // normals.rs:181
+        float e0, e1, e2, x0, y0, z0, x1, y1, z1, x2, y2, z2;
+        sym_eigen3_f32(cxx, cxy, cxz, cyy, cyz, czz, e0, e1, e2, x0, y0, z0, x1, y1, z1, x2, y2, z2);          // normals.rs:181
         // first index with the strictly smallest eigenvalue (normals.rs:186-191), its column of q
-        float vx = qm[0][0], vy = qm[1][0], vz = qm[2][0], emin = ev[0];
-        if (ev[1] < emin) { emin = ev[1]; vx = qm[0][1]; vy = qm[1][1]; vz = qm[2][1]; }
-        if (ev[2] < emin) { vx = qm[0][2]; vy = qm[1][2]; vz = qm[2][2]; }
+        float vx = x0, vy = y0, vz = z0, emin = e0;
+        if (e1 < emin) { emin = e1; vx = x1; vy = y1; vz = z1; }
+        if (e2 < emin) { vx = x2; vy = y2; vz = z2; }
         const float mag = sqrtf(vx * vx + vy * vy + vz * vz);          // normals.rs:197-202
         if (mag > 1e-6f) { nrm_x = vx / mag; nrm_y = vy / mag; nrm_z = vz / mag; }
     }
