@@ -19,9 +19,9 @@
 //   phase 2  rescan the cells within sqrt(tau), append the record positions with d2 <= tau to a per-lane LDS list
 //            (ties at tau: lowest cell-sorted position first), rank them against the register
 //            list -> neighbours in ascending-distance order, exactly the reference's order.
-//   epilogue f32 centroid / covariance in the reference's operation order (bit-identical to
-//            the oracle for identical neighbour sets), smallest eigenvector in f64
-//            (trigonometric estimate + monotone Newton polish + largest cross product).
+//   epilogue f32 centroid / covariance in the reference's operation order, eigenvectors by nalgebra's f32
+//            symmetric_eigen algorithm (sym_eigen3_f32), column of the smallest eigenvalue; the radius-set path keeps an
+//            f64 closed form (trigonometric estimate + monotone Newton polish + largest cross product).
 //
 // Algorithmic HBM bytes per point: 12 (query) + 12*k (neighbours) + 24 (out).
 #include "tc_internal.h"
@@ -114,7 +114,8 @@ __device__ __forceinline__ void smallest_eigvec_sym3(double a00, double a01, dou
 // solve for the last block; eigenvalues unsorted, eigenvectors = columns of q.  The eigenvector of a near-degenerate
 // neighbourhood (two smallest eigenvalues close) is whatever THIS arithmetic produces -- a more accurate solver gives a
 // different, equally valid vector, i.e. no parity on those points -- so the k-NN path runs the reference's algorithm in
-// the reference's precision (the statement of oracle/tc_oracle.c::sym_eigen3, same order of operations; the library is
+// the reference's precision (nalgebra 0.34 linalg: SymmetricTridiagonal::new, householder::assemble_q, SymmetricEigen::
+// do_decompose / delimit_subproblem, GivensRotation::cancel_y / try_new, wilkinson_shift -- same order of operations; the library is
 // built without FMA contraction).  Only the lower triangle of the input is read.
 __device__ __forceinline__ void e3_to_exp(float x, float &mod, float &sign) {
     const float n = fabsf(x);
