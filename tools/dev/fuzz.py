@@ -85,6 +85,13 @@ def run(budget, seed, ctx, sizes=SMALL, log=print):
                 gn = ctx.estimate_normals(tgt, min(16, n - 1))
                 nn = np.linalg.norm(gn[:, 3:], axis=1)
                 if not (np.isfinite(gn).all() and np.abs(nn - 1).max() < 1e-4): bad += 1; log("NORMALS INVALID", tag)
+                # same eigen algorithm as the reference: where the neighbour SETS are untied the normals agree to the last bits,
+                # ill-conditioned neighbourhoods included (kinds with exact duplicates / lattices have tied neighbours)
+                if kind <= 4 and n <= 9000:
+                    rn = O.estimate_normals(tgt, min(16, n - 1))
+                    c = np.abs((gn[:, 3:].astype(np.float64) * rn[:, 3:].astype(np.float64)).sum(1))
+                    off = int((c < 1 - 1e-4).sum())
+                    if off > max(1, n // 2000): bad += 1; log("NORMALS PARITY", tag, off, "of", n)
         except Exception as e:
             bad += 1; log("EXCEPTION", tag, type(e).__name__, e)
     log(f"fuzz: {cases} cases, {bad} problems")
