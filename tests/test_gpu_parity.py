@@ -28,7 +28,7 @@ def _normals_report(gpu, ref):
     return c, bad
 
 
-@pytest.mark.parametrize("n,k", [(10000, 10), (20000, 16), (5000, 3), (3000, 32), (2000, 64), (50000, 20)])
+@pytest.mark.parametrize("n,k", [(10000, 10), (20000, 16), (5000, 3), (3000, 32), (2000, 64), (3000, 100), (2000, 128), (50000, 20)])
 def test_normals_match_oracle_uniform(ctx, n, k):
     pts = synth.uniform_cloud(n, seed=1)
     gpu = ctx.estimate_normals(pts, k)
@@ -560,7 +560,10 @@ def test_search_index_handle_matches_one_shot_calls(ctx):
     empty = tc.SearchIndex(ctx, np.zeros((0, 3), np.float32))
     assert len(empty) == 0 and empty.find_k_nearest_batch(q, 4)[2].sum() == 0
     with pytest.raises(tc.Unsupported):
-        ix.find_k_nearest_batch(q, 66)
+        ix.find_k_nearest_batch(q, 130)
+    i100, d100, c100 = ix.find_k_nearest_batch(q, 100)            # the 129-entry instantiation
+    _, od100, oc100 = O.knn_batch(pts, q, 100)
+    assert np.array_equal(c100, oc100) and np.array_equal(d100, od100)
     for h in (ix, dev, empty):
         h.close()
 
@@ -670,7 +673,7 @@ def test_unbounded_radius_search_matches_brute_force(ctx):
             assert np.array_equal(np.sort(got), want)
             seg = dist[off[j]:off[j + 1]]
             assert np.all(np.diff(seg) >= 0) and np.array_equal(seg, np.sqrt(d2[got]))
-    assert (off[1:] - off[:-1]).max() > 500                     # far beyond the 65-entry selection lists
+    assert (off[1:] - off[:-1]).max() > 500                     # far beyond the selection lists of the k-NN kernels
     tree = threecrate.KdTree(threecrate.PointCloud(pts))
     ri, rd = tree.radius_search(pts[3], 0.2)
     assert len(ri) > 65 and ri[0] == 3 and rd[0] == 0.0 and rd == sorted(rd)

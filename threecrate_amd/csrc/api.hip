@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(256) gicp_cov_kernel(const float *__restrict__
 static tc_status gicp_covariances_device(tc_context *ctx, const float *d_xyz, size_t n, size_t k, DevBuf &idx, DevBuf &dist, DevBuf &cnt,
                                          float *d_cov8) {
     k = std::max<size_t>(k, 4);
-    if (k > 65) return fail(ctx, TC_UNSUPPORTED, "GICP: k_correspondences > 65 is not supported by this backend");
+    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "GICP: k_correspondences > 129 is not supported by this backend");
     if (tc_status s = ensure(ctx, idx, n * k * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, dist, n * k * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, cnt, n * sizeof(uint32_t))) return s;
@@ -605,7 +605,7 @@ tc_status tc_radius_search(tc_context *ctx, const float *cloud, size_t n, const 
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!(radius > 0.0f) || n == 0 || k_max == 0) { std::memset(count, 0, nq * sizeof(uint32_t)); return TC_OK; }
-    if (k_max > 65) return fail(ctx, TC_UNSUPPORTED, "k_max > 65 is not supported by the HIP radius search");
+    if (k_max > 129) return fail(ctx, TC_UNSUPPORTED, "k_max > 129 is not supported by the HIP radius search");
     DevBuf dc, dq, di, dd, dn;
     auto cleanup = [&]() { for (DevBuf *b : {&dc, &dq, &di, &dd, &dn}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } };
     tc_status st = TC_OK;
@@ -665,7 +665,7 @@ tc_status tc_search_index_create_device(tc_context *ctx, const float *d_cloud, s
     if (n >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
     tc_search_index *s = new tc_search_index{ctx, {}, n, {}, {}};
     if (n) {        // an empty cloud is an empty tree (nearest_neighbor.rs:38-45)
-        const size_t k = std::min<size_t>(std::max<size_t>(k_hint, 1), 65);
+        const size_t k = std::min<size_t>(std::max<size_t>(k_hint, 1), 129);
         tc_status rc = build_index(ctx, s->ix, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1) * 2.0f, nullptr, nullptr);
         if (rc == TC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, TC_GPU, "search index build failed");
         if (rc != TC_OK) { free_index(s->ix); delete s; return rc; }
@@ -701,7 +701,7 @@ tc_status tc_search_index_query_device(tc_search_index *s, const float *d_querie
         TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return TC_OK;
     }
-    if (k > 65) return fail(ctx, TC_UNSUPPORTED, "k > 65 is not supported by the HIP neighbour search");
+    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP neighbour search");
     if (nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
     if (tc_status rc = launch_knn(ctx, s->ix, d_queries, nq, k, d_idx, d_dist, d_count, by_radius ? radius * radius : INFINITY)) return rc;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -518,8 +518,8 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     });
 
     // rank -> ascending-distance order (ties keep scan order)
-    unsigned long long taken_lo = 0ull, taken_hi = 0ull;   // bitset over ranks 0..127
-    auto is_taken = [&](uint32_t r) { return r < 64 ? ((taken_lo >> r) & 1ull) : ((taken_hi >> (r - 64)) & 1ull); };
+    unsigned long long taken_lo = 0ull, taken_hi = 0ull, taken_x = 0ull;   // bitset over ranks 0..191 (L <= 129)
+    auto is_taken = [&](uint32_t r) { return r < 64 ? ((taken_lo >> r) & 1ull) : r < 128 ? ((taken_hi >> (r - 64)) & 1ull) : ((taken_x >> (r - 128)) & 1ull); };
     int self_r = -1;
     for (uint32_t e = 0; e < cnt; ++e) {
         const uint32_t j = ldsA[e * BLOCK];
@@ -529,7 +529,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
 #pragma unroll
         for (int t = 0; t < L; ++t) r += (d[t] < v) ? 1u : 0u;
         while (is_taken(r)) ++r;
-        if (r < 64) taken_lo |= 1ull << r; else taken_hi |= 1ull << (r - 64);
+        if (r < 64) taken_lo |= 1ull << r; else if (r < 128) taken_hi |= 1ull << (r - 64); else taken_x |= 1ull << (r - 128);
         ldsB[r * BLOCK] = (uint8_t)e;           // rank -> entry index (one byte; the positions stay in ldsA)
         if (j == p) self_r = (int)r;
     }
@@ -680,8 +680,8 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
         if (!take && v == tau && ties < quota) { take = true; ++ties; }
         if (take && cnt < K1) { ldsA[cnt * BLOCK] = j; ++cnt; }
     });
-    unsigned long long taken_lo = 0ull, taken_hi = 0ull;
-    auto is_taken = [&](uint32_t r) { return r < 64 ? ((taken_lo >> r) & 1ull) : ((taken_hi >> (r - 64)) & 1ull); };
+    unsigned long long taken_lo = 0ull, taken_hi = 0ull, taken_x = 0ull;
+    auto is_taken = [&](uint32_t r) { return r < 64 ? ((taken_lo >> r) & 1ull) : r < 128 ? ((taken_hi >> (r - 64)) & 1ull) : ((taken_x >> (r - 128)) & 1ull); };
     for (uint32_t e = 0; e < cnt; ++e) {
         const uint32_t j = ldsA[e * BLOCK];
         const float4 c = gv.pts[j];
@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
 #pragma unroll
         for (int i = 0; i < L; ++i) r += (d[i] < v) ? 1u : 0u;
         while (is_taken(r)) ++r;
-        if (r < 64) taken_lo |= 1ull << r; else taken_hi |= 1ull << (r - 64);
+        if (r < 64) taken_lo |= 1ull << r; else if (r < 128) taken_hi |= 1ull << (r - 64); else taken_x |= 1ull << (r - 128);
         ldsB[r * BLOCK] = (uint8_t)e;
     }
     uint32_t within = 0;          // radius search: the entries with d2 <= radius^2 (nearest_neighbor.rs:271), a prefix
@@ -752,7 +752,7 @@ tc_status launch_radius_all(tc_context *ctx, const DeviceIndex &ix, const float 
 
 tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, size_t k,
                      uint32_t *d_idx, float *d_dist, uint32_t *d_count, float radius_sq) {
-    if (k > 65) return fail(ctx, TC_UNSUPPORTED, "k > 65 is not supported by the HIP k-NN export");
+    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP k-NN export");
     const GridView gv = view_of(ix);
     ProfScope ps(ctx, "knn_batch");
     hipStream_t st = ctx->stream;
@@ -766,7 +766,8 @@ tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_quer
     if (k <= 9) TC_KNN(9, 256);
     else if (k <= 17) TC_KNN(17, 256);
     else if (k <= 33) TC_KNN(33, 128);
-    else TC_KNN(65, 64);
+    else if (k <= 65) TC_KNN(65, 64);
+    else TC_KNN(129, 64);
 #undef TC_KNN
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
@@ -793,7 +794,7 @@ tc_status launch_normals_unsort(tc_context *ctx, const DeviceIndex &ix, const fl
 
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg, const float vp[3],
                          float *d_out6, size_t p_begin, size_t p_end, bool slice_out) {
-    if (cfg.k_neighbors + 1 > 65) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 64 is not supported by the HIP backend");
+    if (cfg.k_neighbors + 1 > 129) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 128 is not supported by the HIP backend");
     NormalParams prm;
     prm.k = (uint32_t)cfg.k_neighbors;
     prm.orient = cfg.consistent_orientation ? 1 : 0;
@@ -810,7 +811,8 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal
         if (K1 <= 11)      launch_variant<11, 256, true>(ctx->stream, gv, prm, d_out6, ctx);
         else if (K1 <= 17) launch_variant<17, 256, true>(ctx->stream, gv, prm, d_out6, ctx);
         else if (K1 <= 33) launch_variant<33, 128, true>(ctx->stream, gv, prm, d_out6, ctx);
-        else               launch_variant<65, 64, true>(ctx->stream, gv, prm, d_out6, ctx);
+        else if (K1 <= 65) launch_variant<65, 64, true>(ctx->stream, gv, prm, d_out6, ctx);
+        else               launch_variant<129, 64, true>(ctx->stream, gv, prm, d_out6, ctx);
         TC_HIP_TRY(ctx, hipGetLastError());
         return TC_OK;
     }
@@ -819,7 +821,8 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal
     else if (K1 <= 17) launch_variant<17, 256>(ctx->stream, gv, prm, d_out6, ctx);
     else if (K1 <= 21) launch_variant<21, 256>(ctx->stream, gv, prm, d_out6, ctx);
     else if (K1 <= 33) launch_variant<33, 128>(ctx->stream, gv, prm, d_out6, ctx);
-    else               launch_variant<65, 64>(ctx->stream, gv, prm, d_out6, ctx);
+    else if (K1 <= 65) launch_variant<65, 64>(ctx->stream, gv, prm, d_out6, ctx);
+    else               launch_variant<129, 64>(ctx->stream, gv, prm, d_out6, ctx);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
 }
