@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X normals + ICP backend (BASELINE.json config [1]).
+"""bench.py -- headline benchmark of the MI355X normals + ICP backend (BASELINE.json configs[1]).
 
 One "step" = one pass of the hot path over one synthetic 1M-point scan pair:
     estimate_normals(target, k=16)  +  50-iteration point-to-plane ICP (convergence_threshold 0.0,
-    so exactly 50 iterations run: SURVEY.md 7/H4) of source -> target,
-with all inputs already resident in HBM when the timed region starts.  With --gpus N every rank
-runs its own independent pair (BASELINE config [2], weak scaling, no data-path collective);
-the only collective is the max-over-ranks of the wall time.
+    so exactly 50 iterations run: SURVEY.md 7/H4) of source -> target, correspondences returned,
+with all inputs already resident in HBM when the timed region starts.  Source and target carry
+INDEPENDENT sensor noise (sigma = 1e-4 of the extent), so the converged phase of the registration has
+non-zero nearest-neighbour distances like a real scan pair.
+
+`--gpus N`: one rank per GPU, each with its own independent pair (BASELINE configs[2], weak scaling, no
+data-path collective; the only collective is the max-over-ranks of the wall time).  Launched by the driver
+under torch.distributed.run, or -- when WORLD_SIZE is not set -- this script starts the N ranks itself
+(fresh child processes, before anything in the parent touches a GPU).
 
 Prints ONE JSON line (rank 0).  `value` = whole-job ICP iterations / second =
 50 * steps * n_gpus / wall, where wall covers normals + ICP of every step.
@@ -14,10 +19,10 @@ Prints ONE JSON line (rank 0).  `value` = whole-job ICP iterations / second =
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,47 +30,130 @@ sys.path.insert(0, ROOT)
 N_POINTS = 1_000_000
 K_NORMALS = 16
 ICP_ITERS = 50
+NOISE_REL = 1e-4            # sensor noise sigma / cloud extent, independently on source and target
 ALG_BYTES_ICP = 40          # B / source point / iteration: 12 src + 12 tgt + 12 normal + 4 index
 ALG_BYTES_NORMALS = 12 + 12 * K_NORMALS + 24   # = 228 B / point
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like
+    torch.distributed.run).  The parent never imports torch and never touches a GPU; rank 0 prints the JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def timed(fn, warmups, reps):
+    for _ in range(warmups):
+        fn()
+    ts = []
+    out = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    return median(ts), out
+
+
 def cpu_baseline(n_points, tgt, src, gpu_normals=None):
-    """The oracle (CPU restatement of threecrate-algorithms, kind="port") timed on this box's host
-    cores on a bounded sample of the same workload: full k=16 normals on the 1M cloud + the kd-tree
-    build + 3 of the 50 p2plane iterations, extrapolated to the 50-iteration job."""
+    """The oracle (CPU restatement of threecrate-algorithms, kind="port") timed on this box's host cores with the
+    reference harness protocol (warm-ups, repeated whole calls, median: docs/benchmarks.md:29) on a BOUNDED sample of
+    the same workload: the full k=16 normals call on the 1M cloud (1 warm-up + 3 timed), the kd-tree build on its own
+    (single-threaded BY DESIGN: nearest_neighbor.rs:37-58 is a sequential recursion -- it is inside every normals /
+    ICP call of the reference), and p2plane ICP calls of 1 and 4 iterations (3 timed each; the difference / 3 = one
+    steady iteration, extrapolated to 50).  A 1-thread figure comes from a 100k-point subset."""
+    import numpy as np
     from oracle import oracle as O
-    cores = O.num_threads()
-    t0 = time.perf_counter()
-    nrm = O.estimate_normals(tgt, K_NORMALS)
-    t_norm = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.icp_point_to_plane_detailed(src, tgt, nrm[:, 3:], None, 1, None, 0.0)
-    t1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.icp_point_to_plane_detailed(src, tgt, nrm[:, 3:], None, 4, None, 0.0)
-    t4 = time.perf_counter() - t0
+    threads = O.num_threads()
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = None
+    t_norm, nrm = timed(lambda: O.estimate_normals(tgt, K_NORMALS), 1, 3)
+    t_tree, _ = timed(lambda: O.KdTree(tgt), 0, 3)
+    t1, _ = timed(lambda: O.icp_point_to_plane_detailed(src, tgt, nrm[:, 3:], None, 1, None, 0.0), 1, 3)
+    t4, _ = timed(lambda: O.icp_point_to_plane_detailed(src, tgt, nrm[:, 3:], None, 4, None, 0.0), 0, 3)
     t_iter = max((t4 - t1) / 3.0, 1e-9)
     t_build = max(t1 - t_iter, 0.0)
     job = t_norm + t_build + ICP_ITERS * t_iter
+    # one thread, 100k-point subset of the same pair (same generator, same transform)
+    m = min(100_000, n_points)
+    ts, ss = np.ascontiguousarray(tgt[:m]), np.ascontiguousarray(src[:m])
+    t_norm1, nrm1 = timed(lambda: O.estimate_normals(ts, K_NORMALS, threads=1), 0, 1)
+    t_tree1, _ = timed(lambda: O.KdTree(ts), 0, 1)
+    a1, _ = timed(lambda: O.icp_point_to_plane_detailed(ss, ts, nrm1[:, 3:], None, 1, None, 0.0, threads=1), 0, 1)
+    a3, _ = timed(lambda: O.icp_point_to_plane_detailed(ss, ts, nrm1[:, 3:], None, 3, None, 0.0, threads=1), 0, 1)
+    it1 = max((a3 - a1) / 2.0, 1e-9)
     parity = None
     if gpu_normals is not None:      # the oracle's normals of the same cloud are at hand: use them as the checker they are
         a, b = gpu_normals[:, 3:6].astype(np.float64), nrm[:, 3:6].astype(np.float64)
         c = np.abs((a * b).sum(1)) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-300)
         parity = {"normals_max_1_minus_abs_cos": float(1.0 - c.min()), "normals_frac_within_1e-4": float((c >= 1.0 - 1e-4).mean()),
+                  "normals_bit_identical_frac": float((gpu_normals[:, 3:6] == nrm[:, 3:6]).all(1).mean()),
                   "positions_identical": bool(np.array_equal(gpu_normals[:, :3], nrm[:, :3]))}
     return {
-        "parity": parity,
-        "value": ICP_ITERS / job, "unit": "ICP it/s (whole job: normals + 50 it)", "cores": cores, "kind": "port",
-        "sample": f"oracle on {n_points} pts: full k={K_NORMALS} normals ({t_norm:.2f} s) + kd-tree build ({t_build:.2f} s) + "
-                  f"3 timed p2plane iterations ({t_iter:.3f} s/it) extrapolated to {ICP_ITERS}",
+        "parity": parity, "oracle_normals": nrm,
+        "value": ICP_ITERS / job, "unit": "ICP it/s (whole job: normals + 50 it)", "cores": threads, "kind": "port",
+        "sched_affinity_cpus": affinity, "omp_threads": threads,
+        "sample": f"oracle on the same {n_points}-pt pair, all threads: k={K_NORMALS} normals call median of 3 after 1 warm-up "
+                  f"({t_norm:.2f} s, of which the single-threaded kd-tree build is {t_tree:.2f} s) + ICP: p2plane calls of 1 and 4 "
+                  f"iterations, median of 3 each -> {t_iter:.3f} s per steady iteration, {t_build:.2f} s per-call setup (kd-tree "
+                  f"build + first gather), extrapolated to {ICP_ITERS} iterations",
         "normals_mpts_per_s": n_points / t_norm / 1e6,
+        "normals_mpts_per_s_excluding_kdtree_build": n_points / max(t_norm - t_tree, 1e-9) / 1e6,
+        "kdtree_build_s": t_tree,
         "icp_it_per_s_steady": 1.0 / t_iter,
+        "one_thread": {"sample": f"{m}-pt subset, threads=1, one call each", "normals_mpts_per_s": m / t_norm1 / 1e6,
+                       "kdtree_build_s": t_tree1, "icp_it_per_s_steady": 1.0 / it1,
+                       "icp_source_mpts_per_s": m / it1 / 1e6},
+        "all_threads_icp_source_mpts_per_s": n_points / t_iter / 1e6,
     }
+
+
+def dry_run(args):
+    """CPU stand-in for the launch path (tests/test_bench_launch.py): every rank joins a gloo group, the barrier /
+    max-over-ranks plumbing runs, rank 0 prints a JSON line with the world size it saw.  No GPU, no product code."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    wall = time.perf_counter() - t0
+    tw = torch.tensor([wall], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launch path only)", "value": 0.0, "unit": "it/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "max_wall_s": float(tw[0]), "pid": os.getpid(), "ppid": os.getppid()}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def aux_modes(args):
     """Secondary workloads (not the judged line): sharded 10M-point ICP and frame streaming."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     import threecrate_amd as tc
@@ -77,27 +165,25 @@ def aux_modes(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    # on torch's current stream: the sharded loop (kernels, copies, RCCL all-reduce) is then stream ordered
-    ctx = tc.GpuContext(local_rank, stream=torch.cuda.current_stream(dev).cuda_stream) if args.mode == "sharded" else tc.GpuContext(local_rank)
+    ctx = tc.GpuContext(local_rank)
     if args.mode == "sharded":
+        # BASELINE configs[3]: ONE 10M-point cloud; the source is sharded SPATIALLY inside the library (every rank passes the
+        # full source, tc_sharded_icp_point_to_plane_device takes its compact range), target + normals + grid replicated,
+        # one ncclAllReduce of 32 doubles per iteration on the compute stream
         n = args.points if args.points != N_POINTS else 10_000_000
-        tgt_h = synth.uniform_cloud(n, seed=7, scale=(10.0, 10.0, 1.0))
-        T = synth.small_transform(n)
-        Minv = synth.invert_isometry(T)
-        src_h = (tgt_h.astype(np.float64) @ Minv[:3, :3].T + Minv[:3, 3]).astype(np.float32)
-        tgt = torch.from_numpy(tgt_h).to(dev)
-        lo, hi = D.shard_range(n, rank, world)
-        src = torch.from_numpy(src_h[lo:hi]).to(dev)
-        # the normals of the replicated target are sharded too: every rank computes its slice, one all-gather
-        nrm = D.sharded_estimate_normals(ctx, tgt, K_NORMALS)
+        src_h, tgt_h, T = synth.registration_pair(n, seed=7, scale=(10.0, 10.0, 1.0), noise_sigma=NOISE_REL * 10.0)
+        tgt, src = torch.from_numpy(tgt_h).to(dev), torch.from_numpy(src_h).to(dev)
+        comm = D.Comm.from_group(ctx)       # RCCL communicator owned by the library (id broadcast over the process group)
+        nrm = D.sharded_estimate_normals(ctx, tgt, K_NORMALS, comm=comm)
         torch.cuda.synchronize()
         tn0 = time.perf_counter()
         for _ in range(3):
-            nrm = D.sharded_estimate_normals(ctx, tgt, K_NORMALS)
+            nrm = D.sharded_estimate_normals(ctx, tgt, K_NORMALS, comm=comm)
         torch.cuda.synchronize()
         t_normals = (time.perf_counter() - tn0) / 3.0
+
         def step():
-            return D.sharded_icp_point_to_plane(ctx, src, tgt, nrm, None, ICP_ITERS, None, 0.0, source_is_local_slice=True)
+            return D.sharded_icp_point_to_plane(ctx, src, tgt, nrm, None, ICP_ITERS, None, 0.0, comm=comm, correspondences=True)
         for _ in range(max(args.warmup, 1)):
             step()
         torch.cuda.synchronize()
@@ -110,16 +196,22 @@ def aux_modes(args):
         if world > 1:
             dist.barrier()
         wall = time.perf_counter() - t0
+        if world > 1:
+            tw = torch.tensor([wall, t_normals], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            wall, t_normals = [float(v) for v in tw.tolist()]
         if rank == 0:
             err = float(np.linalg.norm(tc.isometry_to_matrix(r.transformation).astype(np.float64) - synth.isometry_matrix(T)))
-            print(json.dumps({"metric": "sharded point-to-plane ICP iterations/sec (one cloud, source sharded, 1 all-reduce/iteration)",
+            print(json.dumps({"metric": "sharded point-to-plane ICP iterations/sec (one cloud, source sharded spatially, 1 ncclAllReduce/iteration in the library)",
                               "value": ICP_ITERS * args.steps / wall, "unit": "it/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
                               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": f"{n}-pt uniform cloud [0,10)x[0,10)x[0,1), 50-iter p2plane ICP, source sharded over ranks",
+                              "config": {"workload": f"{n}-pt uniform cloud [0,10)x[0,10)x[0,1) (BASELINE configs[3]), 50-iter p2plane ICP, "
+                                                     "source sharded spatially over the ranks, correspondences gathered",
                                          "points": n, "parallelism": f"shard{world}"},
-                              "transform_frobenius_error": err,
+                              "transform_frobenius_error_vs_truth": err, "n_correspondences": int((r.corr_target != 0xFFFFFFFF).sum()),
                               "sharded_normals_ms": 1e3 * t_normals, "sharded_normals_mpts_per_s": n / t_normals / 1e6}))
+        comm.close()
     else:
         frames = [synth.kitti_shaped_cloud(seed=i) for i in range(4)]
         # ego motion between consecutive frames: 1 m forward + 0.5 deg yaw
@@ -159,6 +251,7 @@ def aux_modes(args):
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -169,17 +262,24 @@ def main():
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the device-to-device copy bandwidth probe (profile runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the phase / host-path measurements after the timed region (profile runs)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the launch path: gloo group, no GPU work")
     ap.add_argument("--cloud", choices=["uniform", "tum"], default="uniform",
                     help="pairs mode: uniform-random cloud (BASELINE configs[1], the judged line) or a TUM-RGB-D-shaped "
                          "depth-map surface of ~1 M points (configs[2]; auxiliary)")
     ap.add_argument("--mode", choices=["pairs", "sharded", "stream"], default="pairs",
                     help="pairs (default, the judged metric): one independent 1M pair per GPU; sharded: ONE cloud, source "
-                         "sharded over the ranks, one all-reduce of the packed 6x6 system per iteration (BASELINE config [3]); "
-                         "stream: 120k-pt LiDAR-shaped frames, voxel + normals + ICP per frame (BASELINE config [4])")
+                         "sharded over the ranks, one all-reduce of the packed 6x6 system per iteration (BASELINE configs[3]); "
+                         "stream: 120k-pt LiDAR-shaped frames, voxel + normals + ICP per frame (BASELINE configs[4])")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)          # nothing above touched a GPU (torch is not even imported yet)
+    if args.dry_run:
+        return dry_run(args)
     if args.mode != "pairs":
         return aux_modes(args)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     import threecrate_amd as tc
@@ -198,14 +298,15 @@ def main():
     n = args.points
     # every rank owns an independent scan pair (seed differs per rank)
     if args.cloud == "tum":
-        # ~1 M-point depth-map surface, scan-to-scan motion of a hand-held camera (1 cm, 0.3 deg)
-        tgt_h = synth.tum_shaped_cloud(seed=1 + rank)
-        rng = np.random.default_rng(100 + rank)
-        tgt_h = (tgt_h + rng.normal(0, 1e-4, tgt_h.shape)).astype(np.float32)
-        src_h = synth.apply_isometry(synth.yaw_isometry((-0.01, 0.004, 0.002), -np.deg2rad(0.3)), tgt_h)
-        n = len(tgt_h)
+        # ~1 M-point depth-map surface, scan-to-scan motion of a hand-held camera (1 cm, 0.3 deg), 1 mm noise on both scans
+        base = synth.tum_shaped_cloud(seed=1 + rank)
+        n = len(base)
+        T_true = synth.yaw_isometry((0.01, -0.004, -0.002), np.deg2rad(0.3))
+        src_h = (synth.apply_isometry(synth.yaw_isometry((-0.01, 0.004, 0.002), -np.deg2rad(0.3)), base) + synth.gaussian_noise(n, 100 + rank, 1e-3)).astype(np.float32)
+        tgt_h = (base + synth.gaussian_noise(n, 200 + rank, 1e-3)).astype(np.float32)
     else:
-        src_h, tgt_h, _ = synth.registration_pair(n, seed=1 + rank, transform=synth.harness_transform())
+        T_true = synth.harness_transform()
+        src_h, tgt_h, _ = synth.registration_pair(n, seed=1 + rank, transform=T_true, noise_sigma=NOISE_REL)
     src, tgt = torch.from_numpy(src_h).to(dev), torch.from_numpy(tgt_h).to(dev)
     ctx = tc.GpuContext(local_rank)
     # sampled hipEvents around the dominant kernel only (every 4th launch): ~1 % overhead in the timed region
@@ -215,10 +316,11 @@ def main():
         t0 = time.perf_counter()
         nrm = ctx.estimate_normals(tgt, K_NORMALS)                       # (n, 6) NormalPoint3f, stays in HBM
         t1 = time.perf_counter()
-        r = ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, ICP_ITERS, None, 0.0, correspondences=False)
+        # correspondences=True: the dense per-source target index (ICPResult.correspondences) is written to a device buffer
+        r = ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, ICP_ITERS, None, 0.0, correspondences="device")
         t2 = time.perf_counter()
         assert r.iterations == ICP_ITERS
-        return t1 - t0, t2 - t1, r
+        return t1 - t0, t2 - t1, r, nrm
 
     for _ in range(args.warmup):
         step()
@@ -230,7 +332,7 @@ def main():
     tn = ti = 0.0
     last = None
     for _ in range(args.steps):
-        a, b, last = step()
+        a, b, last, nrm_last = step()
         tn += a
         ti += b
     torch.cuda.synchronize()
@@ -285,10 +387,11 @@ def main():
             "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{n}-pt uniform-random cloud, k={K_NORMALS} normals + {ICP_ITERS}-iter point-to-plane ICP "
+            "config": {"workload": (f"{n}-pt uniform-random cloud, k={K_NORMALS} normals + {ICP_ITERS}-iter point-to-plane ICP, independent "
+                                    f"sigma = {NOISE_REL:g} noise on source and target, correspondences returned "
                                     "(BASELINE configs[1]; one independent pair per GPU)") if args.cloud == "uniform" else
-                                   (f"{n}-pt TUM-RGB-D-shaped depth-map surface, k={K_NORMALS} normals + {ICP_ITERS}-iter point-to-plane ICP "
-                                    "(BASELINE configs[2] shape; one independent pair per GPU; auxiliary line)"),
+                                   (f"{n}-pt TUM-RGB-D-shaped depth-map surface, 1 mm noise on both scans, k={K_NORMALS} normals + {ICP_ITERS}-iter "
+                                    "point-to-plane ICP (BASELINE configs[2] shape; one independent pair per GPU; auxiliary line)"),
                        "points": n, "k": K_NORMALS, "icp_iterations": ICP_ITERS, "parallelism": f"pairs{world}"},
             "normals_mpts_per_s": n * args.steps * world / tn / 1e6,
             "icp_only_it_per_s": ICP_ITERS * args.steps * world / ti,
@@ -298,22 +401,57 @@ def main():
                          "measured_copy_gbs": copy_gbs},
             "kernels_us_avg": {kk: round(1e3 * ms / max(c, 1), 2) for kk, (c, ms) in stats.items()},
             "final_mse": last.mse,
+            "n_correspondences": int((last.corr_target != -1).sum()),
         }
         if args.cloud != "uniform":
             out["roofline"]["traffic"] = None          # PMC passes were collected on the uniform config
             out["roofline"].pop("traffic_detail", None)
+        if not args.no_extras:
+            # ---- outside the timed region: the two phases of the registration, and the drop-in (host buffer) view ----
+            # moving: the first 8 iterations from the identity (clouds still misaligned: NN distance ~ half a cell);
+            # converged: 8 iterations started from the final transform (NN distance = the sensor noise).  hipEvents around
+            # every kernel (profile mode 1).
+            ctx.profile_enable(1)
+            phases = {}
+            for name, init in (("moving", None), ("converged", last.transformation)):
+                ctx.profile_reset()
+                ctx.icp_point_to_plane_detailed(src, tgt, nrm_last, init, 8, None, 0.0, correspondences="device")
+                st = ctx.profile_read()
+                phases[name] = {kk: round(1e3 * ms / max(c, 1), 2) for kk, (c, ms) in st.items() if kk.startswith("icp_")}
+            ctx.profile_reset()
+            ctx.estimate_normals(tgt, K_NORMALS)
+            st = ctx.profile_read()
+            out["normals_kernels_us"] = {kk: round(1e3 * ms / max(c, 1), 2) for kk, (c, ms) in st.items()}
+            nk = st.get("normals_knn_pca")
+            if nk:
+                out["normals_roofline"] = {"kernel": "normals_knn_pca", "alg_bytes_per_launch": ALG_BYTES_NORMALS * n,
+                                           "avg_launch_us": 1e3 * nk[1] / max(nk[0], 1),
+                                           "frac": ALG_BYTES_NORMALS * n / (1e-3 * nk[1] / max(nk[0], 1)) / 1e9 / HBM_PEAK_GBS}
+            ctx.profile_enable(0)
+            out["main_pass_us_moving"] = phases["moving"].get(k)
+            out["main_pass_us_converged"] = phases["converged"].get(k)
+            out["phase_kernels_us"] = phases
+            # host path: pageable numpy in, numpy out (what a drop-in caller holding Vec<Point3f> sees; PCIe inclusive)
+            th_n, nrm_host = timed(lambda: ctx.estimate_normals(tgt_h, K_NORMALS), 1, 3)
+            th_i, _ = timed(lambda: ctx.icp_point_to_plane_detailed(src_h, tgt_h, nrm_host, None, ICP_ITERS, None, 0.0, correspondences=True), 1, 3)
+            out["host_path"] = {"normals_ms": 1e3 * th_n, "icp_50it_ms": 1e3 * th_i, "it_per_s_whole_job": ICP_ITERS / (th_n + th_i),
+                                "note": "pageable numpy buffers in and out through tc_estimate_normals / tc_icp_point_to_plane_detailed, "
+                                        "correspondence pairs materialised; median of 3; never part of `value`"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, tgt_h, src_h, ctx.estimate_normals(tgt, K_NORMALS).cpu().numpy())
-            out["parity"] = out["cpu_baseline"].pop("parity")
-            if args.cloud == "uniform":   # source = T^-1 target: the registration must return the harness transform
-                out["parity"]["icp_T_frobenius_vs_truth"] = float(np.linalg.norm(
-                    tc.isometry_to_matrix(last.transformation).astype(np.float64) - synth.isometry_matrix(synth.harness_transform())))
+            cb = cpu_baseline(n, tgt_h, src_h, nrm_last.cpu().numpy())
+            out["parity"] = cb.pop("parity")
+            onrm = cb.pop("oracle_normals")
+            out["cpu_baseline"] = cb
+            out["parity"]["icp_T_frobenius_vs_truth"] = float(np.linalg.norm(
+                tc.isometry_to_matrix(last.transformation).astype(np.float64) - synth.isometry_matrix(T_true)))
+            del onrm
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

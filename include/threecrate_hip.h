@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TC_ABI_VERSION 1
+#define TC_ABI_VERSION 2
 
 /* threecrate_core::Error variants used on the path (threecrate-core/src/error.rs:7-28) */
 typedef enum tc_status {
@@ -99,6 +99,13 @@ int         tc_device_count(void);
 tc_status   tc_context_create(int device, tc_context **out);
 /* same, but run on a caller-owned hipStream_t (e.g. torch's current stream) */
 tc_status   tc_context_create_on_stream(int device, void *hip_stream, tc_context **out);
+/* Stream ordering rule for the *_device entry points: the library reads the caller's device buffers on the CONTEXT's
+ * stream.  Work that produces those buffers on another stream (a torch op on torch's current stream, a hipMemcpyAsync on
+ * the caller's own stream) must be ordered before the call: either create the context on that stream
+ * (tc_context_create_on_stream), synchronise the producer stream, or call tc_context_wait_stream(ctx, producer_stream):
+ * it records an event on `other_stream` and makes the context's stream wait for it (no host wait).  Every entry point
+ * returns with its outputs complete (the context's stream has been synchronised), so nothing is needed on the way out. */
+tc_status   tc_context_wait_stream(tc_context *ctx, void *other_hip_stream);
 void        tc_context_destroy(tc_context *ctx);
 const char *tc_last_error_message(const tc_context *ctx);
 tc_status   tc_synchronize(tc_context *ctx);
@@ -206,6 +213,72 @@ tc_status   tc_icp_shard_done(tc_icp_shard *s, int *done);
 tc_status   tc_icp_shard_apply(tc_icp_shard *s);               /* solve + compose + convergence (device) */
 tc_status   tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *result);
 void        tc_icp_shard_destroy(tc_icp_shard *s);
+
+/* ---- communicator: one rank per GPU of one node (north_star: "a single RCCL all-reduce of the 6x6 system
+ * per ICP iteration over xGMI") ----
+ * The reference has no multi-device code (threecrate-gpu/src/icp.rs:151-185 runs its batch jobs one after the other on
+ * one device), so there is no reference signature to mirror: this is the boundary a Rust host (one process or thread per
+ * GPU) binds to run ONE registration over several GPUs.  A tc_comm wraps an RCCL communicator bound to the context's
+ * device; its collectives are enqueued on the context's stream (no host synchronisation inside the ICP loop).
+ *   rank 0:  tc_comm_unique_id(id)  -> the host distributes the 128 bytes by any means (pipe, file, MPI, torch.distributed)
+ *   all:     tc_comm_create(ctx, nranks, rank, id, &comm)          = ncclCommInitRank
+ *   or:      tc_comm_adopt(ctx, existing ncclComm_t, nranks, rank, &comm)   (the host already owns a communicator)
+ *   or:      tc_comm_create_host(...): the collectives go through a HOST callback on pinned buffers (hosts whose ranks are
+ *            connected by something else than RCCL -- MPI, gloo, shared memory; several ranks on one GPU in tests).
+ *            One blocking device<->host round trip per collective: correct, not fast.
+ *   or:      tc_comm_create_local(ctx, &comm): nranks = 1, every collective is a no-op.
+ * librccl is resolved at run time (symbols already in the process first, then librccl.so.1): the library loads and every
+ * single-GPU entry point works on a machine without RCCL; tc_comm_unique_id / tc_comm_create then return TC_UNSUPPORTED. */
+typedef struct tc_comm tc_comm;
+#define TC_COMM_ID_BYTES 128
+typedef enum tc_coll_op {
+    TC_COLL_SUM_F64 = 0,        /* buf: count doubles, summed over the ranks in place */
+    TC_COLL_SUM_U32 = 1,        /* buf: count uint32, summed in place */
+    TC_COLL_ALLGATHER_U8 = 2    /* buf: nranks x count bytes; rank r's part sits at r * count; in place */
+} tc_coll_op;
+/* returns 0 on success; called from the thread that called the sharded entry point */
+typedef int (*tc_host_collective_fn)(void *user, int op, void *host_buf, size_t count);
+tc_status tc_comm_unique_id(uint8_t id[TC_COMM_ID_BYTES]);
+tc_status tc_comm_create(tc_context *ctx, int nranks, int rank, const uint8_t id[TC_COMM_ID_BYTES], tc_comm **out);
+tc_status tc_comm_adopt(tc_context *ctx, void *nccl_comm, int nranks, int rank, tc_comm **out);
+tc_status tc_comm_create_host(tc_context *ctx, int nranks, int rank, tc_host_collective_fn fn, void *user, tc_comm **out);
+tc_status tc_comm_create_local(tc_context *ctx, tc_comm **out);
+int       tc_comm_rank(const tc_comm *comm);
+int       tc_comm_size(const tc_comm *comm);
+void      tc_comm_destroy(tc_comm *comm);
+
+/* ---- ONE registration over all ranks of a communicator (BASELINE configs[3]: a 10 M-point cloud over 8 GPUs) ----
+ * icp_point_to_plane_detailed (registration.rs:508-602) / icp_detailed (:258-370) with the SOURCE points sharded over
+ * the ranks and the target (+ normals + grid) replicated.  Per iteration every rank reduces its shard to the packed
+ * normal equations (TC_ICP_SUMS_P2PLANE / _P2P f64 words), ONE all-reduce(sum) of TC_ICP_SUMS_STRIDE doubles on the
+ * compute stream makes them global, and every rank applies the identical buffer (same solve, same convergence test: no
+ * broadcast).  The host polls the `done` flag two chunks of iterations behind, like the single-GPU loop: no host wait
+ * sits between an iteration's kernels and its collective.  Every rank returns the same transformation / mse /
+ * iterations / converged / n_correspondences.
+ *   TC_SHARD_SPATIAL: every rank passes the SAME full source cloud; rank r takes the contiguous range
+ *       [r ns / W, (r + 1) ns / W) of the source ordered by the target cell of its initially transformed position (tile
+ *       major): a spatially compact shard.  corr_target (device, n_source entries, optional) is complete on every rank
+ *       (one all-reduce of n_source words after the loop).
+ *   TC_SHARD_LOCAL: every rank passes ITS OWN part of the source (any partition; may be empty on some ranks);
+ *       corr_target then has n_source (local) entries.
+ * Point-to-point: the post-loop mse of a run that did not converge (registration.rs:343-361) is reduced over the ranks
+ * too.  All ranks must call with the same arguments apart from the source in TC_SHARD_LOCAL mode; validation failures are
+ * the single-GPU entry points' and identical on every rank. */
+typedef enum tc_shard_mode { TC_SHARD_SPATIAL = 0, TC_SHARD_LOCAL = 1 } tc_shard_mode;
+tc_status tc_sharded_icp_point_to_plane_device(tc_context *ctx, tc_comm *comm, int shard_mode,
+                          const float *d_source, size_t n_source, const float *d_target, size_t n_target,
+                          const float *d_target_normals, size_t n_target_normals, size_t normal_stride,
+                          const float init[7], size_t max_iters, float max_correspondence_distance,
+                          float convergence_threshold, tc_icp_result *result);
+tc_status tc_sharded_icp_detailed_device(tc_context *ctx, tc_comm *comm, int shard_mode,
+                          const float *d_source, size_t n_source, const float *d_target, size_t n_target,
+                          const float init[7], size_t max_iters, float max_correspondence_distance,
+                          float convergence_threshold, tc_icp_result *result);
+/* estimate_normals_with_config (normals.rs:257-357) of one replicated cloud over the ranks: every rank builds the same
+ * index, computes the records of ITS range of cell-sorted positions, one all-gather (n x 24 bytes in total) on the compute
+ * stream, a local kernel restores the input order.  Every rank receives all n records in d_out (n x 6). */
+tc_status tc_sharded_estimate_normals_device(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n,
+                                             const tc_normal_config *config, float *d_out_normal_points);
 
 /* ---- multiscale ICP ----
  * multiscale_icp_point_to_point(source, target, init, &MultiScaleIcpConfig) -> Result<ICPResult>

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.load()
     for sym in declared_symbols():
         assert hasattr(L, sym), sym
-    assert L.tc_abi_version() == 1
+    assert L.tc_abi_version() == 2
 
 
 def test_no_device_means_gpu_error_not_fallback():

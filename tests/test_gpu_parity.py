@@ -125,11 +125,11 @@ def test_shard_abi_single_rank_equals_fused_loop(ctx):
     src, tgt, T = synth.registration_pair(20000, seed=8)
     ds, dt = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
     nrm = ctx.estimate_normals(dt, 16)
-    a = D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 12, None, 0.0)
+    a = D.stepwise_sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 12, None, 0.0)
     b = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, 12, None, 0.0, correspondences=False)
     assert a.iterations == b.iterations == 12
     assert np.array_equal(a.transformation, b.transformation)
-    a = D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 50)
+    a = D.stepwise_sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 50)
     b = ctx.icp_point_to_plane(ds, dt, nrm, None, 50)
     assert (a.converged, a.iterations) == (b.converged, b.iterations)
     assert np.array_equal(a.transformation, b.transformation)
@@ -623,6 +623,7 @@ def test_sharded_normals_slices_reassemble(ctx):
         assert [len(p) for p in parts] == [b - a for a, b in (D.shard_range(len(pts), r, world) for r in range(world))]
         out = ctx.normals_unsort(torch.cat(parts))
         assert torch.equal(out, ref)
+    assert torch.equal(D.stepwise_sharded_estimate_normals(ctx, d, 12), ref)
     assert torch.equal(D.sharded_estimate_normals(ctx, d, 12), ref)
     with pytest.raises(tc.InvalidData):
         ctx.estimate_normals_slice(d, cfg, 10, len(pts) + 1)

@@ -1,0 +1,167 @@
+"""-m gpu tests of the multi-GPU boundary: tc_comm_* and tc_sharded_*_device.
+
+A GPU box has ONE device, so a 2-rank RCCL run is impossible there (RCCL refuses two ranks on one GPU).  What runs:
+  * the sharded entry points with a one-rank communicator -- both the local one and a REAL RCCL communicator
+    (ncclGetUniqueId -> ncclCommInitRank(1 rank) -> ncclAllReduce / ncclAllGather enqueued on the context's stream) --
+    must reproduce the fused single-GPU loop bit for bit;
+  * two PROCESSES sharing the one GPU (world_size 2, gloo), each driving the C entry points through the host-callback
+    communicator: the spatial sharding, the per-iteration all-reduce, the correspondence gather, the point-to-point
+    post-loop reduction and the normals all-gather all run; both ranks end bit-identical and within the parity budget
+    of the single-GPU result.
+"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import threecrate_amd as tc
+from threecrate_amd import _lib, synth
+from threecrate_amd import distributed as D
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _frob(a, b):
+    return float(np.linalg.norm(tc.isometry_to_matrix(a).astype(np.float64) - tc.isometry_to_matrix(b).astype(np.float64)))
+
+
+def _pair(n, seed, noise=0.0):
+    src, tgt, T = synth.registration_pair(n, seed=seed, noise_sigma=noise)
+    return torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), T
+
+
+def _rccl_comm(ctx):
+    """a real RCCL communicator with one rank (what tc_comm_create does on every rank of an 8-GPU node)"""
+    L = _lib.load()
+    ident = (C.c_uint8 * _lib.TC_COMM_ID_BYTES)()
+    assert L.tc_comm_unique_id(ident) == _lib.TC_OK, "librccl must be loadable on a GPU box"
+    h = C.c_void_p()
+    ctx._check(L.tc_comm_create(ctx._h, 1, 0, ident, C.byref(h)))
+    assert L.tc_comm_size(h) == 1 and L.tc_comm_rank(h) == 0
+    return D.Comm(ctx, h, 0, 1)
+
+
+@pytest.mark.parametrize("kind", ["local", "rccl"])
+def test_one_rank_sharded_entry_equals_fused_loop(ctx, kind):
+    ds, dt, _ = _pair(30000, 8)
+    nrm = ctx.estimate_normals(dt, 16)
+    comm = D.Comm.local(ctx) if kind == "local" else _rccl_comm(ctx)
+    try:
+        for iters, thr in ((12, 0.0), (50, 1e-6)):
+            b = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, iters, None, thr)
+            for local in (False, True):
+                a = D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, iters, None, thr, comm=comm, source_is_local_slice=local,
+                                                 correspondences=True)
+                assert (a.converged, a.iterations, a.mse) == (b.converged, b.iterations, b.mse)
+                assert np.array_equal(a.transformation, b.transformation)
+                assert np.array_equal(a.correspondences, b.correspondences)
+        # point-to-point, not converged: the post-loop mse recompute (registration.rs:343-361) goes through the reduction
+        b = ctx.icp_detailed(ds, dt, None, 5, 0.05, 0.0)
+        a = D.sharded_icp_detailed(ctx, ds, dt, None, 5, 0.05, 0.0, comm=comm, correspondences=True)
+        assert not a.converged and a.iterations == 5 and a.mse == b.mse
+        assert np.array_equal(a.transformation, b.transformation) and np.array_equal(a.correspondences, b.correspondences)
+        b = ctx.icp_detailed(ds, dt, None, 40, None, 1e-9)
+        a = D.sharded_icp_detailed(ctx, ds, dt, None, 40, None, 1e-9, comm=comm)
+        assert (a.converged, a.iterations, a.mse) == (b.converged, b.iterations, b.mse) and np.array_equal(a.transformation, b.transformation)
+        # normals: slice + all-gather + unsort == the single call
+        assert torch.equal(D.sharded_estimate_normals(ctx, dt, 16, comm=comm), nrm)
+    finally:
+        comm.close()
+
+
+def test_sharded_entry_validation_matches_single_gpu(ctx):
+    ds, dt, _ = _pair(2000, 3)
+    nrm = ctx.estimate_normals(dt, 10)
+    comm = D.Comm.local(ctx)
+    with pytest.raises(tc.InvalidData):
+        D.sharded_icp_point_to_plane(ctx, ds[:0], dt, nrm, comm=comm)
+    with pytest.raises(tc.InvalidData):
+        D.sharded_icp_point_to_plane(ctx, ds, dt, nrm[:-1], comm=comm)
+    with pytest.raises(tc.InvalidData):
+        D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 0, comm=comm)
+    with pytest.raises(tc.AlgorithmError):      # nothing within 1e-9: fewer than 6 pairs
+        D.sharded_icp_point_to_plane(ctx, ds + 5.0, dt, nrm, None, 5, 1e-9, comm=comm)
+    other = tc.GpuContext(0)
+    with pytest.raises(tc.InvalidData):         # a communicator belongs to its context
+        D.sharded_icp_point_to_plane(other, ds, dt, nrm, comm=comm)
+    other.close()
+    comm.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    try:
+        ctx = tc.GpuContext(0)
+        comm = D.Comm.from_group(ctx)                    # gloo group -> host-callback communicator
+        assert (comm.rank, comm.size) == (rank, world)
+        ds, dt, _ = _pair(40000, 8, noise=2e-4)
+        nrm = D.sharded_estimate_normals(ctx, dt, 16, comm=comm)
+        out["normals"] = nrm.cpu().numpy()
+        a = D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 12, None, 0.0, comm=comm, correspondences=True)
+        out["p2plane"] = (a.transformation, a.mse, a.iterations, a.converged, a.correspondences)
+        a = D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 50, 0.05, 1e-7, comm=comm)
+        out["p2plane_conv"] = (a.transformation, a.mse, a.iterations, a.converged)
+        a = D.sharded_icp_detailed(ctx, ds, dt, None, 6, None, 0.0, comm=comm, correspondences=True)
+        out["p2p"] = (a.transformation, a.mse, a.iterations, a.converged, a.correspondences)
+        # TC_SHARD_LOCAL with a lopsided partition: rank 0 owns nothing at all
+        mine = ds[:0] if rank == 0 else ds
+        a = D.sharded_icp_point_to_plane(ctx, mine, dt, nrm, None, 8, None, 0.0, comm=comm, source_is_local_slice=True)
+        out["local_empty"] = (a.transformation, a.mse, a.iterations)
+        comm.close()
+        ctx.close()
+    finally:
+        q.put((rank, out))
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_the_gpu_drive_the_c_entry_points(ctx):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0, r1 = outs[0], outs[1]
+    assert set(r0) == {"normals", "p2plane", "p2plane_conv", "p2p", "local_empty"}, "rank 0 failed: " + str(list(r0))
+    # every rank ends with bit-identical state
+    for key in r0:
+        for x, y in zip(np.atleast_1d(r0[key]) if key == "normals" else r0[key], np.atleast_1d(r1[key]) if key == "normals" else r1[key]):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), key
+    # ... and it is the single-GPU answer: normals bit for bit (same kernel, same index), ICP within the parity budget
+    ds, dt, _ = _pair(40000, 8, noise=2e-4)
+    nrm = ctx.estimate_normals(dt, 16)
+    assert np.array_equal(r0["normals"], nrm.cpu().numpy())
+    b = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, 12, None, 0.0)
+    T, mse, it, conv, corr = r0["p2plane"]
+    assert (it, conv) == (b.iterations, b.converged) and _frob(T, b.transformation) <= 1e-5 and abs(mse - b.mse) <= 1e-6 * max(b.mse, 1e-12) + 1e-12
+    assert np.array_equal(corr, b.correspondences)
+    b = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, 50, 0.05, 1e-7)
+    T, mse, it, conv = r0["p2plane_conv"]
+    assert (it, conv) == (b.iterations, b.converged) and _frob(T, b.transformation) <= 1e-5
+    b = ctx.icp_detailed(ds, dt, None, 6, None, 0.0)
+    T, mse, it, conv, corr = r0["p2p"]
+    assert (it, conv) == (6, False) and _frob(T, b.transformation) <= 1e-5 and abs(mse - b.mse) <= 1e-5 * b.mse
+    assert np.array_equal(corr, b.correspondences)
+    b = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, 8, None, 0.0)
+    T, mse, it = r0["local_empty"]
+    assert np.array_equal(T, b.transformation) and it == 8      # one rank owns everything: the same sums, bit for bit

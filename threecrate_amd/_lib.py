@@ -10,6 +10,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libthreecrate_hip.so")
 
 TC_OK, TC_INVALID_DATA, TC_ALGORITHM, TC_GPU, TC_UNSUPPORTED = 0, 1, 2, 3, 4
+TC_COMM_ID_BYTES = 128
+TC_COLL_SUM_F64, TC_COLL_SUM_U32, TC_COLL_ALLGATHER_U8 = 0, 1, 2
+TC_SHARD_SPATIAL, TC_SHARD_LOCAL = 0, 1
+# int (*tc_host_collective_fn)(void *user, int op, void *host_buf, size_t count)
+HOST_COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 SUMS_P2PLANE, SUMS_P2P, SUMS_STRIDE = 29, 17, 32
 
 
@@ -76,13 +81,15 @@ class KernelStatC(C.Structure):
 
 # every symbol include/threecrate_hip.h declares (tests/test_abi_symbols.py checks the header against this)
 EXPORTS = [
-    "tc_abi_version", "tc_device_count", "tc_context_create", "tc_context_create_on_stream",
+    "tc_abi_version", "tc_device_count", "tc_context_create", "tc_context_create_on_stream", "tc_context_wait_stream",
     "tc_context_destroy", "tc_last_error_message", "tc_synchronize", "tc_normal_config_default",
     "tc_estimate_normals", "tc_estimate_normals_device", "tc_estimate_normals_slice_device", "tc_normals_unsort_device", "tc_icp_detailed", "tc_icp_detailed_device",
     "tc_icp_point_to_point", "tc_icp", "tc_icp_point_to_plane_detailed",
     "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
     "tc_icp_shard_reduce", "tc_icp_shard_get_sums", "tc_icp_shard_set_sums", "tc_icp_shard_done",
     "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
+    "tc_comm_unique_id", "tc_comm_create", "tc_comm_adopt", "tc_comm_create_host", "tc_comm_create_local", "tc_comm_rank", "tc_comm_size",
+    "tc_comm_destroy", "tc_sharded_icp_point_to_plane_device", "tc_sharded_icp_detailed_device", "tc_sharded_estimate_normals_device",
     "tc_multiscale_icp_point_to_point", "tc_gicp", "tc_gicp_device", "tc_kiss_icp", "tc_kiss_icp_device", "tc_knn", "tc_knn_device", "tc_radius_search", "tc_radius_search_device",
     "tc_search_index_create", "tc_search_index_create_device", "tc_search_index_size", "tc_search_index_query",
     "tc_search_index_query_device", "tc_search_index_radius_count", "tc_search_index_radius_fill", "tc_search_index_destroy", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device",
@@ -130,6 +137,7 @@ def load():
     L.tc_device_count.restype = i
     L.tc_context_create.argtypes = [i, ctxpp]
     L.tc_context_create_on_stream.argtypes = [i, vp, ctxpp]
+    L.tc_context_wait_stream.argtypes = [vp, vp]
     L.tc_context_destroy.argtypes = [vp]
     L.tc_context_destroy.restype = None
     L.tc_last_error_message.argtypes = [vp]
@@ -159,6 +167,20 @@ def load():
     L.tc_icp_shard_finish.argtypes = [vp, sz, resp]
     L.tc_icp_shard_destroy.argtypes = [vp]
     L.tc_icp_shard_destroy.restype = None
+    L.tc_comm_unique_id.argtypes = [vp]
+    L.tc_comm_create.argtypes = [vp, i, i, vp, ctxpp]
+    L.tc_comm_adopt.argtypes = [vp, vp, i, i, ctxpp]
+    L.tc_comm_create_host.argtypes = [vp, i, i, HOST_COLLECTIVE_FN, vp, ctxpp]
+    L.tc_comm_create_local.argtypes = [vp, ctxpp]
+    L.tc_comm_rank.argtypes = [vp]
+    L.tc_comm_rank.restype = i
+    L.tc_comm_size.argtypes = [vp]
+    L.tc_comm_size.restype = i
+    L.tc_comm_destroy.argtypes = [vp]
+    L.tc_comm_destroy.restype = None
+    L.tc_sharded_icp_point_to_plane_device.argtypes = [vp, vp, i, f32p, sz, f32p, sz, f32p, sz, sz, f32p, sz, f, f, resp]
+    L.tc_sharded_icp_detailed_device.argtypes = [vp, vp, i, f32p, sz, f32p, sz, f32p, sz, f, f, resp]
+    L.tc_sharded_estimate_normals_device.argtypes = [vp, vp, f32p, sz, C.POINTER(NormalConfig), f32p]
     L.tc_multiscale_icp_point_to_point.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(MultiScaleConfigC), resp]
     L.tc_gicp.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(GicpConfigC), resp]
     L.tc_gicp_device.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(GicpConfigC), resp]

@@ -162,6 +162,36 @@ class GpuContext:
             msg = self._L.tc_last_error_message(self._h).decode()
             raise _ERR.get(rc, Error)(msg)
 
+    def _order(self, device):
+        """Stream ordering rule of the *_device entry points (include/threecrate_hip.h): the library reads the
+        tensors on the context's stream, torch produced them (conversions, slices, the caller's own ops) on its
+        current stream -> make the context's stream wait for torch's (an event, no host wait)."""
+        import torch
+        cur = torch.cuda.current_stream(device).cuda_stream
+        if self.stream is None or self.stream != cur:
+            self._check(self._L.tc_context_wait_stream(self._h, C.c_void_p(cur)))
+
+    @staticmethod
+    def _max_dist(d):
+        """Option<f32> -> the ABI's encoding (< 0 = None).  A negative Some(d) must not alias None (see _reject_all):
+        it is returned as None."""
+        if d is None:
+            return -1.0
+        return None if float(d) < 0.0 else float(d)
+
+    @staticmethod
+    def _reject_all(ns, nt, max_iters, normals_len=None):
+        """A negative Some(max_correspondence_distance): the reference rejects every pair (registration.rs:100-101,
+        `distance > d` always holds), i.e. after its validation (:266-276 / :517-531) the first iteration fails with
+        "Insufficient correspondences" (:311-315 / :568-572)."""
+        if ns == 0 or nt == 0:
+            raise InvalidData("Source or target point cloud is empty")
+        if normals_len is not None and normals_len != nt:
+            raise InvalidData("target_normals length must equal the number of target points")
+        if max_iters == 0:
+            raise InvalidData("Max iterations must be positive")
+        raise AlgorithmError("Insufficient correspondences found (negative max_correspondence_distance rejects every pair)")
+
     # ---- profiling ----
     def profile_enable(self, on=True):
         """False/0 off, True/1 every kernel, 2 = sampled events on the dominant kernel only."""
@@ -196,6 +226,7 @@ class GpuContext:
             import torch
             x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
             out = torch.empty((x.shape[0], 6), dtype=torch.float32, device=x.device)
+            self._order(x.device)
             self._check(self._L.tc_estimate_normals_device(self._h, x.data_ptr(), x.shape[0], C.byref(c), out.data_ptr()))
             return out
         x = _as_host(cloud)
@@ -210,6 +241,7 @@ class GpuContext:
         c = self._cfg(config)
         x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
         out = torch.empty((max(end - begin, 0), 6), dtype=torch.float32, device=x.device)
+        self._order(x.device)
         self._check(self._L.tc_estimate_normals_slice_device(self._h, x.data_ptr(), x.shape[0], C.byref(c), int(begin), int(end), out.data_ptr()))
         return out
 
@@ -219,6 +251,7 @@ class GpuContext:
         import torch
         srt = sorted_all.detach().to(torch.float32).contiguous()
         out = torch.empty_like(srt)
+        self._order(srt.device)
         self._check(self._L.tc_normals_unsort_device(self._h, srt.data_ptr(), srt.shape[0], out.data_ptr()))
         return out
 
@@ -279,6 +312,7 @@ class GpuContext:
             import torch
             x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
             out = torch.empty((max(1, x.shape[0]), 3), dtype=torch.float32, device=x.device)
+            self._order(x.device)
             self._check(self._L.tc_voxel_grid_filter_device(self._h, x.data_ptr(), x.shape[0], voxel_size, out.data_ptr(), C.byref(n_out)))
             return out[: n_out.value]
         x = _as_host(cloud)
@@ -290,7 +324,7 @@ class GpuContext:
     def _result(self, r, ns, corr, want_pairs):
         T = np.array(list(r.transformation), np.float32)
         res = ICPResult(T, float(r.mse), int(r.iterations), bool(r.converged), corr_target=corr)
-        if want_pairs and corr is not None:
+        if want_pairs is True and corr is not None:
             ct = corr.cpu().numpy() if _is_torch(corr) else corr
             ct = ct.astype(np.int64)
             src = np.nonzero(ct != 0xFFFFFFFF)[0]
@@ -300,7 +334,7 @@ class GpuContext:
     def icp_detailed(self, source, target, init=None, max_iters=50, max_correspondence_distance=None,
                      convergence_threshold=1e-6, correspondences=True, _checked=False):
         """registration.rs:258-370"""
-        md = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance)
+        md = self._max_dist(max_correspondence_distance)
         i7 = np.ascontiguousarray(IDENTITY if init is None else np.asarray(init, np.float32).reshape(7))
         r = _lib.IcpResultC()
         if _is_torch(source):
@@ -309,16 +343,22 @@ class GpuContext:
             t = target.detach().to(torch.float32).contiguous().reshape(-1, 3)
             corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
             r.corr_target = corr.data_ptr() if corr is not None else None
+            if md is None:
+                self._reject_all(s.shape[0], t.shape[0], max_iters)
             if _checked and not (convergence_threshold > 0):
                 raise InvalidData("Convergence threshold must be positive")
+            self._order(s.device)
             self._check(self._L.tc_icp_detailed_device(self._h, s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0],
                                                        i7.ctypes.data, max_iters, md, convergence_threshold, C.byref(r)))
             if corr is not None:
-                corr = corr[: s.shape[0]].to(torch.int64) & 0xFFFFFFFF
+                # correspondences="device": the dense per-source target index stays as written (int32 bits, -1 = none)
+                corr = corr[: s.shape[0]] if correspondences == "device" else corr[: s.shape[0]].to(torch.int64) & 0xFFFFFFFF
             return self._result(r, s.shape[0], corr, correspondences)
         s, t = _as_host(source), _as_host(target)
         corr = np.empty(max(1, s.shape[0]), np.uint32) if correspondences else None
         r.corr_target = corr.ctypes.data if corr is not None else None
+        if md is None:
+            self._reject_all(s.shape[0], t.shape[0], max_iters)
         fn = self._L.tc_icp_point_to_point if _checked else self._L.tc_icp_detailed
         a, b = (convergence_threshold, md) if _checked else (md, convergence_threshold)
         self._check(fn(self._h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], i7.ctypes.data, max_iters, a, b, C.byref(r)))
@@ -336,9 +376,11 @@ class GpuContext:
             t = target.detach().to(torch.float32).contiguous().reshape(-1, 3)
             corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
             r.corr_target = corr.data_ptr() if corr is not None else None
+            self._order(s.device)
             self._check(self._L.tc_gicp_device(self._h, s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], i7.ctypes.data, C.byref(c), C.byref(r)))
             if corr is not None:
-                corr = corr[: s.shape[0]].to(torch.int64) & 0xFFFFFFFF
+                # correspondences="device": the dense per-source target index stays as written (int32 bits, -1 = none)
+                corr = corr[: s.shape[0]] if correspondences == "device" else corr[: s.shape[0]].to(torch.int64) & 0xFFFFFFFF
             return self._result(r, s.shape[0], corr, correspondences)
         s, t = _as_host(source), _as_host(target)
         corr = np.empty(max(1, s.shape[0]), np.uint32) if correspondences else None
@@ -359,6 +401,7 @@ class GpuContext:
             t = target.detach().to(torch.float32).contiguous().reshape(-1, 3)
             corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
             r.corr_target = corr.data_ptr() if corr is not None else None
+            self._order(s.device)
             self._check(self._L.tc_kiss_icp_device(self._h, s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], i7.ctypes.data,
                                                    C.byref(c), C.byref(r), C.byref(nd)))
             if corr is not None:
@@ -414,7 +457,7 @@ class GpuContext:
                                     max_correspondence_distance=None, convergence_threshold=1e-6, correspondences=True):
         """registration.rs:508-602.  target_normals: (Nt, 3) Vector3f, or the (Nt, 6) NormalPoint3f
         array returned by estimate_normals (its normal columns are used in place, stride 6)."""
-        md = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance)
+        md = self._max_dist(max_correspondence_distance)
         i7 = np.ascontiguousarray(IDENTITY if init is None else np.asarray(init, np.float32).reshape(7))
         r = _lib.IcpResultC()
         if _is_torch(source):
@@ -425,19 +468,25 @@ class GpuContext:
             stride = 6 if (n.dim() == 2 and n.shape[1] == 6) else 3
             nptr = n.data_ptr() + (12 if stride == 6 else 0)
             nn = n.shape[0] if n.dim() == 2 else n.numel() // 3
+            if md is None:
+                self._reject_all(s.shape[0], t.shape[0], max_iters, nn)
             corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
             r.corr_target = corr.data_ptr() if corr is not None else None
+            self._order(s.device)
             self._check(self._L.tc_icp_point_to_plane_detailed_device(
                 self._h, s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], nptr, nn, stride, i7.ctypes.data, max_iters,
                 md, convergence_threshold, C.byref(r)))
             if corr is not None:
-                corr = corr[: s.shape[0]].to(torch.int64) & 0xFFFFFFFF
+                # correspondences="device": the dense per-source target index stays as written (int32 bits, -1 = none)
+                corr = corr[: s.shape[0]] if correspondences == "device" else corr[: s.shape[0]].to(torch.int64) & 0xFFFFFFFF
             return self._result(r, s.shape[0], corr, correspondences)
         s, t = _as_host(source), _as_host(target)
         n = np.ascontiguousarray(np.asarray(target_normals, np.float32))
         stride = 6 if (n.ndim == 2 and n.shape[1] == 6) else 3
         nn = n.shape[0] if n.ndim == 2 else n.size // 3
         nptr = n.ctypes.data + (12 if stride == 6 else 0)
+        if md is None:
+            self._reject_all(s.shape[0], t.shape[0], max_iters, nn)
         corr = np.empty(max(1, s.shape[0]), np.uint32) if correspondences else None
         r.corr_target = corr.ctypes.data if corr is not None else None
         self._check(self._L.tc_icp_point_to_plane_detailed(
@@ -682,6 +731,7 @@ class SearchIndex:
         if _is_torch(cloud):
             import torch
             x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            ctx._order(x.device)
             ctx._check(self._L.tc_search_index_create_device(ctx._h, x.data_ptr(), x.shape[0], int(k_hint), C.byref(h)))
         else:
             x = _as_host(cloud)
@@ -699,6 +749,7 @@ class SearchIndex:
             idx = torch.zeros((q.shape[0], kk), dtype=torch.int32, device=q.device)
             dist = torch.zeros((q.shape[0], kk), dtype=torch.float32, device=q.device)
             cnt = torch.zeros(q.shape[0], dtype=torch.int32, device=q.device)
+            self._ctx._order(q.device)
             self._ctx._check(self._L.tc_search_index_query_device(self._h, q.data_ptr(), q.shape[0], int(k), float(radius), idx.data_ptr(),
                                                                   dist.data_ptr(), cnt.data_ptr()))
             return idx, dist, cnt

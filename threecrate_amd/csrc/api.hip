@@ -5,10 +5,16 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
 namespace tc {
+
+int debug_flags() {
+    static const int flags = [] { const char *e = getenv("TC_DEBUG"); return e ? atoi(e) : 0; }();
+    return flags;
+}
 
 tc_status fail(tc_context *ctx, tc_status st, const std::string &msg) {
     if (ctx) ctx->last_error = msg;
@@ -144,6 +150,17 @@ tc_status tc_context_create_on_stream(int device, void *hip_stream, tc_context *
     return context_create(device, hip_stream, false, out);
 }
 
+tc_status tc_context_wait_stream(tc_context *ctx, void *other_hip_stream) {
+    if (!ctx) return TC_INVALID_DATA;
+    hipStream_t other = (hipStream_t)other_hip_stream;
+    if (other == ctx->stream) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->order_event) TC_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
+    TC_HIP_TRY(ctx, hipEventRecord(ctx->order_event, other));
+    TC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->order_event, 0));
+    return TC_OK;
+}
+
 void tc_context_destroy(tc_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -151,6 +168,8 @@ void tc_context_destroy(tc_context *ctx) {
     free_index(ctx->tgt_index); free_index(ctx->src_index); free_index(ctx->vox_index);
     free_buf(ctx->in_a); free_buf(ctx->in_b); free_buf(ctx->in_c); free_buf(ctx->out_a); free_buf(ctx->bbox);
     free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->gicp_src_cov); free_buf(ctx->overflow);
+    for (auto e : ctx->chunk_events) (void)hipEventDestroy(e);
+    if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     for (auto &t : ctx->timers) for (auto &p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -317,6 +336,57 @@ tc_status tc_icp_point_to_plane_detailed(tc_context *ctx, const float *source, s
     TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_c.p, normals, nbytes, hipMemcpyHostToDevice, ctx->stream));
     return icp_run(ctx, true, (const float *)ctx->in_a.p, n_source, (const float *)ctx->in_b.p, n_target,
                    (const float *)ctx->in_c.p, stride, init, max_iters, max_dist, conv_thr, result, false);
+}
+
+// ---- one registration / one cloud over the ranks of a communicator ----------------------------------
+tc_status tc_sharded_icp_point_to_plane_device(tc_context *ctx, tc_comm *comm, int shard_mode, const float *d_source, size_t n_source,
+                                               const float *d_target, size_t n_target, const float *d_normals, size_t n_normals,
+                                               size_t stride, const float init[7], size_t max_iters, float max_dist, float conv_thr,
+                                               tc_icp_result *result) {
+    if (!ctx || !comm || !result) return TC_INVALID_DATA;
+    if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
+    if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
+    // a rank of a TC_SHARD_LOCAL run may own no source points (the other ranks do)
+    const size_t ns_check = (shard_mode == TC_SHARD_LOCAL && comm->nranks > 1 && n_source == 0) ? 1 : n_source;
+    if (tc_status s = p2plane_validate(ctx, ns_check, n_target, n_normals, stride, max_iters, result)) return s;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return icp_run_sharded(ctx, comm, shard_mode, true, d_source, n_source, d_target, n_target, d_normals, stride, init, max_iters, max_dist,
+                           conv_thr, result);
+}
+
+tc_status tc_sharded_icp_detailed_device(tc_context *ctx, tc_comm *comm, int shard_mode, const float *d_source, size_t n_source,
+                                         const float *d_target, size_t n_target, const float init[7], size_t max_iters, float max_dist,
+                                         float conv_thr, tc_icp_result *result) {
+    if (!ctx || !comm || !result) return TC_INVALID_DATA;
+    if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
+    if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
+    const size_t ns_check = (shard_mode == TC_SHARD_LOCAL && comm->nranks > 1 && n_source == 0) ? 1 : n_source;
+    if (tc_status s = icp_validate(ctx, ns_check, n_target, max_iters, result)) return s;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return icp_run_sharded(ctx, comm, shard_mode, false, d_source, n_source, d_target, n_target, nullptr, 0, init, max_iters, max_dist,
+                           conv_thr, result);
+}
+
+tc_status tc_sharded_estimate_normals_device(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n, const tc_normal_config *cfg,
+                                             float *d_out) {
+    if (!comm) return TC_INVALID_DATA;
+    bool empty;
+    if (tc_status s = normals_validate(ctx, n, cfg, &empty)) return s;
+    if (empty) return TC_OK;
+    if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank;
+    // equal slots of `rows` records (the last ranks' ranges may be shorter or empty): the all-gather runs in place
+    const size_t rows = (n + W - 1) / W;
+    const size_t lo = std::min(r * rows, n), hi = std::min((r + 1) * rows, n);
+    if (tc_status s = ensure(ctx, ctx->out_a, W * rows * 6 * sizeof(float))) return s;
+    float *sorted_all = (float *)ctx->out_a.p;
+    if (tc_status s = normals_device(ctx, d_xyz, n, cfg, sorted_all + r * rows * 6, lo, hi, true)) return s;
+    if (tc_status s = comm_allgather(comm, sorted_all, rows * 6 * sizeof(float))) return s;
+    // slot q holds the cell-sorted positions [q rows, min((q + 1) rows, n)): the slots are contiguous in position
+    if (tc_status s = launch_normals_unsort(ctx, ctx->tgt_index, sorted_all, d_out)) return s;
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
 }
 
 tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp_job *jobs, size_t n_jobs,

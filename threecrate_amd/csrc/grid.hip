@@ -397,7 +397,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     hipStream_t st = ctx->stream;
     const uint32_t n32 = (uint32_t)n;
     const int nb = (int)((n + 255) / 256);
-    static const int dbg = getenv("TC_DEBUG") ? atoi(getenv("TC_DEBUG")) : 0;
+    const int dbg = debug_flags();
 
     if (reuse_geom) {
         ix.geom = *reuse_geom;

@@ -1118,17 +1118,29 @@ __global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restr
 }
 
 // after the last iteration: not-converged epilogue (registration.rs:343-369 / :595-601)
-__global__ void icp_finish_kernel(IcpState *__restrict__ st, const double *__restrict__ partials, uint32_t nblocks, int p2plane) {
+// from_sums: the post-loop (sum |T s - q|^2, count) of a sharded point-to-point run sit in st->sums[0..1], already
+// reduced over the ranks (icp_final_mse_fold_kernel + all-reduce); otherwise the per-block rows are folded here
+__global__ void icp_finish_kernel(IcpState *__restrict__ st, const double *__restrict__ partials, uint32_t nblocks, int p2plane, int from_sums) {
     if (threadIdx.x != 0 || st->done) return;
     st->converged = 0;
     if (p2plane || st->kiss) {         // point-to-plane :595-601 and kiss_icp.rs:292-299 return the last measured mse
         st->mse = st->prev_mse;
     } else {
         double s = 0.0, c = 0.0;
-        for (uint32_t b = 0; b < nblocks; ++b) { s += partials[(size_t)b * TC_ICP_SUMS_STRIDE]; c += partials[(size_t)b * TC_ICP_SUMS_STRIDE + 1]; }
+        if (from_sums) { s = st->sums[0]; c = st->sums[1]; }
+        else for (uint32_t b = 0; b < nblocks; ++b) { s += partials[(size_t)b * TC_ICP_SUMS_STRIDE]; c += partials[(size_t)b * TC_ICP_SUMS_STRIDE + 1]; }
         st->mse = (c > 0.0) ? (float)(s / c) : st->prev_mse;
     }
     st->done = 1;
+}
+
+// sharded point-to-point: this rank's post-loop (sum, count) -> st->sums[0..1] (rest zero), same order as icp_finish_kernel
+__global__ void icp_final_mse_fold_kernel(IcpState *__restrict__ st, const double *__restrict__ partials, uint32_t nblocks) {
+    if (threadIdx.x >= TC_ICP_SUMS_STRIDE) return;
+    double s = 0.0;
+    if (threadIdx.x < 2 && !st->done)
+        for (uint32_t b = 0; b < nblocks; ++b) s += partials[(size_t)b * TC_ICP_SUMS_STRIDE + threadIdx.x];
+    st->sums[threadIdx.x] = s;
 }
 
 // ---- host orchestration ---------------------------------------------------------------------
@@ -1172,7 +1184,7 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
                              uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr_pos, uint32_t *rlist,
                              double *partials, bool do_sum, bool do_apply, bool do_reduce, const float4 *src_cov = nullptr) {
     hipStream_t s = ctx->stream;
-    static const int dbg = getenv("TC_DEBUG") ? atoi(getenv("TC_DEBUG")) : 0;
+    const int dbg = debug_flags();
     double *refine_rows = partials + (size_t)l.nblocks * TC_ICP_SUMS_STRIDE;
     if (do_reduce) {
         {
@@ -1224,7 +1236,8 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, hs, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
     // order the source by the (tile-major) target cell of its initially transformed position
     out.tg = plan_tiles(ctx->tgt_index.geom, ns);
-    if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &ctx->tgt_index.geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
+    if (ns > 0)       // (a rank of a sharded run may own no source points)
+        if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &ctx->tgt_index.geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
     out.l = plan_launch(ns);
     if (tc_status s = ensure(ctx, ctx->partials, ((size_t)(kMaxPartialBlocks + kRefineBlocks) * TC_ICP_SUMS_STRIDE + 2) * sizeof(double))) return s;
     // corr | corr_pos | refine counts (one per wave of a main block) | refine entries (uint2, chunk / 4 per wave)
@@ -1264,6 +1277,41 @@ tc_status icp_run_gicp(tc_context *ctx, const float *d_src, size_t ns, const flo
                         d_cov_tgt);
 }
 
+// Iterations are enqueued in chunks; the `done` flag of chunk c is polled (pinned copy + event) before chunk c + 2 is
+// enqueued, so the stream never drains while running.  Two chunks are always in flight and chunk c + 2 is only enqueued
+// when chunk c did not finish the job: a first chunk of 6 and a second of 2 make a registration that converges within 6
+// iterations -- scan-to-scan odometry -- pay 8 iterations of launches instead of 16 (that was 1/3 of a LiDAR frame's time).
+// The events live in the context (created once, reused by every call).
+template <typename F>
+static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate, F &&enqueue_iteration) {
+    hipStream_t st = ctx->stream;
+    auto chunk_len = [](size_t c) -> size_t { return c == 0 ? 6 : c == 1 ? 2 : c == 2 ? 4 : 8; };
+    size_t nchunks = 0;
+    for (size_t covered = 0; covered < max_iters; covered += chunk_len(nchunks)) ++nchunks;
+    int32_t *flags = (int32_t *)((char *)ctx->pinned + 1024);
+    const size_t max_flags = 200;                                  // pinned bytes 1024 .. 2048 hold them (the bbox partials follow)
+    size_t it = 0;
+    for (size_t c = 0; c < nchunks; ++c) {
+        if (c >= 2 && c - 2 < max_flags) {
+            TC_HIP_TRY(ctx, hipEventSynchronize(ctx->chunk_events[(c - 2) & 3]));
+            if (flags[c - 2]) break;
+        }
+        for (size_t k = 0; k < chunk_len(c) && it < max_iters; ++k, ++it)
+            if (tc_status s = enqueue_iteration()) return s;
+        if (c < max_flags) {
+            flags[c] = 0;
+            TC_HIP_TRY(ctx, hipMemcpyAsync(&flags[c], &dstate->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        }
+        while (ctx->chunk_events.size() < 4) {
+            hipEvent_t ev;
+            TC_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->chunk_events.push_back(ev);
+        }
+        TC_HIP_TRY(ctx, hipEventRecord(ctx->chunk_events[c & 3], st));     // the event of chunk c - 4 was waited for two chunks ago
+    }
+    return TC_OK;
+}
+
 static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                               const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
                               float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, const float *d_cov_src,
@@ -1288,41 +1336,16 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     }
     const float4 *nrm = (const float4 *)ctx->tgt_index.normals.p;
 
-    // iterations are enqueued in chunks; the `done` flag of chunk c is polled (pinned copy +
-    // event) before chunk c+2 is enqueued, so the stream never drains while running.
-    // (two chunks are always in flight and chunk c + 2 is only enqueued when chunk c did not finish the job: a first chunk
-    // of 6 and a second of 2 make a registration that converges within 6 iterations -- scan-to-scan odometry -- pay 8
-    // iterations of launches instead of 16: that was 1/3 of a LiDAR frame's time)
-    auto chunk_len = [](size_t c) -> size_t { return c == 0 ? 6 : c == 1 ? 2 : c == 2 ? 4 : 8; };
-    size_t nchunks = 0;
-    for (size_t covered = 0; covered < max_iters; covered += chunk_len(nchunks)) ++nchunks;
-    int32_t *flags = (int32_t *)((char *)ctx->pinned + 1024);
-    const size_t max_flags = (ctx->pinned_cap - 1024) / sizeof(int32_t);
-    std::vector<hipEvent_t> evs;
-    size_t it = 0;
-    bool stopped = false;
-    for (size_t c = 0; c < nchunks && !stopped; ++c) {
-        if (c >= 2 && c - 2 < max_flags) {
-            TC_HIP_TRY(ctx, hipEventSynchronize(evs[c - 2]));
-            if (flags[c - 2]) { stopped = true; break; }
-        }
-        for (size_t k = 0; k < chunk_len(c) && it < max_iters; ++k, ++it)
+    if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() {
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov);
-        if (c < max_flags) {
-            flags[c] = 0;
-            TC_HIP_TRY(ctx, hipMemcpyAsync(&flags[c], &dstate->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        }
-        hipEvent_t ev;
-        TC_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        TC_HIP_TRY(ctx, hipEventRecord(ev, st));
-        evs.push_back(ev);
-    }
+            return TC_OK;
+        })) return s;
     if (mode == 0) {
         ProfScope ps(ctx, "icp_final_mse");
         hipLaunchKernelGGL(icp_final_mse_kernel, dim3(su.l.mse_blocks), dim3(kIcpBlock), 0, st, su.tv, src, (uint32_t)ns,
                            su.l.mse_chunk, dstate, corr_pos, partials);
     }
-    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, su.l.mse_blocks, mode != 0 ? 1 : 0);
+    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, su.l.mse_blocks, mode != 0 ? 1 : 0, 0);
     IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
     TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
     if (res->corr_target) {
@@ -1332,9 +1355,8 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
                                        corr_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     }
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
-    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
     TC_HIP_TRY(ctx, hipGetLastError());
-    if (getenv("TC_DEBUG") && (atoi(getenv("TC_DEBUG")) & 64))
+    if (debug_flags() & 64)
         fprintf(stderr, "[tc] icp: %u iterations, refine queries total %u max %u  exit ring hist %u %u %u %u %u %u %u %u\n", hs->iterations,
                 hs->refine_total, hs->refine_max, hs->refine_ring_hist[0], hs->refine_ring_hist[1], hs->refine_ring_hist[2], hs->refine_ring_hist[3],
                 hs->refine_ring_hist[4], hs->refine_ring_hist[5], hs->refine_ring_hist[6], hs->refine_ring_hist[7]);
@@ -1344,6 +1366,78 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
                     : p2plane ? "Insufficient correspondences for point-to-plane ICP (need >= 6) or ill-conditioned system"
                             : "Insufficient correspondences found");
     }
+    for (int i = 0; i < 4; ++i) res->transformation[i] = hs->q[i];
+    for (int i = 0; i < 3; ++i) res->transformation[4 + i] = hs->t[i];
+    res->mse = hs->mse;
+    res->iterations = hs->converged ? hs->iterations : max_iters;
+    res->converged = hs->converged;
+    res->n_correspondences = hs->n_corr;
+    return TC_OK;
+}
+
+
+// ---- one registration over the ranks of a communicator -----------------------------------------------
+// Same kernels as the single-GPU loop; per iteration
+//     main + refine (this rank's shard)  ->  icp_finalize(sum only): 29 / 17 words in IcpState::sums
+//     ->  all-reduce(sum) of TC_ICP_SUMS_STRIDE doubles in place, on the context's stream (RCCL)
+//     ->  icp_finalize(apply only): every rank solves the identical system -> identical state, no broadcast.
+// nranks == 1: the all-reduce is skipped and the sums, the solve and therefore every bit of the result equal the fused
+// loop's (the finalize kernel folds the same rows in the same order whether or not it also applies them).
+__global__ void __launch_bounds__(256) icp_zero_u32_kernel(uint32_t *__restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p2plane, const float *d_src, size_t ns, const float *d_tgt,
+                          size_t nt, const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
+                          float conv_thr, tc_icp_result *res) {
+    const int mode = p2plane ? 1 : 0;
+    const int W = comm ? comm->nranks : 1, rank = comm ? comm->rank : 0;
+    IcpSetup su;
+    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, 0)) return s;
+    hipStream_t st = ctx->stream;
+    IcpState *dstate = (IcpState *)ctx->state.p;
+    // this rank's range of the tile-major sorted source: a spatially compact shard (TC_SHARD_SPATIAL), or everything it was given
+    size_t lo = 0, hi = ns;
+    if (shard_mode == TC_SHARD_SPATIAL) { lo = ns * (size_t)rank / (size_t)W; hi = ns * ((size_t)rank + 1) / (size_t)W; }
+    const size_t nl = hi - lo;
+    const IcpLaunch l = plan_launch(nl);
+    // corr (ns) | corr_pos (nl) | refine counts + entries -- inside the buffer icp_setup sized for the whole source
+    uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns, *rlist = corr + 2 * ns;
+    double *partials = (double *)ctx->partials.p;
+    const float4 *src = (const float4 *)ctx->src_index.pts.p + lo;
+    const float4 *nrm = (const float4 *)ctx->tgt_index.normals.p;
+    if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
+            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, true, false, true);
+            if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;
+            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, false, true, false);
+            return TC_OK;
+        })) return s;
+    if (mode == 0) {        // registration.rs:343-361: the post-loop mse of a run that did not converge, summed over the ranks
+        hipLaunchKernelGGL(icp_final_mse_kernel, dim3(l.mse_blocks), dim3(kIcpBlock), 0, st, su.tv, src, (uint32_t)nl, l.mse_chunk, dstate,
+                           corr_pos, partials);
+        hipLaunchKernelGGL(icp_final_mse_fold_kernel, dim3(1), dim3(64), 0, st, dstate, partials, l.mse_blocks);
+        if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;
+    }
+    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, 0u, mode != 0 ? 1 : 0, 1);
+    IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
+    TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
+    if (res->corr_target && ns > 0) {
+        const bool gather = shard_mode == TC_SHARD_SPATIAL && (W > 1 || (comm && comm->nccl));
+        // the write-out kernel scatters by ORIGINAL source index: with the source sharded spatially every rank fills its own
+        // entries of a zeroed array and one all-reduce(sum) of n_source words completes it everywhere
+        if (gather) hipLaunchKernelGGL(icp_zero_u32_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, corr, (uint32_t)ns);
+        if (nl > 0)
+            hipLaunchKernelGGL(icp_write_corr_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, su.tv, src, (uint32_t)nl, corr_pos, corr);
+        if (gather)
+            if (tc_status s = comm_allreduce_u32(comm, corr, ns)) return s;
+        TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    }
+    TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+    TC_HIP_TRY(ctx, hipGetLastError());
+    if (hs->status != TC_OK)
+        return fail(ctx, (tc_status)hs->status, p2plane ? "Insufficient correspondences for point-to-plane ICP (need >= 6) or ill-conditioned system"
+                                                        : "Insufficient correspondences found");
     for (int i = 0; i < 4; ++i) res->transformation[i] = hs->q[i];
     for (int i = 0; i < 3; ++i) res->transformation[4 + i] = hs->t[i];
     res->mse = hs->mse;
@@ -1371,6 +1465,9 @@ tc_status tc_icp_shard_create(tc_context *ctx, int point_to_plane, const float *
                               tc_icp_shard **out) {
     if (!ctx || !out) return TC_INVALID_DATA;
     if (n_source_slice == 0 || n_target == 0) return tc::fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");
+    // the step-wise building blocks have no cross-rank post-loop mse recompute (registration.rs:343-361):
+    // point-to-point runs go through tc_sharded_icp_detailed_device
+    if (!point_to_plane) return tc::fail(ctx, TC_UNSUPPORTED, "tc_icp_shard_*: point-to-plane only; use tc_sharded_icp_detailed_device");
     tc_icp_shard *s = new tc_icp_shard{ctx, point_to_plane != 0, n_source_slice, {}};
     tc_status rc = tc::icp_setup(ctx, s->p2plane, d_source_slice, n_source_slice, d_target, n_target, d_target_normals,
                                  normal_stride, init, max_correspondence_distance, convergence_threshold, s->su);
@@ -1430,7 +1527,7 @@ tc_status tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *
     tc::IcpState *dstate = (tc::IcpState *)ctx->state.p;
     // point-to-point's post-loop mse recompute needs a cross-rank sum: the host driver does it
     // (threecrate_amd.distributed); here the p2plane rule (mse = previous_mse) is applied.
-    hipLaunchKernelGGL(tc::icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, (const double *)ctx->partials.p, 0u, 1);
+    hipLaunchKernelGGL(tc::icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, (const double *)ctx->partials.p, 0u, 1, 0);
     tc::IcpState *hs = (tc::IcpState *)((char *)ctx->pinned + 256);
     TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(tc::IcpState), hipMemcpyDeviceToHost, st));
     if (res->corr_target) {

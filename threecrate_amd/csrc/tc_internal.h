@@ -134,6 +134,8 @@ struct tc_context {
     uint32_t prof_tick = 0;
     std::vector<tc::KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
+    hipEvent_t order_event = nullptr;       // tc_context_wait_stream
+    std::vector<hipEvent_t> chunk_events;   // hipEventDisableTiming events of the ICP loop's chunk polling, reused across calls
 
     // persistent (grow-only) device buffers, reused across calls
     tc::DeviceIndex tgt_index;      // target / normals cloud
@@ -149,6 +151,15 @@ struct tc_context {
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
     size_t pinned_cap = 0;
+};
+
+struct tc_comm {
+    tc_context *ctx = nullptr;
+    int rank = 0, nranks = 1;
+    void *nccl = nullptr;               // ncclComm_t (RCCL), or null
+    bool own_nccl = false;
+    tc_host_collective_fn host_fn = nullptr;
+    void *host_user = nullptr;
 };
 
 namespace tc {
@@ -197,7 +208,18 @@ tc_status launch_normals_unsort(tc_context *ctx, const DeviceIndex &ix, const fl
 tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, size_t k,
                      uint32_t *d_idx, float *d_dist, uint32_t *d_count, float radius_sq = INFINITY);
 
+// TC_DEBUG bit mask, read from the environment once per process
+int debug_flags();
+
+// comm.hip: collectives of a tc_comm on the context's stream (RCCL) or through the host callback (blocking)
+tc_status comm_allreduce_f64(tc_comm *comm, double *d_buf, size_t count);
+tc_status comm_allreduce_u32(tc_comm *comm, uint32_t *d_buf, size_t count);
+tc_status comm_allgather(tc_comm *comm, void *d_buf, size_t bytes_per_rank);     // in place: rank r's part at r * bytes_per_rank
+
 // icp.hip
+tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p2plane, const float *d_src, size_t ns, const float *d_tgt,
+                          size_t nt, const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
+                          float conv_thr, tc_icp_result *res);
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters,
                   float max_dist, float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss = 0);

@@ -9,9 +9,15 @@ Two ways the path shards:
     (RCCL over xGMI when the backend is "nccl") makes them global.  Every rank then applies the
     identical reduced buffer, so all ranks hold the same transform without a broadcast.
 
-The per-shard work is done by a backend object: HipShardBackend calls the C ABI
-(tc_icp_shard_*); the CPU tests (gloo, world_size 2) plug in a checker backend instead, so that
-the sharding / collective / control flow is exercised without a GPU.
+The product path is the C ABI: `Comm` wraps a tc_comm (an RCCL communicator bound to the context's stream, created
+from a 128-byte id that this module distributes over the torch.distributed group -- any bootstrap would do) and
+sharded_icp_point_to_plane / sharded_icp_detailed / sharded_estimate_normals call tc_sharded_*_device: the whole
+loop, the per-iteration ncclAllReduce included, runs inside the library on the context's stream.  A Rust host binds
+the same entry points.
+
+The older step-wise building blocks (tc_icp_shard_* driven by sharded_icp_loop) remain for hosts that own the
+collective themselves; the CPU tests (gloo, world_size 2) plug a checker backend into that loop, so that the
+sharding / collective / control flow is exercised without a GPU.
 """
 import ctypes as C
 
@@ -46,8 +52,11 @@ class HipShardBackend:
             from .api import InvalidData
             raise InvalidData("target_normals length must equal the number of target points")
         i7 = np.ascontiguousarray(np.asarray(init, np.float32).reshape(7))
-        md = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance)
+        md = ctx._max_dist(max_correspondence_distance)
+        if md is None:
+            ctx._reject_all(self.s.shape[0], self.t.shape[0], 1, n.shape[0] if n.dim() == 2 else n.numel() // 3)
         h = C.c_void_p()
+        ctx._order(self.s.device)
         rc = self.L.tc_icp_shard_create(ctx._h, 1, self.s.data_ptr(), self.s.shape[0], self.t.data_ptr(), self.t.shape[0],
                                         n.data_ptr() + (12 if self.stride == 6 else 0), self.stride, i7.ctypes.data, md,
                                         convergence_threshold, C.byref(h))
@@ -102,13 +111,186 @@ def sharded_icp_loop(backend, max_iters, group=None, poll_every=4):
     return backend.finish(max_iters)
 
 
+class Comm:
+    """tc_comm of this rank (include/threecrate_hip.h, "communicator").
+
+    Comm.from_group(ctx, group): over a torch.distributed process group.  With the "nccl" backend (RCCL) rank 0 draws
+    a unique id (tc_comm_unique_id), the group broadcasts its 128 bytes and every rank calls tc_comm_create =
+    ncclCommInitRank: the library then owns its own communicator and enqueues its collectives on the context's
+    stream.  With a CPU backend ("gloo": several ranks sharing one GPU in the tests, or hosts without RCCL between
+    the ranks) the collectives go through the tc_comm_create_host callback and this module runs them over the group.
+    Comm.local(ctx): one rank, collectives are no-ops."""
+
+    def __init__(self, ctx, handle, rank, size, keep=None):
+        self.ctx, self._h, self.rank, self.size, self._keep = ctx, handle, rank, size, keep
+        self._L = _lib.load()
+
+    @classmethod
+    def local(cls, ctx):
+        L = _lib.load()
+        h = C.c_void_p()
+        ctx._check(L.tc_comm_create_local(ctx._h, C.byref(h)))
+        return cls(ctx, h, 0, 1)
+
+    @classmethod
+    def from_group(cls, ctx, group=None, force_host=False):
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return cls.local(ctx)
+        L = _lib.load()
+        rank, size = dist.get_rank(group), dist.get_world_size(group)
+        h = C.c_void_p()
+        backend = str(dist.get_backend(group))
+        if "nccl" in backend and not force_host:
+            ident = (C.c_uint8 * _lib.TC_COMM_ID_BYTES)()
+            if rank == 0:
+                rc = L.tc_comm_unique_id(ident)
+                if rc != _lib.TC_OK:
+                    raise Unsupported("RCCL is not available to libthreecrate_hip (tc_comm_unique_id)")
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = (C.c_uint8 * _lib.TC_COMM_ID_BYTES).from_buffer_copy(box[0])
+            ctx._check(L.tc_comm_create(ctx._h, size, rank, ident, C.byref(h)))
+            return cls(ctx, h, rank, size)
+
+        def host_collective(_user, op, buf, count):
+            try:
+                if op == _lib.TC_COLL_SUM_F64:
+                    a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
+                    t = torch.from_numpy(a)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                elif op == _lib.TC_COLL_SUM_U32:
+                    a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint32)), shape=(count,))
+                    t = torch.from_numpy(a.astype(np.int64))            # gloo has no uint32 reduction
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    a[:] = t.numpy().astype(np.uint32)
+                elif op == _lib.TC_COLL_ALLGATHER_U8:
+                    a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(size * count,))
+                    mine = torch.from_numpy(a[rank * count:(rank + 1) * count].copy())
+                    parts = [torch.empty(count, dtype=torch.uint8) for _ in range(size)]
+                    dist.all_gather(parts, mine, group=group)
+                    a[:] = torch.cat(parts).numpy()
+                else:
+                    return 2
+                return 0
+            except Exception:       # never raise through the C frame
+                return 1
+
+        cb = _lib.HOST_COLLECTIVE_FN(host_collective)
+        ctx._check(L.tc_comm_create_host(ctx._h, size, rank, cb, None, C.byref(h)))
+        return cls(ctx, h, rank, size, keep=cb)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tc_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _icp_args(ctx, source, target, init, max_correspondence_distance):
+    import torch
+    from .api import IDENTITY
+    s = source.detach().to(torch.float32).contiguous().reshape(-1, 3)
+    t = target.detach().to(torch.float32).contiguous().reshape(-1, 3)
+    i7 = np.ascontiguousarray(np.asarray(IDENTITY if init is None else init, np.float32).reshape(7))
+    md = ctx._max_dist(max_correspondence_distance)
+    return s, t, i7, md
+
+
+def _finish(ctx, r, corr, correspondences):
+    import torch
+    if corr is not None:
+        corr = corr.to(torch.int64) & 0xFFFFFFFF
+    return ctx._result(r, 0, corr, correspondences)
+
+
 def sharded_icp_point_to_plane(ctx, source, target, target_normals, init=None, max_iters=50,
                                max_correspondence_distance=None, convergence_threshold=1e-6, group=None,
+                               source_is_local_slice=False, comm=None, correspondences=False):
+    """icp_point_to_plane_detailed (registration.rs:508-602) over all ranks of `comm` (default: Comm.from_group(ctx,
+    group)) through tc_sharded_icp_point_to_plane_device: `source` is the full source cloud, replicated (the library
+    takes a spatially compact range of it per rank: TC_SHARD_SPATIAL), or -- source_is_local_slice=True -- this rank's
+    own part (TC_SHARD_LOCAL); target / normals are replicated torch CUDA tensors.  One ncclAllReduce of the packed
+    6x6 system per iteration on the context's stream; every rank returns the same ICPResult."""
+    import torch
+    own = comm is None
+    comm = comm or Comm.from_group(ctx, group)
+    try:
+        s, t, i7, md = _icp_args(ctx, source, target, init, max_correspondence_distance)
+        n = target_normals.detach().to(torch.float32).contiguous()
+        stride = 6 if (n.dim() == 2 and n.shape[1] == 6) else 3
+        nn = n.shape[0] if n.dim() == 2 else n.numel() // 3
+        if md is None:
+            ctx._reject_all(max(s.shape[0], 1 if source_is_local_slice else 0), t.shape[0], max_iters, nn)
+        r = _lib.IcpResultC()
+        corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
+        r.corr_target = corr.data_ptr() if corr is not None else None
+        ctx._order(t.device)
+        ctx._check(_lib.load().tc_sharded_icp_point_to_plane_device(
+            ctx._h, comm._h, _lib.TC_SHARD_LOCAL if source_is_local_slice else _lib.TC_SHARD_SPATIAL, s.data_ptr(), s.shape[0],
+            t.data_ptr(), t.shape[0], n.data_ptr() + (12 if stride == 6 else 0), nn, stride, i7.ctypes.data, max_iters, md,
+            convergence_threshold, C.byref(r)))
+        return _finish(ctx, r, None if corr is None else corr[: s.shape[0]], correspondences)
+    finally:
+        if own:
+            comm.close()
+
+
+def sharded_icp_detailed(ctx, source, target, init=None, max_iters=50, max_correspondence_distance=None,
+                         convergence_threshold=1e-6, group=None, source_is_local_slice=False, comm=None, correspondences=False):
+    """icp_detailed (registration.rs:258-370, point-to-point) over all ranks: tc_sharded_icp_detailed_device."""
+    import torch
+    own = comm is None
+    comm = comm or Comm.from_group(ctx, group)
+    try:
+        s, t, i7, md = _icp_args(ctx, source, target, init, max_correspondence_distance)
+        if md is None:
+            ctx._reject_all(max(s.shape[0], 1 if source_is_local_slice else 0), t.shape[0], max_iters)
+        r = _lib.IcpResultC()
+        corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
+        r.corr_target = corr.data_ptr() if corr is not None else None
+        ctx._order(t.device)
+        ctx._check(_lib.load().tc_sharded_icp_detailed_device(
+            ctx._h, comm._h, _lib.TC_SHARD_LOCAL if source_is_local_slice else _lib.TC_SHARD_SPATIAL, s.data_ptr(), s.shape[0],
+            t.data_ptr(), t.shape[0], i7.ctypes.data, max_iters, md, convergence_threshold, C.byref(r)))
+        return _finish(ctx, r, None if corr is None else corr[: s.shape[0]], correspondences)
+    finally:
+        if own:
+            comm.close()
+
+
+def sharded_estimate_normals(ctx, cloud, k=10, config=None, group=None, comm=None):
+    """estimate_normals(cloud, k) (normals.rs:238-241) of a device-resident cloud replicated on every rank:
+    tc_sharded_estimate_normals_device (every rank computes its range of cell-sorted positions, ONE ncclAllGather of
+    n x 24 bytes in total on the context's stream, a local kernel restores the input order)."""
+    import torch
+    from .api import NormalEstimationConfig
+    own = comm is None
+    comm = comm or Comm.from_group(ctx, group)
+    try:
+        c = ctx._cfg(config or NormalEstimationConfig(k_neighbors=k))
+        x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
+        out = torch.empty((x.shape[0], 6), dtype=torch.float32, device=x.device)
+        ctx._order(x.device)
+        ctx._check(_lib.load().tc_sharded_estimate_normals_device(ctx._h, comm._h, x.data_ptr(), x.shape[0], C.byref(c), out.data_ptr()))
+        return out
+    finally:
+        if own:
+            comm.close()
+
+
+def stepwise_sharded_icp_point_to_plane(ctx, source, target, target_normals, init=None, max_iters=50,
+                               max_correspondence_distance=None, convergence_threshold=1e-6, group=None,
                                source_is_local_slice=False):
-    """icp_point_to_plane_detailed (registration.rs:508-602) over all ranks of `group`:
-    `source` is the full source cloud (every rank takes its shard_range) or, with
-    source_is_local_slice=True, already this rank's slice; target / normals are replicated
-    torch CUDA tensors."""
+    """The same registration driven step by step from the host (tc_icp_shard_* + torch.distributed.all_reduce): for
+    hosts that own the collective themselves.  `source` is the full source cloud (every rank takes its index
+    shard_range) or, with source_is_local_slice=True, already this rank's slice."""
     import torch.distributed as dist
     from .api import IDENTITY, InvalidData
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -168,8 +350,9 @@ def sharded_normals(backend, group=None):
     return backend.unsort(torch.cat(pieces))
 
 
-def sharded_estimate_normals(ctx, cloud, k=10, config=None, group=None):
-    """estimate_normals(cloud, k) (normals.rs:238-241) of a device-resident cloud replicated on every rank of `group`."""
+def stepwise_sharded_estimate_normals(ctx, cloud, k=10, config=None, group=None):
+    """sharded normals with the all-gather done by the host (torch.distributed) around tc_estimate_normals_slice_device /
+    tc_normals_unsort_device; the product path is sharded_estimate_normals."""
     from .api import NormalEstimationConfig
     return sharded_normals(HipNormalsBackend(ctx, cloud, config or NormalEstimationConfig(k_neighbors=k)), group)
 

@@ -66,12 +66,25 @@ def small_transform(n):
     return yaw_isometry((0.3 * s, -0.2 * s, 0.1 * s), 0.1 * s)
 
 
-def registration_pair(n, seed=1, transform=None, scale=(1.0, 1.0, 1.0)):
-    """target = cloud(seed); source = T^-1 * cloud, so that ICP(source -> target) recovers T."""
+def gaussian_noise(n, seed, sigma):
+    """(n, 3) f32 normal deviates, counter based like the clouds (Box-Muller over splitmix_u01): same bits everywhere."""
+    c = np.arange(6 * n, dtype=np.uint64)
+    u = splitmix_u01(seed, c).astype(np.float64).reshape(n, 3, 2)
+    r = np.sqrt(-2.0 * np.log(np.maximum(u[..., 0], 2.0 ** -25)))
+    return (sigma * r * np.cos(2.0 * np.pi * u[..., 1])).astype(np.float32)
+
+
+def registration_pair(n, seed=1, transform=None, scale=(1.0, 1.0, 1.0), noise_sigma=0.0):
+    """target = cloud(seed); source = T^-1 * cloud, so that ICP(source -> target) recovers T.
+    noise_sigma > 0: INDEPENDENT sensor noise on both clouds (two scans of one scene never hold the same points): the
+    converged phase of a registration then has non-zero nearest-neighbour distances, like real scan pairs."""
     tgt = uniform_cloud(n, seed, scale)
     T = small_transform(n) if transform is None else transform
     Minv = invert_isometry(T)
     src = (tgt.astype(np.float64) @ Minv[:3, :3].T + Minv[:3, 3]).astype(np.float32)
+    if noise_sigma > 0.0:
+        src = (src + gaussian_noise(n, 1000003 + 2 * seed, noise_sigma)).astype(np.float32)
+        tgt = (tgt + gaussian_noise(n, 1000004 + 2 * seed, noise_sigma)).astype(np.float32)
     return src, tgt, T
 
 
