@@ -101,6 +101,23 @@ def cpu_baseline(n_points, tgt, src, gpu_normals=None):
     a1, _ = timed(lambda: O.icp_point_to_plane_detailed(ss, ts, nrm1[:, 3:], None, 1, None, 0.0, threads=1), 0, 1)
     a3, _ = timed(lambda: O.icp_point_to_plane_detailed(ss, ts, nrm1[:, 3:], None, 3, None, 0.0, threads=1), 0, 1)
     it1 = max((a3 - a1) / 2.0, 1e-9)
+    # why "all threads" is not "threads x one thread": the container's CPU bandwidth quota (cgroup) and the scaling of the
+    # parallel section itself, measured on the 100k-point subset
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if txt and txt[0] not in ("max", "-1"):
+                quota = float(txt[0]) / float(txt[1] if len(txt) > 1 else open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError):
+            continue
+    scaling = {}
+    for th in (1, 8, 32, threads):
+        if th > threads or str(th) in scaling:
+            continue
+        tt, _ = timed(lambda: O.estimate_normals(ts, K_NORMALS, threads=th), 0, 2)
+        scaling[str(th)] = round(m / max(tt - t_tree1, 1e-9) / 1e6, 3)
     parity = None
     if gpu_normals is not None:      # the oracle's normals of the same cloud are at hand: use them as the checker they are
         a, b = gpu_normals[:, 3:6].astype(np.float64), nrm[:, 3:6].astype(np.float64)
@@ -111,7 +128,8 @@ def cpu_baseline(n_points, tgt, src, gpu_normals=None):
     return {
         "parity": parity, "oracle_normals": nrm,
         "value": ICP_ITERS / job, "unit": "ICP it/s (whole job: normals + 50 it)", "cores": threads, "kind": "port",
-        "sched_affinity_cpus": affinity, "omp_threads": threads,
+        "sched_affinity_cpus": affinity, "omp_threads": threads, "cgroup_cpu_quota_cores": quota,
+        "normals_query_mpts_per_s_by_threads_100k_subset": scaling,
         "sample": f"oracle on the same {n_points}-pt pair, all threads: k={K_NORMALS} normals call median of 3 after 1 warm-up "
                   f"({t_norm:.2f} s, of which the single-threaded kd-tree build is {t_tree:.2f} s) + ICP: p2plane calls of 1 and 4 "
                   f"iterations, median of 3 each -> {t_iter:.3f} s per steady iteration, {t_build:.2f} s per-call setup (kd-tree "

@@ -1,0 +1,81 @@
+"""H1 reports: every result that differs from the oracle's beyond the parity budget must be
+EXPLAINED by the input, not waved through by a looser tolerance.
+
+  * normals: a point may differ only if (a) the (k+1)-th and (k+2)-th squared distances of its neighbourhood are an exact
+    f32 tie (the neighbour SET is then implementation defined: the kd-tree's winner depends on its traversal order,
+    nearest_neighbor.rs:211-219), or (b) its covariance has a (near-)degenerate smallest eigenvalue pair (relative gap
+    below EIGEN_GAP_BOUND: the eigenvector of the reference's own f32 solve then is rounding noise).
+  * correspondences of ONE iteration under the SAME transform: a source point may be matched differently only if both
+    candidates are at exactly the same f32 squared distance (same formula, no FMA).
+  * transforms over many iterations on clouds where the reference's sequential f32 sums are the noisy side: the distance to
+    the oracle is bounded by the oracle's OWN sensitivity to the order of its input (same point set, permuted).
+"""
+import numpy as np
+
+from oracle import oracle as O
+
+EIGEN_GAP_BOUND = 1e-3      # (l1 - l0) / l2 of the neighbourhood covariance: f32 eigenvector error ~ 1e-6 / gap rad
+
+
+def d2_f32(a, b):
+    """nearest_neighbor.rs:162-167: (a - b) per component, dx*dx + dy*dy + dz*dz, f32, left to right, no FMA"""
+    d = (np.asarray(a, np.float32) - np.asarray(b, np.float32)).astype(np.float32)
+    x, y, z = d[..., 0] * d[..., 0], d[..., 1] * d[..., 1], d[..., 2] * d[..., 2]
+    return ((x + y).astype(np.float32) + z).astype(np.float32)
+
+
+def cos_abs(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return np.abs((a * b).sum(1)) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-300)
+
+
+def normals_report(pts, k, gpu6, ref6, tol=1e-4, max_offenders=200):
+    """-> dict(n, n_beyond, n_bit_identical, offenders=[...]); raises AssertionError on an unexplained offender."""
+    c = cos_abs(gpu6[:, 3:6], ref6[:, 3:6])
+    bad = np.nonzero(~(c >= 1.0 - tol))[0]
+    rep = {"n": len(pts), "n_beyond": int(len(bad)), "worst": float(1.0 - c.min()) if len(c) else 0.0,
+           "n_bit_identical": int((gpu6[:, 3:6] == ref6[:, 3:6]).all(1).sum()), "offenders": []}
+    assert len(bad) <= max_offenders, f"{len(bad)} normals beyond {tol}: not a tie / conditioning tail, a defect"
+    if len(bad) == 0:
+        return rep
+    idx, dist, cnt = O.knn_batch(pts, pts[bad], k + 3)
+    for row, i in enumerate(bad):
+        nb = idx[row, : cnt[row]].astype(np.int64)
+        d2 = np.sort(d2_f32(pts[nb], pts[i]))
+        tie = bool(len(d2) > k + 1 and d2[k] == d2[k + 1])          # entries 0..k = the k+1 nearest (self included)
+        first = nb[np.argsort(d2_f32(pts[nb], pts[i]), kind="stable")][: k + 1]
+        P = pts[first].astype(np.float64)
+        ev = np.linalg.eigvalsh(np.cov(P.T, bias=True))
+        gap = float((ev[1] - ev[0]) / max(ev[2], 1e-300))
+        entry = {"point": int(i), "one_minus_abs_cos": float(1.0 - c[i]), "boundary_tie": tie, "d2_k": float(d2[min(k, len(d2) - 1)]),
+                 "d2_k_plus_1": float(d2[min(k + 1, len(d2) - 1)]), "rel_eigen_gap": gap}
+        rep["offenders"].append(entry)
+        assert tie or gap < EIGEN_GAP_BOUND, f"unexplained normal mismatch: {entry}"
+    return rep
+
+
+def correspondence_report(src, tgt, T, g_corr, r_corr):
+    """One iteration under the same transform T (7 floats).  g_corr / r_corr: (m, 2) pairs (source, target) of the two sides.
+    Every difference must be an exact f32 tie of the two candidates.  -> number of (explained) differences."""
+    assert len(g_corr) == len(r_corr), (len(g_corr), len(r_corr))
+    assert np.array_equal(g_corr[:, 0], r_corr[:, 0])
+    diff = np.nonzero(g_corr[:, 1] != r_corr[:, 1])[0]
+    assert len(diff) <= 1000, f"{len(diff)} correspondences differ: a defect, not ties"
+    for row in diff:
+        j = int(g_corr[row, 0])
+        ts = O.isometry_apply(T, src[j:j + 1])[0]
+        da, db = d2_f32(tgt[int(g_corr[row, 1])], ts), d2_f32(tgt[int(r_corr[row, 1])], ts)
+        assert da == db, f"source {j}: targets {int(g_corr[row, 1])} (d2 {da}) vs {int(r_corr[row, 1])} (d2 {db}) are not tied"
+    return int(len(diff))
+
+
+def reference_order_noise(run, src, seeds=(1, 2, 3)):
+    """max Frobenius distance between the oracle's transform on `src` and on the same points in a permuted order:
+    what the reference's sequential f32 sums (registration.rs:154-172 / :409-428) make of the SAME input."""
+    base = O.isometry_to_matrix(run(src).transformation).astype(np.float64)
+    worst = 0.0
+    for s in seeds:
+        perm = np.random.default_rng(s).permutation(len(src))
+        m = O.isometry_to_matrix(run(np.ascontiguousarray(src[perm])).transformation).astype(np.float64)
+        worst = max(worst, float(np.linalg.norm(m - base)))
+    return worst
