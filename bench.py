@@ -81,15 +81,27 @@ def cpu_baseline(n_points, tgt, src, gpu_normals=None):
     steady iteration, extrapolated to 50).  A 1-thread figure comes from a 100k-point subset."""
     import numpy as np
     from oracle import oracle as O
-    threads = O.num_threads()
+    omp_max = O.num_threads()
     try:
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = None
-    t_norm, nrm = timed(lambda: O.estimate_normals(tgt, K_NORMALS), 1, 3)
+    # the container's CPU bandwidth quota (cgroup): more runnable threads than that are throttled, not run
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if txt and txt[0] not in ("max", "-1"):
+                quota = float(txt[0]) / float(txt[1] if len(txt) > 1 else open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError):
+            continue
+    threads = max(1, min(omp_max, int(quota + 0.5))) if quota else omp_max
+    _est, _icp = O.estimate_normals, O.icp_point_to_plane_detailed
+    t_norm, nrm = timed(lambda: _est(tgt, K_NORMALS, threads=threads), 1, 3)
     t_tree, _ = timed(lambda: O.KdTree(tgt), 0, 3)
-    t1, _ = timed(lambda: O.icp_point_to_plane_detailed(src, tgt, nrm[:, 3:], None, 1, None, 0.0), 1, 3)
-    t4, _ = timed(lambda: O.icp_point_to_plane_detailed(src, tgt, nrm[:, 3:], None, 4, None, 0.0), 0, 3)
+    t1, _ = timed(lambda: _icp(src, tgt, nrm[:, 3:], None, 1, None, 0.0, threads=threads), 1, 3)
+    t4, _ = timed(lambda: _icp(src, tgt, nrm[:, 3:], None, 4, None, 0.0, threads=threads), 0, 3)
     t_iter = max((t4 - t1) / 3.0, 1e-9)
     t_build = max(t1 - t_iter, 0.0)
     job = t_norm + t_build + ICP_ITERS * t_iter
@@ -101,20 +113,10 @@ def cpu_baseline(n_points, tgt, src, gpu_normals=None):
     a1, _ = timed(lambda: O.icp_point_to_plane_detailed(ss, ts, nrm1[:, 3:], None, 1, None, 0.0, threads=1), 0, 1)
     a3, _ = timed(lambda: O.icp_point_to_plane_detailed(ss, ts, nrm1[:, 3:], None, 3, None, 0.0, threads=1), 0, 1)
     it1 = max((a3 - a1) / 2.0, 1e-9)
-    # why "all threads" is not "threads x one thread": the container's CPU bandwidth quota (cgroup) and the scaling of the
-    # parallel section itself, measured on the 100k-point subset
-    quota = None
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if txt and txt[0] not in ("max", "-1"):
-                quota = float(txt[0]) / float(txt[1] if len(txt) > 1 else open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            break
-        except (OSError, ValueError):
-            continue
+    # scaling of the parallel section (k-NN + PCA per point), measured on the 100k-point subset
     scaling = {}
-    for th in (1, 8, 32, threads):
-        if th > threads or str(th) in scaling:
+    for th in (1, 4, threads, omp_max):
+        if str(th) in scaling:
             continue
         tt, _ = timed(lambda: O.estimate_normals(ts, K_NORMALS, threads=th), 0, 2)
         scaling[str(th)] = round(m / max(tt - t_tree1, 1e-9) / 1e6, 3)
@@ -128,9 +130,9 @@ def cpu_baseline(n_points, tgt, src, gpu_normals=None):
     return {
         "parity": parity, "oracle_normals": nrm,
         "value": ICP_ITERS / job, "unit": "ICP it/s (whole job: normals + 50 it)", "cores": threads, "kind": "port",
-        "sched_affinity_cpus": affinity, "omp_threads": threads, "cgroup_cpu_quota_cores": quota,
+        "sched_affinity_cpus": affinity, "omp_max_threads": omp_max, "cgroup_cpu_quota_cores": quota,
         "normals_query_mpts_per_s_by_threads_100k_subset": scaling,
-        "sample": f"oracle on the same {n_points}-pt pair, all threads: k={K_NORMALS} normals call median of 3 after 1 warm-up "
+        "sample": f"oracle on the same {n_points}-pt pair, {threads} threads (= the container's CPU quota; the box shows {affinity} CPUs): k={K_NORMALS} normals call median of 3 after 1 warm-up "
                   f"({t_norm:.2f} s, of which the single-threaded kd-tree build is {t_tree:.2f} s) + ICP: p2plane calls of 1 and 4 "
                   f"iterations, median of 3 each -> {t_iter:.3f} s per steady iteration, {t_build:.2f} s per-call setup (kd-tree "
                   f"build + first gather), extrapolated to {ICP_ITERS} iterations",

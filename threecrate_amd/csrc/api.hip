@@ -63,7 +63,7 @@ ProfScope::~ProfScope() {
 
 static void free_buf(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 static void free_index(DeviceIndex &ix) {
-    free_buf(ix.pts); free_buf(ix.cell_start); free_buf(ix.normals); free_buf(ix.cell_of);
+    free_buf(ix.pts); free_buf(ix.cell_start); free_buf(ix.normals); free_buf(ix.vor); free_buf(ix.cell_of);
     free_buf(ix.slot); free_buf(ix.arrival); free_buf(ix.fill); free_buf(ix.blocksum);
 }
 

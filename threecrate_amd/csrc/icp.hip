@@ -411,7 +411,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
-    double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov) {
+    double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov, const float *__restrict__ vor) {
     constexpr bool P2PLANE = MODE == 1;
     constexpr int NACC = MODE == 0 ? TC_ICP_SUMS_P2P : TC_ICP_SUMS_P2PLANE;
     if (st->done) return;
@@ -456,7 +456,14 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
             float best;
             uint32_t bestg;
             bool refine;
-            nn_search_pruned(tgt, x, y, z, ub2, best, bestg, refine, max_dist, spans);
+            // Inscribed-ball test (exact): vor[p] = a quarter of the squared distance from target point p to its nearest OTHER
+            // target point (shaved).  |T s - p| < d_nn(p) / 2 puts every other target point t at |T s - t| >= d_nn(p) - |T s - p|
+            // > |T s - p|: the previous match is still THE nearest neighbour and nothing has to be searched.  Once the clouds
+            // are aligned to within the point spacing this is every lane of almost every wave.
+            const float vr = (vor != nullptr && pj != 0xFFFFFFFFu) ? vor[pj] : 0.0f;
+            const bool keep = ub2p < vr;
+            if (__ballot(!keep) != 0ull) nn_search_pruned(tgt, x, y, z, keep ? -1.0f : ub2, best, bestg, refine, max_dist, spans);
+            if (keep) { best = ub2p; bestg = pj; refine = false; }
             const unsigned long long rmask = __ballot(refine);
             if (refine) {
                 // hand the refine pass the best real point seen so far: previous match or ring-1 best
@@ -810,6 +817,33 @@ __global__ void __launch_bounds__(kIcpBlock) icp_final_mse_kernel(GridView tgt, 
         acc[1] += 1.0;
     }
     block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * TC_ICP_SUMS_STRIDE, red);
+}
+
+// vor[p] = 0.25 * (1 - 1e-4) * min(|p - t|^2 over the other target records t of the 3x3x3 block, (0.996 h)^2): a LOWER bound of a
+// quarter of the squared distance to the nearest other target point (a record outside the block is at least one cell edge away
+// along some axis, also in a clamped grid: the boundary cells are part of the block when they are adjacent).  Squared distances
+// computed like every other one here (d2_nc: relative error 4 ulp at most, the subtraction of two floats is exact to half an
+// ulp of the DIFFERENCE), so the 1e-4 shave keeps the inscribed-ball test strict.  Duplicate points get 0: never skipped.
+__global__ void __launch_bounds__(256) icp_target_nn_bound_kernel(GridView tgt, float *__restrict__ vor, const IcpState *__restrict__ st) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const GridGeom &g = tgt.g;
+    if (p >= g.n || st->done) return;
+    const float4 q = tgt.pts[p];
+    const int cx = cell_coord(q.x, g.minx, g.inv_h, g.gx), cy = cell_coord(q.y, g.miny, g.inv_h, g.gy), cz = cell_coord(q.z, g.minz, g.inv_h, g.gz);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
+    const float hb = 0.996f * g.h;
+    float m = hb * hb;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.gz - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.gy - 1); ++y) {
+            const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
+            const uint32_t s = tgt.cell_start[row + x0], e = tgt.cell_start[row + x1 + 1];
+            for (uint32_t j = s; j < e; ++j) {
+                const float4 c = tgt.pts[j];
+                const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+                m = (j != p) ? fminf(m, v) : m;            // fminf ignores a NaN candidate
+            }
+        }
+    vor[p] = 0.25f * 0.9999f * m;
 }
 
 // ---- small f64 solvers (one lane) -----------------------------------------------------------
@@ -1182,7 +1216,8 @@ static TileGeom plan_tiles(const GridGeom &g, size_t ns) {
 // mode: 0 point-to-point, 1 point-to-plane (nrm = target normals), 2 GICP (nrm = target covariances, src_cov)
 static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, const float4 *nrm, const float4 *src,
                              uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr_pos, uint32_t *rlist,
-                             double *partials, bool do_sum, bool do_apply, bool do_reduce, const float4 *src_cov = nullptr) {
+                             double *partials, bool do_sum, bool do_apply, bool do_reduce, const float4 *src_cov = nullptr,
+                             const float *vor = nullptr) {
     hipStream_t s = ctx->stream;
     const int dbg = debug_flags();
     double *refine_rows = partials + (size_t)l.nblocks * TC_ICP_SUMS_STRIDE;
@@ -1190,7 +1225,8 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
         {
             ProfScope ps(ctx, mode == 1 ? "icp_correspond_reduce_p2plane" : mode == 2 ? "icp_correspond_reduce_gicp" : "icp_correspond_reduce_p2p", true);
             auto kern = mode == 1 ? icp_correspond_reduce_kernel<1> : mode == 2 ? icp_correspond_reduce_kernel<2> : icp_correspond_reduce_kernel<0>;
-            hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st, corr_pos, rlist, partials, dbg, src_cov);
+            hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st, corr_pos, rlist, partials, dbg, src_cov,
+                               (dbg & 4) ? nullptr : vor);
         }
         ProfScope ps(ctx, "icp_refine");
         auto kern = mode == 1 ? icp_refine_kernel<1> : mode == 2 ? icp_refine_kernel<2> : icp_refine_kernel<0>;
@@ -1203,6 +1239,19 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
         auto kern = mode == 0 ? icp_finalize_kernel<0> : icp_finalize_kernel<1>;
         hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0, (do_apply && !(dbg & 32)) ? 1 : 0);
     }
+}
+
+// The inscribed-ball bounds of the target (icp_target_nn_bound_kernel) cost about one iteration's main pass: they are computed
+// when a registration is still running after kVorAfter iterations (scan-to-scan odometry that converges in a handful of
+// iterations never pays for them).  Exact either way: with or without them every iteration finds the same matches.
+constexpr size_t kVorAfter = 6;
+static tc_status launch_target_nn_bounds(tc_context *ctx, DeviceIndex &ix, const GridView &tv, const IcpState *st, const float **out) {
+    *out = nullptr;
+    if (tc_status s = ensure(ctx, ix.vor, (size_t)ix.geom.n * sizeof(float))) return s;
+    ProfScope ps(ctx, "icp_target_nn_bounds");
+    hipLaunchKernelGGL(icp_target_nn_bound_kernel, dim3((ix.geom.n + 255) / 256), dim3(256), 0, ctx->stream, tv, (float *)ix.vor.p, st);
+    *out = (const float *)ix.vor.p;
+    return TC_OK;
 }
 
 // ~1.45 pts/cell.  Scanned again after the main / refine split (50-iteration ICP, 1 M points): 0.8 -> 6.55 ms, 0.9 -> 5.55,
@@ -1336,8 +1385,12 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     }
     const float4 *nrm = (const float4 *)ctx->tgt_index.normals.p;
 
-    if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() {
-            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov);
+    size_t enq = 0;
+    const float *vor = nullptr;
+    if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
+            if (enq++ == kVorAfter)
+                if (tc_status s = launch_target_nn_bounds(ctx, ctx->tgt_index, su.tv, dstate, &vor)) return s;
+            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor);
             return TC_OK;
         })) return s;
     if (mode == 0) {
@@ -1407,8 +1460,12 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     double *partials = (double *)ctx->partials.p;
     const float4 *src = (const float4 *)ctx->src_index.pts.p + lo;
     const float4 *nrm = (const float4 *)ctx->tgt_index.normals.p;
+    size_t enq = 0;
+    const float *vor = nullptr;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
-            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, true, false, true);
+            if (enq++ == kVorAfter)
+                if (tc_status s = launch_target_nn_bounds(ctx, ctx->tgt_index, su.tv, dstate, &vor)) return s;
+            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, true, false, true, nullptr, vor);
             if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, false, true, false);
             return TC_OK;
