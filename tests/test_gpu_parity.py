@@ -723,3 +723,49 @@ def test_normals_bit_identical_to_oracle(ctx, n, k, orient):
     assert same.mean() >= 0.9999
     a, b = g[~same, 3:6].astype(np.float64), r[~same, 3:6].astype(np.float64)
     assert len(a) == 0 or float((1.0 - (a * b).sum(1)).max()) <= 1e-6      # signed cosine: same orientation
+
+
+def test_non_finite_points_are_inert(ctx):
+    """NaN pixels of an organised depth image / infinite ranges.  The reference's kd-tree accepts such clouds without
+    panicking (its NaN comparisons place them arbitrarily and a NaN-distance entry may enter a heap that is not yet full); here
+    they are indexed in a bucket no search visits: the finite points get exactly the normals / neighbours / matches of the
+    cloud WITHOUT those points, the non-finite points themselves get the reference's NaN outcome -- the default normal
+    (0, 0, 1) (normals.rs:197-202), no neighbours, no correspondence."""
+    rng = np.random.default_rng(12)
+    clean = synth.uniform_cloud(30000, seed=21)
+    bad_rows = np.sort(rng.choice(len(clean) + 300, 300, replace=False))
+    pts = np.empty((len(clean) + 300, 3), np.float32)
+    mask = np.ones(len(pts), bool)
+    mask[bad_rows] = False
+    pts[mask] = clean
+    junk = clean[rng.integers(0, len(clean), 300)].copy()
+    junk[np.arange(300), rng.integers(0, 3, 300)] = np.where(rng.random(300) < 0.6, np.nan, np.where(rng.random(300) < 0.5, np.inf, -np.inf))
+    junk[:20] = np.nan                                                   # whole rows, and some near the box minimum
+    junk[20:40, 0] = clean[:, 0].min()
+    pts[bad_rows] = junk
+    for data in (pts, torch.from_numpy(pts).cuda()):
+        g = ctx.estimate_normals(data, 12)
+        g = g.cpu().numpy() if hasattr(g, "cpu") else g
+        ref = ctx.estimate_normals(clean, 12)
+        assert np.array_equal(g[mask], ref)                              # the finite points: bit for bit the clean cloud's normals
+        assert np.array_equal(g[~mask][:, :3], junk, equal_nan=True)     # positions copied through
+        assert np.array_equal(g[~mask][:, 3:], np.tile(np.array([0, 0, 1], np.float32), (300, 1)))
+    # k-NN export: finite queries see only finite points; a NaN query has no neighbours
+    q = np.concatenate([clean[:500], junk[:5]])
+    idx, dist, cnt = ctx.find_k_nearest_batch(pts, q, 8)
+    ridx, rdist, rcnt = ctx.find_k_nearest_batch(clean, clean[:500], 8)
+    remap = np.nonzero(mask)[0]
+    assert np.array_equal(cnt[:500], rcnt) and np.array_equal(dist[:500], rdist) and np.array_equal(idx[:500], remap[ridx])
+    assert (cnt[500:] == 0).all()
+    # ICP: non-finite source points have no correspondence, non-finite target points are never matched
+    src_clean, tgt_clean, T = synth.registration_pair(30000, seed=21)
+    src = np.empty_like(pts); src[mask] = src_clean; src[bad_rows] = junk
+    tgt = pts.copy(); tgt[mask] = tgt_clean
+    a = ctx.icp_detailed(src, tgt, None, 10, None, 0.0)
+    b = ctx.icp_detailed(src_clean, tgt_clean, None, 10, None, 0.0)
+    assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse
+    assert np.array_equal(a.correspondences, np.stack([remap[b.correspondences[:, 0]], remap[b.correspondences[:, 1]]], axis=1))
+    nrm = ctx.estimate_normals(tgt, 12)
+    a = ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, 10, None, 0.0)
+    b = ctx.icp_point_to_plane_detailed(src_clean, tgt_clean, nrm[mask], None, 10, None, 0.0)
+    assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse

@@ -104,7 +104,7 @@ static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, c
         const float extent = std::sqrt(ex * ex + ey * ey + ez * ez);
         vp[0] = cx + 0.0f; vp[1] = cy + 0.0f; vp[2] = cz + extent;
     }
-    return launch_normals(ctx, ctx->tgt_index, *cfg, vp, d_out, p_begin, p_end, slice_out);
+    return launch_normals(ctx, ctx->tgt_index, d_xyz, *cfg, vp, d_out, p_begin, p_end, slice_out);
 }
 
 }  // namespace tc

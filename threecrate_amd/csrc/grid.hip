@@ -48,7 +48,9 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
     // each thread reads whole points; consecutive lanes read consecutive 12-B records
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);   // fminf ignores NaN
+        // a point with a NaN or infinite coordinate takes no part in the box (it is indexed in the bucket behind the last cell)
+        if (!(fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f)) continue;
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
         mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
         if (sbox && ((i * 2654435761u) >> 28) == 0u) {
             smn[0] = fminf(smn[0], x); smn[1] = fminf(smn[1], y); smn[2] = fminf(smn[2], z);
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
 // cell id per point (+ histogram).  With `st` != null the point is first moved by the
 // isometry in *st (ICP source ordering by target cell); the stored record keeps the raw point.
 __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g,
-                                                       const IcpState *__restrict__ st, TileGeom tg, int tile_major,
+                                                       const IcpState *__restrict__ st, TileGeom tg, int tile_major, uint32_t nkeys,
                                                        uint32_t *__restrict__ cell_of, uint32_t *__restrict__ hist,
                                                        uint32_t *__restrict__ arrival, uint32_t *__restrict__ pts_pad,
                                                        uint32_t *__restrict__ cs_front, uint32_t *__restrict__ cs_tail) {
@@ -124,6 +126,10 @@ __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict_
     int iy = cell_coord(y, g.miny, g.inv_h, g.gy);
     int iz = cell_coord(z, g.minz, g.inv_h, g.gz);
     uint32_t c = tile_major ? tile_major_id(tg, ix, iy, iz) : ((uint32_t)iz * g.gy + iy) * g.gx + ix;
+    // Non-finite points (NaN pixels of an organised depth image, inf ranges) live in ONE extra bucket behind the last cell:
+    // no neighbour search ever visits it (a scan ends at cell_start[ncell]), so they are inert as candidates, and their
+    // records hold huge finite coordinates (rank_gather_kernel) -- harmless when a 4-wide step reads past its span.
+    if (!(fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f)) c = nkeys;
     cell_of[i] = c;
     // the returned count is this point's arrival rank inside its cell: the scatter pass then needs
     // no second round of atomics
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(256) scatter_kernel(const uint32_t *__restrict
 }
 
 // stable re-rank inside the cell (ascending original index) + gather into the sorted record array
-__global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restrict__ xyz, uint32_t n,
+__global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restrict__ xyz, uint32_t n, uint32_t nkeys,
                                                          const uint32_t *__restrict__ cell_of,
                                                          const uint32_t *__restrict__ cell_start,
                                                          const uint32_t *__restrict__ slot,
@@ -254,6 +260,7 @@ __global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restric
     }
     float4 r;
     r.x = xyz[3 * (size_t)i]; r.y = xyz[3 * (size_t)i + 1]; r.z = xyz[3 * (size_t)i + 2];
+    if (c == nkeys) r.x = r.y = r.z = __uint_as_float(0x7F7F7F7Fu);     // the non-finite bucket: d2 to anything = +inf, never selected
     r.w = __uint_as_float(i);
     pts[s + rank] = r;
 }
@@ -442,26 +449,27 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         if (tc_status s = ensure(ctx, ix.cell_of, n * sizeof(uint32_t))) return s;
         if (tc_status s = ensure(ctx, ix.slot, n * sizeof(uint32_t))) return s;
         if (tc_status s = ensure(ctx, ix.arrival, n * sizeof(uint32_t))) return s;
-        if (tc_status s = ensure(ctx, ix.fill, (size_t)nkeys * sizeof(uint32_t))) return s;
-        if (tc_status s = ensure(ctx, ix.cell_start, (kCellStartFront + (size_t)nkeys + 1 + kCellStartPad) * sizeof(uint32_t))) return s;
+        // nkeys cells + the bucket of the non-finite points behind them
+        if (tc_status s = ensure(ctx, ix.fill, ((size_t)nkeys + 1) * sizeof(uint32_t))) return s;
+        if (tc_status s = ensure(ctx, ix.cell_start, (kCellStartFront + (size_t)nkeys + 2 + kCellStartPad) * sizeof(uint32_t))) return s;
         uint32_t *const cs = (uint32_t *)ix.cell_start.p + kCellStartFront;       // zeros in front (the ICP window of cell 0 starts at -1)
 
-        TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, (size_t)nkeys * sizeof(uint32_t), st));
+        TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st));
         // records past the end: huge finite coordinates -> d2 = +inf, never a match (kernels may read, never select them)
         {
             ProfScope ps(ctx, "cell_hist");
-            hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0,
+            hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0, nkeys,
                                (uint32_t *)ix.cell_of.p, (uint32_t *)ix.fill.p, (uint32_t *)ix.arrival.p,
-                               reinterpret_cast<uint32_t *>((float4 *)ix.pts.p + n), (uint32_t *)ix.cell_start.p, cs + nkeys + 1);
+                               reinterpret_cast<uint32_t *>((float4 *)ix.pts.p + n), (uint32_t *)ix.cell_start.p, cs + nkeys + 2);
         }
         {
             ProfScope ps(ctx, "cell_scan");
-            if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, nkeys, cs, ix.blocksum)) return s;
+            if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, nkeys + 1, cs, ix.blocksum)) return s;
         }
         const bool check = adapt && attempt < 3;
         uint32_t *h_occ = (uint32_t *)((char *)ctx->pinned + 2048 + 8192);
         if (check) {
-            const uint32_t nscan = (nkeys + kScanTile - 1) / kScanTile;
+            const uint32_t nscan = (nkeys + 1 + kScanTile - 1) / kScanTile;
             TC_HIP_TRY(ctx, hipMemcpyAsync(h_occ, (const uint32_t *)ix.blocksum.p + 2 * nscan, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         }
         {
@@ -471,7 +479,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         }
         {
             ProfScope ps(ctx, "cell_rank_gather");
-            hipLaunchKernelGGL(rank_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, (const uint32_t *)ix.cell_of.p,
+            hipLaunchKernelGGL(rank_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, nkeys, (const uint32_t *)ix.cell_of.p,
                                (const uint32_t *)cs, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p);
         }
         TC_HIP_TRY(ctx, hipGetLastError());

@@ -407,8 +407,10 @@ constexpr int kRefineBlocks = 256;          // blocks of the refine pass = rows 
 
 // MODE: 0 point-to-point, 1 point-to-plane (tgt_nrm = target normals in cell order), 2 GICP (tgt_nrm = target
 // covariances, two float4 per cell-sorted position; src_cov = source covariances in the source's sorted order)
+// 4 waves per SIMD = the launch geometry (one round of 1024 blocks of 4 waves on 1024 SIMDs): the register allocator may use up
+// to 128 VGPRs and must not use more (a 3-wave kernel needs a second round of blocks: +20-40 %)
 template <int MODE>
-__global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
+__global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
     double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov, const float *__restrict__ vor) {
@@ -437,33 +439,66 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
     const uint32_t beg = lb * chunk;
     const uint32_t end = min(beg + chunk, ns);
     for (uint32_t gb = beg; gb < end; gb += kIcpGroup * kIcpBlock) {
-        // ---- phase S ----
-        uint32_t ok = 0;
-#pragma unroll 1
+        // A group = kIcpGroup points per lane, in four stages.  The converged phase of a registration is LATENCY bound (a kept
+        // match needs ~150 instructions and three dependent memory round trips), so the loads of the group's points go out
+        // together: stage 1 the source records + previous matches, stage 2 the matched target records + their inscribed-ball
+        // bounds, stage 4 the final records + normals; only stage 3, the search of the lanes that need one, runs point by point.
+        float px[kIcpGroup], py[kIcpGroup], pz[kIcpGroup], ubp[kIcpGroup];
+        uint32_t pjv[kIcpGroup], mv[kIcpGroup];
+        bool fin[kIcpGroup];
+        {   // ---- stage 1 + 2 ----
+            float4 sv[kIcpGroup];
+#pragma unroll
+            for (int u = 0; u < kIcpGroup; ++u) {
+                const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
+                const bool in = j < end;
+                sv[u] = src[in ? j : beg];
+                uint32_t pj = corr_pos[in ? j : beg];          // (allocated but meaningless before iteration 1)
+                if (!warm || !in) pj = 0xFFFFFFFFu;
+                pjv[u] = pj;
+                fin[u] = in && sv[u].x < 3.0e38f;              // a non-finite source point (placeholder record, grid.hip) has no match
+            }
+            float4 pv[kIcpGroup];
+            float vrv[kIcpGroup];
+#pragma unroll
+            for (int u = 0; u < kIcpGroup; ++u) {
+                pv[u] = tgt.pts[pjv[u] != 0xFFFFFFFFu ? pjv[u] : 0u];
+                vrv[u] = (vor != nullptr && pjv[u] != 0xFFFFFFFFu) ? vor[pjv[u]] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kIcpGroup; ++u) {
+                iso_apply(q, t, sv[u].x, sv[u].y, sv[u].z, px[u], py[u], pz[u]);
+                // warm start: the previous match is a real target point, its distance bounds the new nearest-neighbour distance
+                const float d = pjv[u] != 0xFFFFFFFFu ? d2_nc(pv[u].x, pv[u].y, pv[u].z, px[u], py[u], pz[u]) : INFINITY;
+                // Inscribed-ball test (exact): vor[p] = a quarter of the squared distance from target point p to its nearest OTHER
+                // target point (shaved).  |T s - p| < d_nn(p) / 2 puts every other target point t at |T s - t| >= d_nn(p) - |T s - p|
+                // > |T s - p|: the previous match is still THE nearest neighbour, nothing has to be searched.  The flag travels
+                // in the sign bit of the (non-negative) bound.
+                ubp[u] = (d < vrv[u]) ? -d : d;
+            }
+        }
+        // ---- stage 3 ----
+#pragma unroll
         for (int u = 0; u < kIcpGroup; ++u) {
             const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
-            if (j >= end) break;
-            const float4 s = src[j];
-            float x, y, z;
-            iso_apply(q, t, s.x, s.y, s.z, x, y, z);
-            // branch-free warm start (corr_pos is allocated but meaningless before iteration 1)
-            uint32_t pj = corr_pos[j];
-            if (!warm) pj = 0xFFFFFFFFu;
-            const float4 p = tgt.pts[pj != 0xFFFFFFFFu ? pj : 0u];
-            const float ub2p = pj != 0xFFFFFFFFu ? d2_nc(p.x, p.y, p.z, x, y, z) : INFINITY;
+            const bool in = fin[u];
+            const float x = px[u], y = py[u], z = pz[u];
+            const uint32_t pj = pjv[u];
+            const bool keep = __float_as_uint(ubp[u]) >> 31;             // (-0.0 too: an exact hit on a non-duplicate point)
+            const float ub2p = fabsf(ubp[u]);
             float ub2 = ub2p;
             if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f);   // farther matches are rejected anyway
-            float best;
-            uint32_t bestg;
-            bool refine;
-            // Inscribed-ball test (exact): vor[p] = a quarter of the squared distance from target point p to its nearest OTHER
-            // target point (shaved).  |T s - p| < d_nn(p) / 2 puts every other target point t at |T s - t| >= d_nn(p) - |T s - p|
-            // > |T s - p|: the previous match is still THE nearest neighbour and nothing has to be searched.  Once the clouds
-            // are aligned to within the point spacing this is every lane of almost every wave.
-            const float vr = (vor != nullptr && pj != 0xFFFFFFFFu) ? vor[pj] : 0.0f;
-            const bool keep = ub2p < vr;
-            if (__ballot(!keep) != 0ull) nn_search_pruned(tgt, x, y, z, keep ? -1.0f : ub2, best, bestg, refine, max_dist, spans);
-            if (keep) { best = ub2p; bestg = pj; refine = false; }
+            float best = INFINITY;
+            uint32_t bestg = 0xFFFFFFFFu;
+            bool refine = false;
+            if (__ballot(in && !keep) != 0ull) nn_search_pruned(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans);
+            if (keep) { best = ub2p; bestg = pj; }
+            refine = refine && in && !keep;
+            if ((dbg & 8) && lane == 0) {          // statistics: wave trips / trips without a search
+                IcpState *sw = const_cast<IcpState *>(st);
+                atomicAdd(&sw->refine_ring_hist[5], 1u);
+                if (__ballot(in && !keep) == 0ull) atomicAdd(&sw->refine_ring_hist[6], 1u);
+            }
             const unsigned long long rmask = __ballot(refine);
             if (refine) {
                 // hand the refine pass the best real point seen so far: previous match or ring-1 best
@@ -474,35 +509,37 @@ __global__ void __launch_bounds__(kIcpBlock) icp_correspond_reduce_kernel(
                 wseg[wcnt + __popcll(rmask & ((1ull << lane) - 1ull))] = make_uint2(j, km != ~0ull ? (uint32_t)km : 0xFFFFFFFFu);
             }
             wcnt += __popcll(rmask);
-            if (refine) continue;
-            bool valid = bestg != 0xFFFFFFFFu;
+            bool valid = in && !refine && bestg != 0xFFFFFFFFu;
             if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
-            corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
-            if (valid) ok |= 1u << u;
+            const uint32_t newv = valid ? bestg : 0xFFFFFFFFu;
+            if (j < end && !refine && (!warm || newv != pj)) corr_pos[j] = newv;     // an unchanged match is not written again
+            mv[u] = (dbg & 16) ? 0xFFFFFFFFu : newv;                             // dbg & 16: timing experiments only (no sums)
         }
-        wcnt = __builtin_amdgcn_readfirstlane(wcnt);       // lanes past the chunk's end left the loop early
-        // ---- phase A ----
+        // ---- stage 4 ----: per-pair terms of the group -> per-lane f32 sums -> the wave's f64 row
         float acc[NACC];
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
-#pragma unroll 1
-        for (int u = 0; u < kIcpGroup; ++u) {
-            if (!((ok >> u) & 1u)) continue;
-            const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
-            const float4 sv = src[j];
-            const uint32_t pj = corr_pos[j];                 // this lane's own store of phase S
-            const float4 cv = tgt.pts[pj];
-            float x, y, z;
-            iso_apply(q, t, sv.x, sv.y, sv.z, x, y, z);
-            if constexpr (MODE == 2) {
-                float R[9];
-                quat_to_rot(q, R);
-                accumulate_gicp(acc, x, y, z, cv, d2_nc(cv.x, cv.y, cv.z, x, y, z), R, src_cov[2 * (size_t)j], src_cov[2 * (size_t)j + 1],
-                                tgt_nrm[2 * (size_t)pj], tgt_nrm[2 * (size_t)pj + 1]);
-            } else {
-                float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (P2PLANE) nv = tgt_nrm[pj];
-                accumulate_pair<P2PLANE, NACC>(g, acc, x, y, z, cv, nv);
+        {
+            float4 cv[kIcpGroup], nv[kIcpGroup];
+#pragma unroll
+            for (int u = 0; u < kIcpGroup; ++u) {
+                const uint32_t m = mv[u] != 0xFFFFFFFFu ? mv[u] : 0u;
+                cv[u] = tgt.pts[m];
+                nv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MODE == 1) nv[u] = tgt_nrm[m];
+            }
+#pragma unroll
+            for (int u = 0; u < kIcpGroup; ++u) {
+                if (mv[u] == 0xFFFFFFFFu) continue;
+                if constexpr (MODE == 2) {
+                    const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
+                    float R[9];
+                    quat_to_rot(q, R);
+                    accumulate_gicp(acc, px[u], py[u], pz[u], cv[u], d2_nc(cv[u].x, cv[u].y, cv[u].z, px[u], py[u], pz[u]), R, src_cov[2 * (size_t)j],
+                                    src_cov[2 * (size_t)j + 1], tgt_nrm[2 * (size_t)mv[u]], tgt_nrm[2 * (size_t)mv[u] + 1]);
+                } else {
+                    accumulate_pair<P2PLANE, NACC>(g, acc, px[u], py[u], pz[u], cv[u], nv[u]);
+                }
             }
         }
         // per-group fold: transposing wave reduction (f32, fixed tree) -> this wave's f64 row
@@ -1242,9 +1279,12 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
 }
 
 // The inscribed-ball bounds of the target (icp_target_nn_bound_kernel) cost about one iteration's main pass: they are computed
-// when a registration is still running after kVorAfter iterations (scan-to-scan odometry that converges in a handful of
+// when a registration is still running after 6 iterations (TC_VOR_AFTER overrides, for experiments) (scan-to-scan odometry that converges in a handful of
 // iterations never pays for them).  Exact either way: with or without them every iteration finds the same matches.
-constexpr size_t kVorAfter = 6;
+static size_t vor_after() {
+    static const size_t v = [] { const char *e = getenv("TC_VOR_AFTER"); return e ? (size_t)atoi(e) : (size_t)6; }();
+    return v;
+}
 static tc_status launch_target_nn_bounds(tc_context *ctx, DeviceIndex &ix, const GridView &tv, const IcpState *st, const float **out) {
     *out = nullptr;
     if (tc_status s = ensure(ctx, ix.vor, (size_t)ix.geom.n * sizeof(float))) return s;
@@ -1388,7 +1428,7 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     size_t enq = 0;
     const float *vor = nullptr;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
-            if (enq++ == kVorAfter)
+            if (enq++ == vor_after())
                 if (tc_status s = launch_target_nn_bounds(ctx, ctx->tgt_index, su.tv, dstate, &vor)) return s;
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor);
             return TC_OK;
@@ -1463,7 +1503,7 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     size_t enq = 0;
     const float *vor = nullptr;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
-            if (enq++ == kVorAfter)
+            if (enq++ == vor_after())
                 if (tc_status s = launch_target_nn_bounds(ctx, ctx->tgt_index, su.tv, dstate, &vor)) return s;
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, true, false, true, nullptr, vor);
             if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;

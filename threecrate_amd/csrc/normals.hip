@@ -42,6 +42,7 @@ struct NormalParams {
     int      R0;            // ring count of the main launch
     int      has_radius;
     float    radius;
+    const float *xyz;       // the caller's AoS input (positions of non-finite points are copied from here)
     uint32_t p_begin, p_end;    // cell-sorted positions handled by this launch (a multi-GPU shard: SURVEY 8e)
     int      slice_out;         // 1: record of position p goes to row p - p_begin (sorted order) instead of its original index
 };
@@ -417,6 +418,16 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     const float4 q = gv.pts[p];
     const uint32_t orig = __float_as_uint(q.w);
     const uint32_t K1 = prm.k + 1;
+    if (p >= gv.cell_start[g.ncell]) {
+        // A point with a NaN / infinite coordinate (the bucket behind the last cell; its record holds placeholder coordinates).
+        // The reference's PCA of such a neighbourhood is NaN throughout: `norm > 1e-6` is false -> the default normal (0, 0, 1)
+        // (normals.rs:197-202), and the orientation test `dot < 0` is false for NaN (:216).  Finite points never see these
+        // points as neighbours here (the reference's kd-tree places them wherever its NaN comparisons fall).
+        float *o = out6 + 6 * (size_t)(prm.slice_out ? p - prm.p_begin : orig);
+        o[0] = prm.xyz[3 * (size_t)orig]; o[1] = prm.xyz[3 * (size_t)orig + 1]; o[2] = prm.xyz[3 * (size_t)orig + 2];
+        o[3] = 0.0f; o[4] = 0.0f; o[5] = 1.0f;
+        return;
+    }
     const int cx = cell_coord(q.x, g.minx, g.inv_h, g.gx);
     const int cy = cell_coord(q.y, g.miny, g.inv_h, g.gy);
     const int cz = cell_coord(q.z, g.minz, g.inv_h, g.gz);
@@ -630,6 +641,9 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
     const GridGeom &g = gv.g;
     float4 q;
     q.x = queries[3 * (size_t)t]; q.y = queries[3 * (size_t)t + 1]; q.z = queries[3 * (size_t)t + 2]; q.w = 0.0f;
+    // a NaN / infinite query has no finite distance to anything: no neighbours (the reference's kd-tree returns whatever nodes
+    // its NaN comparisons visit first, with NaN distances)
+    if (!(fabsf(q.x) <= 3.0e38f && fabsf(q.y) <= 3.0e38f && fabsf(q.z) <= 3.0e38f)) { out_count[t] = 0; return; }
     const float qx = fminf(fmaxf(q.x, g.minx), g.maxx), qy = fminf(fmaxf(q.y, g.miny), g.maxy), qz = fminf(fmaxf(q.z, g.minz), g.maxz);
     const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx), cy = cell_coord(qy, g.miny, g.inv_h, g.gy), cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
     const float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy, fz = (qz - g.minz) * g.inv_h - (float)cz;
@@ -637,7 +651,8 @@ __global__ void __launch_bounds__(BLOCK) knn_kernel(GridView gv, const float *__
     const float ex = q.x - qx, ey = q.y - qy, ez = q.z - qz;
     // |p - q|^2 >= |p - q'|^2 + |q - q'|^2 needs every record inside the box: not so when the box is clamped
     const float out2 = EXT ? 0.0f : (ex * ex + ey * ey + ez * ez) * 0.9999f;
-    const uint32_t K1 = min(k, g.n);
+    const uint32_t K1 = min(k, gv.cell_start[g.ncell]);      // the finite points
+    if (K1 == 0) { out_count[t] = 0; return; }
     float d[L];
 #pragma unroll
     for (int i = 0; i < L; ++i) d[i] = INFINITY;
@@ -716,6 +731,7 @@ __global__ void __launch_bounds__(128) radius_all_kernel(GridView gv, const floa
     const GridGeom &g = gv.g;
     float4 q;
     q.x = queries[3 * (size_t)t]; q.y = queries[3 * (size_t)t + 1]; q.z = queries[3 * (size_t)t + 2]; q.w = 0.0f;
+    if (!(fabsf(q.x) <= 3.0e38f && fabsf(q.y) <= 3.0e38f && fabsf(q.z) <= 3.0e38f)) { if (!FILL) counts[t] = 0; return; }
     const float qx = fminf(fmaxf(q.x, g.minx), g.maxx), qy = fminf(fmaxf(q.y, g.miny), g.maxy), qz = fminf(fmaxf(q.z, g.minz), g.maxz);
     const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx), cy = cell_coord(qy, g.miny, g.inv_h, g.gy), cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
     const float r2 = radius * radius;                                                 // nearest_neighbor.rs:259
@@ -792,7 +808,7 @@ tc_status launch_normals_unsort(tc_context *ctx, const DeviceIndex &ix, const fl
     return TC_OK;
 }
 
-tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg, const float vp[3],
+tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_xyz, const tc_normal_config &cfg, const float vp[3],
                          float *d_out6, size_t p_begin, size_t p_end, bool slice_out) {
     if (cfg.k_neighbors + 1 > 129) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 128 is not supported by the HIP backend");
     NormalParams prm;
@@ -802,6 +818,7 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal
     prm.R0 = 2;
     prm.has_radius = (cfg.has_radius && cfg.radius > 0.0f) ? 1 : 0;
     prm.radius = prm.has_radius ? cfg.radius : 0.0f;
+    prm.xyz = d_xyz;
     prm.p_begin = (uint32_t)p_begin;
     prm.p_end = (uint32_t)std::min<size_t>(p_end, ix.geom.n);
     prm.slice_out = slice_out ? 1 : 0;

@@ -200,7 +200,7 @@ tc_status voxel_filter_device(tc_context *ctx, const float *d_xyz, size_t n, flo
 tc_status range_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float min_range, float max_range, float *d_out, size_t *n_out);
 
 // normals.hip
-tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const tc_normal_config &cfg,
+tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_xyz, const tc_normal_config &cfg,
                          const float vp[3], float *d_out6, size_t p_begin = 0, size_t p_end = (size_t)-1, bool slice_out = false);
 tc_status launch_radius_all(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, float radius, uint32_t *d_counts,
                             const unsigned long long *d_offsets, uint32_t *d_idx, float *d_dist);
