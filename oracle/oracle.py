@@ -74,6 +74,8 @@ def lib():
         L.tco_kiss_adaptive_threshold.restype = C.c_float
         L.tco_kiss_icp.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, f32p, C.c_float, C.c_float, C.c_float, C.c_size_t,
                                    C.POINTER(_IcpResult), C.POINTER(C.c_size_t), C.c_int]
+        L.tco_set_voxel_order_seed.argtypes = [C.c_uint64]
+        L.tco_set_voxel_order_seed.restype = None
         L.tco_p2plane_partial.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_void_p, f32p, f32p, f32p, C.c_float, f64p, u32p]
         L.tco_p2p_partial.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_void_p, f32p, f32p, C.c_float, f64p, u32p]
         L.tco_symmetric_eigen3.argtypes = [f32p, f32p, f32p]
@@ -253,7 +255,7 @@ def gicp_covariances(points, k=20, threads=0):
     return out.reshape(-1, 3, 3)
 
 
-def kiss_icp(src, tgt, init=None, voxel_size=1.0, max_range=100.0, min_range=0.5, max_iterations=50, threads=0):
+def kiss_icp(src, tgt, init=None, voxel_size=1.0, max_range=100.0, min_range=0.5, max_iterations=50, threads=0, voxel_order_seed=0):
     """kiss_icp.rs:183-300 (KissIcpConfig defaults :40-49); correspondences index the voxel-downsampled source.
     Returns (IcpResult, number of downsampled source points)."""
     s, t = _f32(src, 3), _f32(tgt, 3)
@@ -264,8 +266,12 @@ def kiss_icp(src, tgt, init=None, voxel_size=1.0, max_range=100.0, min_range=0.5
     r.corr_tgt = _p(ct, C.c_uint64)
     i7 = _f32(IDENTITY if init is None else init).reshape(7)
     nd = C.c_size_t(0)
-    rc = lib().tco_kiss_icp(_p(s), len(s), _p(t), len(t), _p(i7), voxel_size, max_range, min_range, max_iterations,
-                            C.byref(r), C.byref(nd), threads)
+    lib().tco_set_voxel_order_seed(int(voxel_order_seed))      # the reference's HashMap order is unspecified: see tc_oracle.c
+    try:
+        rc = lib().tco_kiss_icp(_p(s), len(s), _p(t), len(t), _p(i7), voxel_size, max_range, min_range, max_iterations,
+                                C.byref(r), C.byref(nd), threads)
+    finally:
+        lib().tco_set_voxel_order_seed(0)
     if rc:
         raise OracleError(rc)
     return IcpResult(r, len(s), cs, ct), int(nd.value)

@@ -1441,6 +1441,13 @@ float tco_kiss_adaptive_threshold(const float init[7], float voxel_size) {      
     return fminf(fmaxf(3.0f * motion, 3.0f * voxel_size), 10.0f * voxel_size);
 }
 
+/* The reference's voxel_grid_filter emits its voxels in HashMap iteration order (filtering.rs:120-130), which Rust randomises
+ * per process: kiss_icp's sequential f32 sums over the down-sampled source therefore run in an UNSPECIFIED order.  The oracle
+ * emits voxels sorted by key; a non-zero seed applies a deterministic shuffle to the down-sampled source instead, so that
+ * tests can measure how far the reference's own result moves with that order (tests/test_gpu_parity.py). */
+static uint64_t g_voxel_order_seed = 0;
+void tco_set_voxel_order_seed(uint64_t seed) { g_voxel_order_seed = seed; }
+
 int tco_kiss_icp(const float *src, size_t ns, const float *tgt, size_t nt, const float init[7],
                  float voxel_size, float max_range, float min_range, size_t max_iters,
                  tco_icp_result *res, size_t *n_source_down, int threads) {
@@ -1462,6 +1469,15 @@ int tco_kiss_icp(const float *src, size_t ns, const float *tgt, size_t nt, const
     free(ranged);
     if (vrc != TCO_OK || nd == 0) { free(down); return TCO_INVALID_DATA; }
     if (n_source_down) *n_source_down = nd;
+    if (g_voxel_order_seed) {                                /* Fisher-Yates over the voxels, SplitMix64 */
+        uint64_t z = g_voxel_order_seed;
+        for (size_t i = nd - 1; i > 0; --i) {
+            z += 0x9E3779B97F4A7C15ull;
+            uint64_t r = z; r = (r ^ (r >> 30)) * 0xBF58476D1CE4E5B9ull; r = (r ^ (r >> 27)) * 0x94D049BB133111EBull; r ^= r >> 31;
+            size_t k = (size_t)(r % (i + 1));
+            float t3[3]; memcpy(t3, &down[3 * i], 12); memcpy(&down[3 * i], &down[3 * k], 12); memcpy(&down[3 * k], t3, 12);
+        }
+    }
     float sigma = tco_kiss_adaptive_threshold(init, voxel_size);
     tco_kdtree *tree = tco_kdtree_new(tgt, nt);
     float cur[7]; memcpy(cur, init, sizeof(cur));

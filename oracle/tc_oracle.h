@@ -127,6 +127,10 @@ int tco_kiss_icp(const float *src, size_t ns, const float *tgt, size_t nt, const
                  float voxel_size, float max_range, float min_range, size_t max_iters,
                  tco_icp_result *res, size_t *n_source_down, int threads);
 
+/* 0 (default): voxels of the down-sampled source in key order; otherwise a deterministic shuffle standing in for the reference's
+   unspecified HashMap order (filtering.rs:120-130) */
+void tco_set_voxel_order_seed(uint64_t seed);
+
 /* GICP (threecrate-algorithms/src/gicp.rs:100-305); cov9 = n x 9 row-major 3x3 covariances (:52-86) */
 void tco_gicp_covariances(const float *xyz, size_t n, size_t k, float *cov9, int threads);
 int tco_gicp(const float *src, size_t ns, const float *tgt, size_t nt, const float init[7],
