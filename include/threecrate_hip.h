@@ -181,6 +181,35 @@ tc_status tc_icp_point_to_plane_detailed_device(tc_context *ctx, const float *d_
                           float max_correspondence_distance, float convergence_threshold,
                           tc_icp_result *result);
 
+/* ---- device-resident cloud handles ("tc_cloud_upload -> handle, so frames can stay on the GPU") ----
+ * The reference passes &PointCloud<Point3f> and rebuilds its KdTree inside every call (normals.rs:272, registration.rs:281,
+ * :536).  A tc_cloud owns a device copy of the points and is indexed ONCE: tc_cloud_estimate_normals leaves the cell-sorted
+ * records AND the cell-sorted normals in the handle -- the layout the ICP kernels read -- so the registration of the next frame
+ * against it needs no second index build and no normals gather.  Same answers as the handle-free entry points (the cell edge
+ * of the shared grid changes speed, never results).
+ *   tc_cloud_estimate_normals[_device](c, cfg, out): estimate_normals_with_config (normals.rs:257-357); out (n x 6
+ *       NormalPoint3f, host / device) may be NULL when only the handle needs them (the 24-byte scattered stores are skipped).
+ *   tc_cloud_set_normals_device: normals computed elsewhere (n x 3 with stride 3, or &NormalPoint3f[0].normal with stride 6).
+ *   tc_cloud_icp_point_to_plane(source, target, ...): icp_point_to_plane_detailed (registration.rs:508-602) with the target's
+ *       normals; a target without normals -> TC_INVALID_DATA (the reference's length check, :522-526).
+ *   tc_cloud_icp_detailed(source, target, ...): icp_detailed (registration.rs:258-370).
+ *   result->corr_target, when given, is DEVICE memory (n_source entries).  max_correspondence_distance < 0: None.
+ * Handles belong to their context (same thread rule); destroy them before the context. */
+typedef struct tc_cloud tc_cloud;
+tc_status    tc_cloud_upload(tc_context *ctx, const float *xyz, size_t n, tc_cloud **out);            /* host -> HBM */
+tc_status    tc_cloud_upload_device(tc_context *ctx, const float *d_xyz, size_t n, tc_cloud **out);   /* HBM -> HBM copy */
+size_t       tc_cloud_size(const tc_cloud *cloud);
+const float *tc_cloud_points_device(const tc_cloud *cloud);      /* n x 3, device */
+const float *tc_cloud_normals_device(const tc_cloud *cloud);     /* n x 6 NormalPoint3f in input order, or NULL if not kept */
+tc_status    tc_cloud_estimate_normals(tc_cloud *cloud, const tc_normal_config *config, float *out_normal_points);
+tc_status    tc_cloud_estimate_normals_device(tc_cloud *cloud, const tc_normal_config *config, float *d_out_normal_points);
+tc_status    tc_cloud_set_normals_device(tc_cloud *cloud, const float *d_normals, size_t n_normals, size_t normal_stride);
+tc_status    tc_cloud_icp_point_to_plane(tc_cloud *source, tc_cloud *target, const float init[7], size_t max_iters,
+                                         float max_correspondence_distance, float convergence_threshold, tc_icp_result *result);
+tc_status    tc_cloud_icp_detailed(tc_cloud *source, tc_cloud *target, const float init[7], size_t max_iters,
+                                   float max_correspondence_distance, float convergence_threshold, tc_icp_result *result);
+void         tc_cloud_destroy(tc_cloud *cloud);
+
 /* gpu_batch_icp(&GpuContext, &[BatchICPJob]) (threecrate-gpu/src/icp.rs:997-1002, 151-185):
  * job i runs on ctxs[i % n_ctx]; jobs on different contexts (GPUs) run concurrently. */
 tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp_job *jobs,

@@ -74,6 +74,8 @@ def lib():
         L.tco_kiss_adaptive_threshold.restype = C.c_float
         L.tco_kiss_icp.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, f32p, C.c_float, C.c_float, C.c_float, C.c_size_t,
                                    C.POINTER(_IcpResult), C.POINTER(C.c_size_t), C.c_int]
+        L.tco_set_exact_sums.argtypes = [C.c_int]
+        L.tco_set_exact_sums.restype = None
         L.tco_set_voxel_order_seed.argtypes = [C.c_uint64]
         L.tco_set_voxel_order_seed.restype = None
         L.tco_p2plane_partial.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_void_p, f32p, f32p, f32p, C.c_float, f64p, u32p]
@@ -227,12 +229,17 @@ def icp(src, tgt, init, max_iters, threads=0):
 
 
 def icp_point_to_plane_detailed(src, tgt, tgt_normals, init, max_iters, max_correspondence_distance=None,
-                                convergence_threshold=1e-6, threads=0):
-    """registration.rs:508-602"""
+                                convergence_threshold=1e-6, threads=0, exact_sums=False):
+    """registration.rs:508-602.  exact_sums (diagnostic): the 6x6 system's per-pair f32 terms are added in f64 instead of the
+    reference's sequential f32 (tc_oracle.c, tco_set_exact_sums)."""
     n = _f32(tgt_normals, 3)
     md = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance)
-    return _icp_common(lib().tco_icp_point_to_plane, src, tgt, (_p(n), len(n)), init, max_iters,
-                       (C.c_float(md), C.c_float(convergence_threshold)), threads)
+    lib().tco_set_exact_sums(1 if exact_sums else 0)
+    try:
+        return _icp_common(lib().tco_icp_point_to_plane, src, tgt, (_p(n), len(n)), init, max_iters,
+                           (C.c_float(md), C.c_float(convergence_threshold)), threads)
+    finally:
+        lib().tco_set_exact_sums(0)
 
 
 def icp_point_to_plane(src, tgt, tgt_normals, init, max_iters, threads=0):

@@ -1202,19 +1202,36 @@ void tco_icp(const float *src, size_t ns, const float *tgt, size_t nt,
     else memcpy(out, init, 7 * sizeof(float));   /* :240 */
 }
 
+/* DIAGNOSTIC switch (default 0 = the reference's arithmetic).  The reference adds the per-pair terms of its 6x6 system one
+ * after the other in f32 (registration.rs:409-428): with ~10^6 pairs every sum carries a rounding error of ~1e-5 relative
+ * (terms below half an ulp of the running sum are even dropped outright).  With the switch on, the SAME f32 per-pair terms are
+ * added in f64, i.e. the sums the reference's formula defines, without its accumulation error.  Tests use it to show that a
+ * transform which is 2e-5 away from the reference's on a 10^6-point surface is that far away because of the reference's own
+ * accumulation error, not because of different pairs or a different solve (tests/test_gpu_fullsize.py). */
+static int g_exact_sums = 0;
+void tco_set_exact_sums(int on) { g_exact_sums = on; }
+
 /* compute_transformation_point_to_plane (registration.rs:395-450) */
 static int p2plane_solve(const float *vs, const float *vq, const float *vn, size_t n, float out[7]) {
     float ata[36]; float atb[6];
     memset(ata, 0, sizeof(ata)); memset(atb, 0, sizeof(atb));
+    double data[36], datb[6];
+    memset(data, 0, sizeof(data)); memset(datb, 0, sizeof(datb));
     for (size_t i = 0; i < n; ++i) {
         const float *s = &vs[3 * i], *q = &vq[3 * i], *nn = &vn[3 * i];
         float c[3]; cross3(s, nn, c);
         float a[6] = { c[0], c[1], c[2], nn[0], nn[1], nn[2] };
         float d[3] = { q[0] - s[0], q[1] - s[1], q[2] - s[2] };
         float b = nn[0] * d[0] + nn[1] * d[1] + nn[2] * d[2];
+        if (g_exact_sums) {
+            for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc) data[6 * r + cc] += (double)(a[r] * a[cc]);
+            for (int r = 0; r < 6; ++r) datb[r] += (double)(a[r] * b);
+            continue;
+        }
         for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc) ata[6 * r + cc] += a[r] * a[cc];
         for (int r = 0; r < 6; ++r) atb[r] += a[r] * b;
     }
+    if (g_exact_sums) { for (int e = 0; e < 36; ++e) ata[e] = (float)data[e]; for (int e = 0; e < 6; ++e) atb[e] = (float)datb[e]; }
     float x[6];
     if (!tco_cholesky6_solve(ata, atb, x)) { if (!tco_lu6_solve(ata, atb, x)) return 0; }   /* :432-438 */
     /* rot = Rz(x2) * Ry(x1) * Rx(x0), axis-angle unit quaternions (:441-444) */

@@ -127,6 +127,10 @@ int tco_kiss_icp(const float *src, size_t ns, const float *tgt, size_t nt, const
                  float voxel_size, float max_range, float min_range, size_t max_iters,
                  tco_icp_result *res, size_t *n_source_down, int threads);
 
+/* diagnostic, default 0: 1 = the per-pair terms of the point-to-plane 6x6 system are added in f64 instead of the reference's
+   sequential f32 (see tc_oracle.c) */
+void tco_set_exact_sums(int on);
+
 /* 0 (default): voxels of the down-sampled source in key order; otherwise a deterministic shuffle standing in for the reference's
    unspecified HashMap order (filtering.rs:120-130) */
 void tco_set_voxel_order_seed(uint64_t seed);

@@ -740,8 +740,10 @@ def test_non_finite_points_are_inert(ctx):
     pts[mask] = clean
     junk = clean[rng.integers(0, len(clean), 300)].copy()
     junk[np.arange(300), rng.integers(0, 3, 300)] = np.where(rng.random(300) < 0.6, np.nan, np.where(rng.random(300) < 0.5, np.inf, -np.inf))
-    junk[:20] = np.nan                                                   # whole rows, and some near the box minimum
+    junk[:20] = np.nan                                                   # whole rows, and some at the box minimum (cell 0)
     junk[20:40, 0] = clean[:, 0].min()
+    junk[20:40, 1] = np.nan
+    assert not np.isfinite(junk).all(axis=1).any()
     pts[bad_rows] = junk
     for data in (pts, torch.from_numpy(pts).cuda()):
         g = ctx.estimate_normals(data, 12)
@@ -761,11 +763,13 @@ def test_non_finite_points_are_inert(ctx):
     src_clean, tgt_clean, T = synth.registration_pair(30000, seed=21)
     src = np.empty_like(pts); src[mask] = src_clean; src[bad_rows] = junk
     tgt = pts.copy(); tgt[mask] = tgt_clean
+    # (the same pairs, summed in a different tree: the rows land in other lanes -> equal to rounding, not to the bit)
     a = ctx.icp_detailed(src, tgt, None, 10, None, 0.0)
     b = ctx.icp_detailed(src_clean, tgt_clean, None, 10, None, 0.0)
-    assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse
+    assert frob(a.transformation, b.transformation, O.isometry_to_matrix) <= 1e-6 and abs(a.mse - b.mse) <= 1e-6 * b.mse
     assert np.array_equal(a.correspondences, np.stack([remap[b.correspondences[:, 0]], remap[b.correspondences[:, 1]]], axis=1))
     nrm = ctx.estimate_normals(tgt, 12)
     a = ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, 10, None, 0.0)
     b = ctx.icp_point_to_plane_detailed(src_clean, tgt_clean, nrm[mask], None, 10, None, 0.0)
-    assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse
+    assert frob(a.transformation, b.transformation, O.isometry_to_matrix) <= 1e-6
+    assert np.array_equal(a.correspondences, np.stack([remap[b.correspondences[:, 0]], remap[b.correspondences[:, 1]]], axis=1))

@@ -12,7 +12,7 @@ from .api import (  # noqa: F401
     estimate_normals_with_config, gpu_batch_icp, gpu_estimate_normals, gpu_icp, gpu_icp_point_to_plane, icp,
     icp_detailed, icp_point_to_plane, icp_point_to_plane_detailed, icp_point_to_point, icp_point_to_point_default,
     isometry_to_matrix, voxel_grid_filter, gpu_voxel_grid_filter,
-    GicpConfig, gicp, KissIcpConfig, kiss_icp, BackpressureConfig, FrameResult, FrameStream, RealtimeMetrics, read_kitti_bin, SearchIndex,
+    GicpConfig, gicp, KissIcpConfig, kiss_icp, BackpressureConfig, FrameResult, FrameStream, RealtimeMetrics, read_kitti_bin, SearchIndex, Cloud,
 )
 
 __all__ = [n for n in dir() if not n.startswith("_")]

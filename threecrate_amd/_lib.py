@@ -88,6 +88,9 @@ EXPORTS = [
     "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
     "tc_icp_shard_reduce", "tc_icp_shard_get_sums", "tc_icp_shard_set_sums", "tc_icp_shard_done",
     "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
+    "tc_cloud_upload", "tc_cloud_upload_device", "tc_cloud_size", "tc_cloud_points_device", "tc_cloud_normals_device",
+    "tc_cloud_estimate_normals", "tc_cloud_estimate_normals_device", "tc_cloud_set_normals_device", "tc_cloud_icp_point_to_plane",
+    "tc_cloud_icp_detailed", "tc_cloud_destroy",
     "tc_comm_unique_id", "tc_comm_create", "tc_comm_adopt", "tc_comm_create_host", "tc_comm_create_local", "tc_comm_rank", "tc_comm_size",
     "tc_comm_destroy", "tc_sharded_icp_point_to_plane_device", "tc_sharded_icp_detailed_device", "tc_sharded_estimate_normals_device",
     "tc_multiscale_icp_point_to_point", "tc_gicp", "tc_gicp_device", "tc_kiss_icp", "tc_kiss_icp_device", "tc_knn", "tc_knn_device", "tc_radius_search", "tc_radius_search_device",
@@ -167,6 +170,21 @@ def load():
     L.tc_icp_shard_finish.argtypes = [vp, sz, resp]
     L.tc_icp_shard_destroy.argtypes = [vp]
     L.tc_icp_shard_destroy.restype = None
+    L.tc_cloud_upload.argtypes = [vp, f32p, sz, ctxpp]
+    L.tc_cloud_upload_device.argtypes = [vp, f32p, sz, ctxpp]
+    L.tc_cloud_size.argtypes = [vp]
+    L.tc_cloud_size.restype = sz
+    L.tc_cloud_points_device.argtypes = [vp]
+    L.tc_cloud_points_device.restype = C.c_void_p
+    L.tc_cloud_normals_device.argtypes = [vp]
+    L.tc_cloud_normals_device.restype = C.c_void_p
+    L.tc_cloud_estimate_normals.argtypes = [vp, C.POINTER(NormalConfig), f32p]
+    L.tc_cloud_estimate_normals_device.argtypes = [vp, C.POINTER(NormalConfig), f32p]
+    L.tc_cloud_set_normals_device.argtypes = [vp, f32p, sz, sz]
+    L.tc_cloud_icp_point_to_plane.argtypes = [vp, vp, f32p, sz, f, f, resp]
+    L.tc_cloud_icp_detailed.argtypes = [vp, vp, f32p, sz, f, f, resp]
+    L.tc_cloud_destroy.argtypes = [vp]
+    L.tc_cloud_destroy.restype = None
     L.tc_comm_unique_id.argtypes = [vp]
     L.tc_comm_create.argtypes = [vp, i, i, vp, ctxpp]
     L.tc_comm_adopt.argtypes = [vp, vp, i, i, ctxpp]

@@ -499,6 +499,106 @@ class GpuContext:
         return self.icp_point_to_plane_detailed(source, target, target_normals, init, max_iters, None, 1e-6)
 
 
+class Cloud:
+    """Device-resident cloud handle (tc_cloud_*): owns a copy of the points in HBM, is indexed once, keeps its
+    normals in the layout the ICP kernels read.  `points`: numpy (uploaded) or a torch CUDA tensor (copied on the device).
+
+        prev = tc.Cloud(ctx, frame0); prev.estimate_normals(16, out=False)
+        cur = tc.Cloud(ctx, frame1)
+        r = cur.icp_point_to_plane(prev)          # icp_point_to_plane(source=cur, target=prev, prev's normals)
+    """
+
+    def __init__(self, ctx: "GpuContext", points):
+        self._ctx, self._L = ctx, _lib.load()
+        h = C.c_void_p()
+        if _is_torch(points):
+            import torch
+            x = points.detach().to(torch.float32).contiguous().reshape(-1, 3)
+            ctx._order(x.device)
+            ctx._check(self._L.tc_cloud_upload_device(ctx._h, x.data_ptr(), x.shape[0], C.byref(h)))
+            ctx._check(self._L.tc_synchronize(ctx._h))          # `x` may be a temporary: the copy must have landed
+            self._torch_device = x.device
+        else:
+            x = _as_host(points)
+            ctx._check(self._L.tc_cloud_upload(ctx._h, x.ctypes.data, x.shape[0], C.byref(h)))
+            self._torch_device = None
+        self._h = h
+
+    def __len__(self):
+        return int(self._L.tc_cloud_size(self._h))
+
+    def estimate_normals(self, k: int = 10, config: "NormalEstimationConfig" = None, out=True):
+        """estimate_normals_with_config (normals.rs:257-357) on the handle's cloud; the normals stay with the handle.
+        out=True: also return the (n, 6) NormalPoint3f array (torch on the device for a torch-made handle, numpy otherwise);
+        out=False: nothing is returned and the scattered 24-byte record stores are skipped."""
+        c = self._ctx._cfg(config or NormalEstimationConfig(k_neighbors=k))
+        n = len(self)
+        if not out:
+            self._ctx._check(self._L.tc_cloud_estimate_normals_device(self._h, C.byref(c), None))
+            return None
+        if self._torch_device is not None:
+            import torch
+            o = torch.empty((n, 6), dtype=torch.float32, device=self._torch_device)
+            self._ctx._order(o.device)
+            self._ctx._check(self._L.tc_cloud_estimate_normals_device(self._h, C.byref(c), o.data_ptr()))
+            return o
+        o = np.empty((n, 6), np.float32)
+        self._ctx._check(self._L.tc_cloud_estimate_normals(self._h, C.byref(c), o.ctypes.data))
+        return o
+
+    def set_normals(self, normals):
+        """normals computed elsewhere: (n, 3), or the (n, 6) NormalPoint3f array of an estimate_normals call"""
+        import torch
+        if not _is_torch(normals):
+            normals = torch.from_numpy(np.ascontiguousarray(np.asarray(normals, np.float32))).to(torch.device("cuda", self._ctx.device))
+        t = normals.detach().to(torch.float32).contiguous()
+        stride = 6 if (t.dim() == 2 and t.shape[1] == 6) else 3
+        nn = t.shape[0] if t.dim() == 2 else t.numel() // 3
+        self._ctx._order(t.device)
+        self._ctx._check(self._L.tc_cloud_set_normals_device(self._h, t.data_ptr() + (12 if stride == 6 else 0), nn, stride))
+
+    def _icp(self, fn, target, init, max_iters, max_correspondence_distance, convergence_threshold, correspondences, needs_normals):
+        import torch
+        ctx = self._ctx
+        md = ctx._max_dist(max_correspondence_distance)
+        if md is None:
+            ctx._reject_all(len(self), len(target), max_iters)
+        i7 = np.ascontiguousarray(IDENTITY if init is None else np.asarray(init, np.float32).reshape(7))
+        r = _lib.IcpResultC()
+        corr = None
+        if correspondences:
+            corr = torch.empty(max(1, len(self)), dtype=torch.int32, device=torch.device("cuda", ctx.device))
+            r.corr_target = corr.data_ptr()
+            ctx._order(corr.device)
+        ctx._check(fn(self._h, target._h, i7.ctypes.data, max_iters, md, convergence_threshold, C.byref(r)))
+        if corr is not None:
+            corr = corr[: len(self)] if correspondences == "device" else corr[: len(self)].to(torch.int64) & 0xFFFFFFFF
+        return ctx._result(r, len(self), corr, correspondences)
+
+    def icp_point_to_plane(self, target: "Cloud", init=None, max_iters=50, max_correspondence_distance=None,
+                           convergence_threshold=1e-6, correspondences=False):
+        """icp_point_to_plane_detailed (registration.rs:508-602): self = source, `target` = a handle with normals"""
+        return self._icp(self._L.tc_cloud_icp_point_to_plane, target, init, max_iters, max_correspondence_distance, convergence_threshold,
+                         correspondences, True)
+
+    def icp_detailed(self, target: "Cloud", init=None, max_iters=50, max_correspondence_distance=None, convergence_threshold=1e-6,
+                     correspondences=False):
+        """icp_detailed (registration.rs:258-370): self = source"""
+        return self._icp(self._L.tc_cloud_icp_detailed, target, init, max_iters, max_correspondence_distance, convergence_threshold,
+                         correspondences, False)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tc_cloud_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- module-level free functions with the reference's names ----------------------------------
 _default_ctx = None
 

@@ -62,14 +62,10 @@ ProfScope::~ProfScope() {
 }
 
 static void free_buf(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
-static void free_index(DeviceIndex &ix) {
-    free_buf(ix.pts); free_buf(ix.cell_start); free_buf(ix.normals); free_buf(ix.vor); free_buf(ix.cell_of);
-    free_buf(ix.slot); free_buf(ix.arrival); free_buf(ix.fill); free_buf(ix.blocksum);
-}
 
 // NormalEstimationConfig -> cell edge factor: ring R0 = 2 must cover the (k+1)-NN sphere for all
 // but ~1e-3 of the queries of a locally uniform cloud (Poisson tail), the rest take the overflow pass.
-static float normals_cell_factor(size_t k, bool large = false) {
+float normals_cell_factor(size_t k, bool large) {
     const double K1 = (double)k + 1.0;
     const double lam = K1 + 3.1 * std::sqrt(K1) + 2.0;
     const double c = std::cbrt(lam / 4.18879);
@@ -83,28 +79,41 @@ static float normals_cell_factor(size_t k, bool large = false) {
 
 // points per occupied cell wanted on a SURFACE: the disc of radius ~1.9 h (ring 2) must hold the same
 // lambda(k) points the volumetric factor above puts into the ring-2 sphere: sigma h^2 = lambda / (pi 1.9^2)
-static float normals_target_ppo(size_t k) {
+float normals_target_ppo(size_t k) {
     const double K1 = (double)k + 1.0;
     return (float)((K1 + 3.1 * std::sqrt(K1) + 2.0) / 11.3);
 }
 
-static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, float *d_out,
-                                size_t p_begin = 0, size_t p_end = (size_t)-1, bool slice_out = false) {
-    // radius mode: ring 2 must cover the radius ball, so the cell edge is at least radius / 2
-    const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
-    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(cfg->k_neighbors, n >= kAdaptMinPoints), nullptr, nullptr, nullptr, min_h,
-                                  normals_target_ppo(cfg->k_neighbors))) return s;
+void free_index(DeviceIndex &ix) {
+    free_buf(ix.pts); free_buf(ix.cell_start); free_buf(ix.normals); free_buf(ix.vor); free_buf(ix.cell_of);
+    free_buf(ix.slot); free_buf(ix.arrival); free_buf(ix.fill); free_buf(ix.blocksum);
+}
+
+// build == false: `ix` already indexes this cloud (a cloud handle)
+tc_status normals_on_index(tc_context *ctx, DeviceIndex &ix, bool build, float cell_factor_override, const float *d_xyz, size_t n,
+                           const tc_normal_config *cfg, float *d_out, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm) {
+    if (build) {
+        // radius mode: ring 2 must cover the radius ball, so the cell edge is at least radius / 2
+        const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
+        const float f = cell_factor_override > 0.0f ? cell_factor_override : normals_cell_factor(cfg->k_neighbors, n >= kAdaptMinPoints);
+        if (tc_status s = build_index(ctx, ix, d_xyz, n, f, nullptr, nullptr, nullptr, min_h, normals_target_ppo(cfg->k_neighbors))) return s;
+    }
     float vp[3];
     if (cfg->has_viewpoint) {
         vp[0] = cfg->viewpoint[0]; vp[1] = cfg->viewpoint[1]; vp[2] = cfg->viewpoint[2];
     } else {   // normals.rs:275-303 (f32, same operation order; min/max are order independent)
-        const float *bmn = ctx->tgt_index.exact_min, *bmx = ctx->tgt_index.exact_max;      // the cloud's exact box (the grid's may be clamped)
+        const float *bmn = ix.exact_min, *bmx = ix.exact_max;      // the cloud's exact box (the grid's may be clamped)
         const float cx = (bmn[0] + bmx[0]) / 2.0f, cy = (bmn[1] + bmx[1]) / 2.0f, cz = (bmn[2] + bmx[2]) / 2.0f;
         const float ex = bmx[0] - bmn[0], ey = bmx[1] - bmn[1], ez = bmx[2] - bmn[2];
         const float extent = std::sqrt(ex * ex + ey * ey + ez * ez);
         vp[0] = cx + 0.0f; vp[1] = cy + 0.0f; vp[2] = cz + extent;
     }
-    return launch_normals(ctx, ctx->tgt_index, d_xyz, *cfg, vp, d_out, p_begin, p_end, slice_out);
+    return launch_normals(ctx, ix, d_xyz, *cfg, vp, d_out, p_begin, p_end, slice_out, d_sorted_nrm);
+}
+
+static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, float *d_out,
+                                size_t p_begin = 0, size_t p_end = (size_t)-1, bool slice_out = false) {
+    return normals_on_index(ctx, ctx->tgt_index, true, 0.0f, d_xyz, n, cfg, d_out, p_begin, p_end, slice_out, nullptr);
 }
 
 }  // namespace tc
@@ -573,7 +582,7 @@ static tc_status gicp_covariances_device(tc_context *ctx, const float *d_xyz, si
     if (tc_status s = ensure(ctx, dist, n * k * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, cnt, n * sizeof(uint32_t))) return s;
     // same grid as tc_knn (the point itself is one of its k nearest)
-    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(k > 1 ? k - 1 : 1) * 2.0f, nullptr, nullptr)) return s;
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_xyz, n, normals_cell_factor(k > 1 ? k - 1 : 1, false) * 2.0f, nullptr, nullptr)) return s;
     if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_xyz, n, k, (uint32_t *)idx.p, (float *)dist.p, (uint32_t *)cnt.p)) return s;
     ProfScope ps(ctx, "gicp_covariances");
     hipLaunchKernelGGL(gicp_cov_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, (const uint32_t *)idx.p,
@@ -645,7 +654,7 @@ tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const f
         return TC_OK;
     }
     if (n >= 0xFFFFFFF0ull || nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
-    if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1) * 2.0f, nullptr, nullptr)) return s;
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1, false) * 2.0f, nullptr, nullptr)) return s;
     if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k, d_idx, d_dist, d_count)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
@@ -663,7 +672,7 @@ tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t 
         return TC_OK;
     }
     if (n >= 0xFFFFFFF0ull || nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
-    if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k_max > 1 ? k_max - 1 : 1) * 2.0f, nullptr, nullptr)) return s;
+    if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k_max > 1 ? k_max - 1 : 1, false) * 2.0f, nullptr, nullptr)) return s;
     if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k_max, d_idx, d_dist, d_count, radius * radius)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
@@ -736,7 +745,7 @@ tc_status tc_search_index_create_device(tc_context *ctx, const float *d_cloud, s
     tc_search_index *s = new tc_search_index{ctx, {}, n, {}, {}};
     if (n) {        // an empty cloud is an empty tree (nearest_neighbor.rs:38-45)
         const size_t k = std::min<size_t>(std::max<size_t>(k_hint, 1), 129);
-        tc_status rc = build_index(ctx, s->ix, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1) * 2.0f, nullptr, nullptr);
+        tc_status rc = build_index(ctx, s->ix, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1, false) * 2.0f, nullptr, nullptr);
         if (rc == TC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, TC_GPU, "search index build failed");
         if (rc != TC_OK) { free_index(s->ix); delete s; return rc; }
         // queries only need the sorted records and the cell starts: drop the build scratch (16 B per point)

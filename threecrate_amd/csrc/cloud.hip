@@ -1,0 +1,174 @@
+// cloud.hip -- tc_cloud: a device-resident cloud that OWNS its points, its spatial index and (optionally) its normals
+// ("device-resident variants (tc_cloud_upload -> handle) so frames can stay on the GPU").
+//
+// The reference rebuilds its kd-tree inside every call (estimate_normals: normals.rs:272; icp*: registration.rs:281 / :536),
+// so a frame that gets normals and then serves as the target of the next registration is indexed twice.  A handle is indexed
+// ONCE: estimate_normals leaves the cell-sorted records and the cell-sorted normals in the handle -- exactly the layout the ICP
+// kernels read -- and every later registration against it starts from there (no second build, no normals gather, and the
+// inscribed-ball bounds of the first registration are kept too).  Results are bit-identical to the handle-free entry points on
+// the same grid; the grid's cell edge differs (one edge serves both uses), which changes speed, never answers.
+#include "tc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+struct tc_cloud {
+    tc_context *ctx = nullptr;
+    size_t n = 0;
+    tc::DevBuf xyz;                 // n x 3 f32, owned
+    tc::DeviceIndex ix;
+    bool indexed = false;
+    float factor = 0.0f;            // cell-edge factor the index was built with
+    bool has_normals = false;       // ix.normals holds the cell-sorted normals of the current index
+    tc::DevBuf normals6;            // n x 6 NormalPoint3f in input order (kept when normals were estimated here or set by the caller)
+    bool has_normals6 = false;
+};
+
+namespace {
+
+using namespace tc;
+
+void release(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+// One cell edge for both uses when their wishes are close (k = 16 normals want 1.01 x the point spacing, the 1-NN search of ICP
+// 1.13): the index is built with the ICP edge then -- measured on the 1 M-point benchmark cloud the normals lose less on the
+// larger edge than fifty ICP iterations lose on the smaller one.  Otherwise the first use decides and a later use with a very
+// different wish rebuilds (a k = 64 normals grid is a poor 1-NN grid).
+float shared_factor(float want) {
+    const float icp = icp_cell_factor();
+    return (want > 0.8f * icp && want < 1.25f * icp) ? icp : want;
+}
+
+tc_status ensure_index(tc_cloud *c, float want_factor, float target_ppo, float min_h) {
+    tc_context *ctx = c->ctx;
+    const float f = shared_factor(want_factor);
+    if (c->indexed && c->factor > 0.8f * f && c->factor < 1.25f * f && min_h <= c->ix.geom.h) return TC_OK;
+    c->has_normals = false;
+    if (tc_status s = build_index(ctx, c->ix, (const float *)c->xyz.p, c->n, f, nullptr, nullptr, nullptr, min_h, target_ppo)) return s;
+    c->indexed = true;
+    c->factor = f;
+    return TC_OK;
+}
+
+tc_status cloud_create(tc_context *ctx, const float *p, size_t n, bool from_host, tc_cloud **out) {
+    if (!ctx || !out) return TC_INVALID_DATA;
+    *out = nullptr;
+    if (n >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    tc_cloud *c = new tc_cloud();
+    c->ctx = ctx;
+    c->n = n;
+    if (n) {
+        tc_status s = ensure(ctx, c->xyz, n * 3 * sizeof(float));
+        if (s == TC_OK && hipMemcpyAsync(c->xyz.p, p, n * 3 * sizeof(float), from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                                         ctx->stream) != hipSuccess) s = fail(ctx, TC_GPU, "cloud upload failed");
+        if (s == TC_OK && from_host && hipStreamSynchronize(ctx->stream) != hipSuccess) s = fail(ctx, TC_GPU, "cloud upload failed");   // the caller's buffer is free on return
+        if (s != TC_OK) { release(c->xyz); delete c; return s; }
+    }
+    *out = c;
+    return TC_OK;
+}
+
+// sorted float4 normals from an n x stride array in input order
+tc_status adopt_normals(tc_cloud *c, const float *d_normals, size_t stride) {
+    if (tc_status s = ensure_index(c, icp_cell_factor(), 2.5f, 0.0f)) return s;
+    if (tc_status s = gather_normals(c->ctx, c->ix, d_normals, stride)) return s;
+    c->has_normals = true;
+    return TC_OK;
+}
+
+tc_status cloud_icp(tc_cloud *src, tc_cloud *tgt, bool p2plane, const float init[7], size_t max_iters, float max_dist, float conv_thr,
+                    tc_icp_result *res) {
+    if (!src || !tgt || !res || !init) return TC_INVALID_DATA;
+    tc_context *ctx = tgt->ctx;
+    if (src->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "source and target handles belong to different contexts");
+    // validation in the reference's order (registration.rs:266-276 / :517-531)
+    if (src->n == 0 || tgt->n == 0) return fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");
+    if (p2plane && !tgt->has_normals && !tgt->has_normals6)
+        return fail(ctx, TC_INVALID_DATA, "target_normals length must equal the number of target points (the target handle has no normals: "
+                                          "tc_cloud_estimate_normals or tc_cloud_set_normals_device first)");
+    if (max_iters == 0) return fail(ctx, TC_INVALID_DATA, "Max iterations must be positive");
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = ensure_index(tgt, icp_cell_factor(), 2.5f, 0.0f)) return s;
+    if (p2plane && !tgt->has_normals) {          // the index was rebuilt since the normals were made: re-sort them
+        if (tc_status s = gather_normals(ctx, tgt->ix, (const float *)tgt->normals6.p + 3, 6)) return s;
+        tgt->has_normals = true;
+    }
+    return icp_run(ctx, p2plane, (const float *)src->xyz.p, src->n, (const float *)tgt->xyz.p, tgt->n, nullptr, 0, init, max_iters, max_dist,
+                   conv_thr, res, true, 0, &tgt->ix);
+}
+
+}  // namespace
+
+extern "C" {
+
+tc_status tc_cloud_upload(tc_context *ctx, const float *xyz, size_t n, tc_cloud **out) { return cloud_create(ctx, xyz, n, true, out); }
+tc_status tc_cloud_upload_device(tc_context *ctx, const float *d_xyz, size_t n, tc_cloud **out) { return cloud_create(ctx, d_xyz, n, false, out); }
+size_t tc_cloud_size(const tc_cloud *c) { return c ? c->n : 0; }
+const float *tc_cloud_points_device(const tc_cloud *c) { return c ? (const float *)c->xyz.p : nullptr; }
+const float *tc_cloud_normals_device(const tc_cloud *c) { return (c && c->has_normals6) ? (const float *)c->normals6.p : nullptr; }
+
+static tc_status cloud_normals(tc_cloud *c, const tc_normal_config *cfg, float *out, bool out_on_host, bool keep6) {
+    if (!c || !cfg) return TC_INVALID_DATA;
+    tc_context *ctx = c->ctx;
+    if (c->n == 0) return TC_OK;                                                              // normals.rs:261-263
+    if (cfg->k_neighbors < 3) return fail(ctx, TC_INVALID_DATA, "k_neighbors must be at least 3");   // :265-269
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
+    if (tc_status s = ensure_index(c, normals_cell_factor(cfg->k_neighbors, c->n >= kAdaptMinPoints), normals_target_ppo(cfg->k_neighbors), min_h)) return s;
+    if (tc_status s = ensure(ctx, c->ix.normals, c->n * sizeof(float4))) return s;
+    // the N x 6 records in input order (24-byte scattered stores) are only produced when somebody wants them
+    const bool want6 = out != nullptr || keep6;
+    float *d_out6 = nullptr;
+    if (want6) {
+        if (tc_status s = ensure(ctx, c->normals6, c->n * 6 * sizeof(float))) return s;
+        d_out6 = (float *)c->normals6.p;
+    }
+    c->has_normals = false;
+    c->has_normals6 = false;
+    if (tc_status s = normals_on_index(ctx, c->ix, false, 0.0f, (const float *)c->xyz.p, c->n, cfg, d_out6, 0, (size_t)-1, false,
+                                       (float4 *)c->ix.normals.p)) return s;
+    c->has_normals = true;
+    c->has_normals6 = want6;
+    if (out) TC_HIP_TRY(ctx, hipMemcpyAsync(out, d_out6, c->n * 6 * sizeof(float), out_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TC_OK;
+}
+
+tc_status tc_cloud_estimate_normals(tc_cloud *c, const tc_normal_config *cfg, float *out) { return cloud_normals(c, cfg, out, true, false); }
+tc_status tc_cloud_estimate_normals_device(tc_cloud *c, const tc_normal_config *cfg, float *d_out) { return cloud_normals(c, cfg, d_out, false, false); }
+
+tc_status tc_cloud_set_normals_device(tc_cloud *c, const float *d_normals, size_t n_normals, size_t stride) {
+    if (!c) return TC_INVALID_DATA;
+    tc_context *ctx = c->ctx;
+    if (n_normals != c->n) return fail(ctx, TC_INVALID_DATA, "target_normals length must equal the number of target points");   // registration.rs:522-526
+    if (stride < 3) return fail(ctx, TC_INVALID_DATA, "normal_stride must be >= 3");
+    if (c->n == 0) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    c->has_normals6 = false;
+    if (tc_status s = adopt_normals(c, d_normals, stride)) return s;
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the caller's array is free on return
+    return TC_OK;
+}
+
+tc_status tc_cloud_icp_point_to_plane(tc_cloud *source, tc_cloud *target, const float init[7], size_t max_iters, float max_dist,
+                                      float conv_thr, tc_icp_result *result) {
+    return cloud_icp(source, target, true, init, max_iters, max_dist, conv_thr, result);
+}
+
+tc_status tc_cloud_icp_detailed(tc_cloud *source, tc_cloud *target, const float init[7], size_t max_iters, float max_dist,
+                                float conv_thr, tc_icp_result *result) {
+    return cloud_icp(source, target, false, init, max_iters, max_dist, conv_thr, result);
+}
+
+void tc_cloud_destroy(tc_cloud *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    release(c->xyz); release(c->normals6);
+    tc::free_index(c->ix);
+    delete c;
+}
+
+}  // extern "C"

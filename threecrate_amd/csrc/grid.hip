@@ -401,6 +401,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
                       const GridGeom *reuse_geom, const IcpState *d_state_transform, const TileGeom *tile_major,
                       float min_cell_edge, float target_ppo) {
     if (n == 0 || n >= 0xFFFFFFF0ull) return fail(ctx, TC_INVALID_DATA, "build_index: bad point count");
+    ix.vor_valid = false;
     hipStream_t st = ctx->stream;
     const uint32_t n32 = (uint32_t)n;
     const int nb = (int)((n + 255) / 256);

@@ -864,7 +864,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_final_mse_kernel(GridView tgt, 
 __global__ void __launch_bounds__(256) icp_target_nn_bound_kernel(GridView tgt, float *__restrict__ vor, const IcpState *__restrict__ st) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const GridGeom &g = tgt.g;
-    if (p >= g.n || st->done) return;
+    if (p >= g.n || (st && st->done)) return;
     const float4 q = tgt.pts[p];
     const int cx = cell_coord(q.x, g.minx, g.inv_h, g.gx), cy = cell_coord(q.y, g.miny, g.inv_h, g.gy), cz = cell_coord(q.z, g.minz, g.inv_h, g.gz);
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
@@ -1287,31 +1287,40 @@ static size_t vor_after() {
 }
 static tc_status launch_target_nn_bounds(tc_context *ctx, DeviceIndex &ix, const GridView &tv, const IcpState *st, const float **out) {
     *out = nullptr;
+    if (ix.vor_valid) { *out = (const float *)ix.vor.p; return TC_OK; }      // a cloud handle that has been a target before
     if (tc_status s = ensure(ctx, ix.vor, (size_t)ix.geom.n * sizeof(float))) return s;
     ProfScope ps(ctx, "icp_target_nn_bounds");
-    hipLaunchKernelGGL(icp_target_nn_bound_kernel, dim3((ix.geom.n + 255) / 256), dim3(256), 0, ctx->stream, tv, (float *)ix.vor.p, st);
+    // (st == nullptr: unconditional; otherwise skipped once the registration is done)
+    const bool persistent = &ix != &ctx->tgt_index;          // a cloud handle's index: the bounds are kept for its later registrations
+    hipLaunchKernelGGL(icp_target_nn_bound_kernel, dim3((ix.geom.n + 255) / 256), dim3(256), 0, ctx->stream, tv, (float *)ix.vor.p,
+                       persistent ? nullptr : st);
+    ix.vor_valid = persistent;
     *out = (const float *)ix.vor.p;
     return TC_OK;
 }
 
 // ~1.45 pts/cell.  Scanned again after the main / refine split (50-iteration ICP, 1 M points): 0.8 -> 6.55 ms, 0.9 -> 5.55,
 // 1.0 -> 5.00, 1.13 -> 4.75, 1.25 -> 4.72, 1.4 -> 4.72 (flat: the main pass grows as the refine pass shrinks)
-static float icp_cell_factor() { return 1.13f; }   // ~1.45 pts/cell: ring 1 is exact for ~99.8 % of uniform queries
+float icp_cell_factor() { return 1.13f; }   // ~1.45 pts/cell: ring 1 is exact for ~99.8 % of uniform queries
 
 struct IcpSetup {
     IcpLaunch l;
     GridView tv;
     TileGeom tg;
+    DeviceIndex *tix = nullptr;      // the target's index: ctx->tgt_index, or a cloud handle's
 };
 
 static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                            const float *d_nrm, size_t nstride, const float init[7], float max_dist, float conv_thr,
-                           IcpSetup &out, int kiss = 0) {
+                           IcpSetup &out, int kiss = 0, DeviceIndex *tgt_prebuilt = nullptr) {
     // the search addresses target records by 32-bit byte offsets (16 B each)
     if (nt >= (1ull << 28)) return fail(ctx, TC_UNSUPPORTED, "ICP target clouds are limited to 2^28 - 1 points");
-    if (tc_status s = build_index(ctx, ctx->tgt_index, d_tgt, nt, icp_cell_factor(), nullptr, nullptr, nullptr, 0.0f, 2.5f)) return s;
-    if (p2plane)
-        if (tc_status s = gather_normals(ctx, ctx->tgt_index, d_nrm, nstride)) return s;
+    out.tix = tgt_prebuilt ? tgt_prebuilt : &ctx->tgt_index;
+    if (!tgt_prebuilt) {
+        if (tc_status s = build_index(ctx, ctx->tgt_index, d_tgt, nt, icp_cell_factor(), nullptr, nullptr, nullptr, 0.0f, 2.5f)) return s;
+        if (p2plane)
+            if (tc_status s = gather_normals(ctx, ctx->tgt_index, d_nrm, nstride)) return s;
+    }
     if (tc_status s = ensure(ctx, ctx->state, sizeof(IcpState))) return s;
     IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
     std::memset(hs, 0, sizeof(IcpState));
@@ -1324,14 +1333,14 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     hs->status = TC_OK;
     TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, hs, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
     // order the source by the (tile-major) target cell of its initially transformed position
-    out.tg = plan_tiles(ctx->tgt_index.geom, ns);
+    out.tg = plan_tiles((*out.tix).geom, ns);
     if (ns > 0)       // (a rank of a sharded run may own no source points)
-        if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &ctx->tgt_index.geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
+        if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &(*out.tix).geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
     out.l = plan_launch(ns);
     if (tc_status s = ensure(ctx, ctx->partials, ((size_t)(kMaxPartialBlocks + kRefineBlocks) * TC_ICP_SUMS_STRIDE + 2) * sizeof(double))) return s;
     // corr | corr_pos | refine counts (one per wave of a main block) | refine entries (uint2, chunk / 4 per wave)
     if (tc_status s = ensure(ctx, ctx->corr, (2 * ns + (size_t)kMaxPartialBlocks * (kIcpBlock / 64) + 2 * (size_t)out.l.nblocks * out.l.chunk) * sizeof(uint32_t))) return s;
-    out.tv = view_of(ctx->tgt_index);
+    out.tv = view_of((*out.tix));
     return TC_OK;
 }
 
@@ -1349,13 +1358,13 @@ __global__ void __launch_bounds__(256) gather_cov_kernel(const float4 *__restric
 static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                               const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
                               float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, const float *d_cov_src,
-                              const float *d_cov_tgt);
+                              const float *d_cov_tgt, DeviceIndex *tgt_prebuilt = nullptr);
 
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
-                  float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss) {
+                  float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, DeviceIndex *tgt_prebuilt) {
     return icp_run_mode(ctx, p2plane ? 1 : 0, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_iters, max_dist, conv_thr, res, corr_on_device,
-                        kiss, nullptr, nullptr);
+                        kiss, nullptr, nullptr, tgt_prebuilt);
 }
 
 // gicp.rs:157-305 once the covariances exist (d_cov_*: 8 floats per point, original order)
@@ -1404,10 +1413,10 @@ static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate
 static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                               const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
                               float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, const float *d_cov_src,
-                              const float *d_cov_tgt) {
+                              const float *d_cov_tgt, DeviceIndex *tgt_prebuilt) {
     const bool p2plane = mode == 1;
     IcpSetup su;
-    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, kiss)) return s;
+    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, kiss, tgt_prebuilt)) return s;
     hipStream_t st = ctx->stream;
     IcpState *dstate = (IcpState *)ctx->state.p;
     uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns;
@@ -1415,21 +1424,21 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     const float4 *src = (const float4 *)ctx->src_index.pts.p;
     const float4 *src_cov = nullptr;
     if (mode == 2) {
-        if (tc_status s = ensure(ctx, ctx->tgt_index.normals, nt * 2 * sizeof(float4))) return s;
+        if (tc_status s = ensure(ctx, (*su.tix).normals, nt * 2 * sizeof(float4))) return s;
         if (tc_status s = ensure(ctx, ctx->gicp_src_cov, ns * 2 * sizeof(float4))) return s;
-        hipLaunchKernelGGL(gather_cov_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const float4 *)ctx->tgt_index.pts.p,
-                           (uint32_t)nt, (const float4 *)d_cov_tgt, (float4 *)ctx->tgt_index.normals.p);
+        hipLaunchKernelGGL(gather_cov_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const float4 *)(*su.tix).pts.p,
+                           (uint32_t)nt, (const float4 *)d_cov_tgt, (float4 *)(*su.tix).normals.p);
         hipLaunchKernelGGL(gather_cov_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, src, (uint32_t)ns,
                            (const float4 *)d_cov_src, (float4 *)ctx->gicp_src_cov.p);
         src_cov = (const float4 *)ctx->gicp_src_cov.p;
     }
-    const float4 *nrm = (const float4 *)ctx->tgt_index.normals.p;
+    const float4 *nrm = (const float4 *)(*su.tix).normals.p;
 
     size_t enq = 0;
     const float *vor = nullptr;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
             if (enq++ == vor_after())
-                if (tc_status s = launch_target_nn_bounds(ctx, ctx->tgt_index, su.tv, dstate, &vor)) return s;
+                if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor);
             return TC_OK;
         })) return s;
@@ -1499,12 +1508,12 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns, *rlist = corr + 2 * ns;
     double *partials = (double *)ctx->partials.p;
     const float4 *src = (const float4 *)ctx->src_index.pts.p + lo;
-    const float4 *nrm = (const float4 *)ctx->tgt_index.normals.p;
+    const float4 *nrm = (const float4 *)(*su.tix).normals.p;
     size_t enq = 0;
     const float *vor = nullptr;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
             if (enq++ == vor_after())
-                if (tc_status s = launch_target_nn_bounds(ctx, ctx->tgt_index, su.tv, dstate, &vor)) return s;
+                if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, true, false, true, nullptr, vor);
             if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, false, true, false);

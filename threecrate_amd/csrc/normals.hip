@@ -43,6 +43,7 @@ struct NormalParams {
     int      has_radius;
     float    radius;
     const float *xyz;       // the caller's AoS input (positions of non-finite points are copied from here)
+    float4 *sorted_nrm;     // optional: the normal of cell-sorted position p -> sorted_nrm[p] (a cloud handle keeps them: the ICP target layout)
     uint32_t p_begin, p_end;    // cell-sorted positions handled by this launch (a multi-GPU shard: SURVEY 8e)
     int      slice_out;         // 1: record of position p goes to row p - p_begin (sorted order) instead of its original index
 };
@@ -423,9 +424,12 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         // The reference's PCA of such a neighbourhood is NaN throughout: `norm > 1e-6` is false -> the default normal (0, 0, 1)
         // (normals.rs:197-202), and the orientation test `dot < 0` is false for NaN (:216).  Finite points never see these
         // points as neighbours here (the reference's kd-tree places them wherever its NaN comparisons fall).
-        float *o = out6 + 6 * (size_t)(prm.slice_out ? p - prm.p_begin : orig);
-        o[0] = prm.xyz[3 * (size_t)orig]; o[1] = prm.xyz[3 * (size_t)orig + 1]; o[2] = prm.xyz[3 * (size_t)orig + 2];
-        o[3] = 0.0f; o[4] = 0.0f; o[5] = 1.0f;
+        if (prm.sorted_nrm) prm.sorted_nrm[p] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (out6) {
+            float *o = out6 + 6 * (size_t)(prm.slice_out ? p - prm.p_begin : orig);
+            o[0] = prm.xyz[3 * (size_t)orig]; o[1] = prm.xyz[3 * (size_t)orig + 1]; o[2] = prm.xyz[3 * (size_t)orig + 2];
+            o[3] = 0.0f; o[4] = 0.0f; o[5] = 1.0f;
+        }
         return;
     }
     const int cx = cell_coord(q.x, g.minx, g.inv_h, g.gx);
@@ -588,8 +592,11 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         const float dp = nrm_x * ux + nrm_y * uy + nrm_z * uz;
         if (dp < 0.0f) { nrm_x = -nrm_x; nrm_y = -nrm_y; nrm_z = -nrm_z; }
     }
-    float *o = out6 + 6 * (size_t)(prm.slice_out ? p - prm.p_begin : orig);
-    o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = nrm_x; o[4] = nrm_y; o[5] = nrm_z;
+    if (prm.sorted_nrm) prm.sorted_nrm[p] = make_float4(nrm_x, nrm_y, nrm_z, 0.0f);      // coalesced: lane = position
+    if (out6) {
+        float *o = out6 + 6 * (size_t)(prm.slice_out ? p - prm.p_begin : orig);
+        o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = nrm_x; o[4] = nrm_y; o[5] = nrm_z;
+    }
 }
 
 // XCD-aware block remap: hardware deals blocks round-robin over the 8 XCDs, so give each XCD
@@ -809,7 +816,7 @@ tc_status launch_normals_unsort(tc_context *ctx, const DeviceIndex &ix, const fl
 }
 
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_xyz, const tc_normal_config &cfg, const float vp[3],
-                         float *d_out6, size_t p_begin, size_t p_end, bool slice_out) {
+                         float *d_out6, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm) {
     if (cfg.k_neighbors + 1 > 129) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 128 is not supported by the HIP backend");
     NormalParams prm;
     prm.k = (uint32_t)cfg.k_neighbors;
@@ -819,6 +826,7 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     prm.has_radius = (cfg.has_radius && cfg.radius > 0.0f) ? 1 : 0;
     prm.radius = prm.has_radius ? cfg.radius : 0.0f;
     prm.xyz = d_xyz;
+    prm.sorted_nrm = d_sorted_nrm;
     prm.p_begin = (uint32_t)p_begin;
     prm.p_end = (uint32_t)std::min<size_t>(p_end, ix.geom.n);
     prm.slice_out = slice_out ? 1 : 0;

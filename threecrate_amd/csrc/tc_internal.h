@@ -117,6 +117,7 @@ struct DeviceIndex {
     DevBuf cell_start;  // u32 * (ncell+1)
     DevBuf normals;     // float4 * n   (cell-sorted target normals; optional)
     DevBuf vor;         // float * n    (ICP target: inscribed-ball bounds, icp_target_nn_bound_kernel; optional)
+    bool vor_valid = false;     // vor belongs to the current contents of pts (build_index resets it)
     DevBuf cell_of;     // u32 * n      (scratch: cell id per original point)
     DevBuf slot;        // u32 * n      (scratch: atomic scatter order)
     DevBuf arrival;     // u32 * n      (scratch: arrival rank of a point inside its cell)
@@ -201,7 +202,15 @@ tc_status range_filter_device(tc_context *ctx, const float *d_xyz, size_t n, flo
 
 // normals.hip
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_xyz, const tc_normal_config &cfg,
-                         const float vp[3], float *d_out6, size_t p_begin = 0, size_t p_end = (size_t)-1, bool slice_out = false);
+                         const float vp[3], float *d_out6, size_t p_begin = 0, size_t p_end = (size_t)-1, bool slice_out = false,
+                         float4 *d_sorted_nrm = nullptr);
+// api.hip: index (into `ix`) + normals of a device-resident cloud
+tc_status normals_on_index(tc_context *ctx, DeviceIndex &ix, bool build, float cell_factor_override, const float *d_xyz, size_t n,
+                           const tc_normal_config *cfg, float *d_out6, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm);
+float normals_cell_factor(size_t k, bool large);
+float normals_target_ppo(size_t k);
+float icp_cell_factor();
+void free_index(DeviceIndex &ix);
 tc_status launch_radius_all(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, float radius, uint32_t *d_counts,
                             const unsigned long long *d_offsets, uint32_t *d_idx, float *d_dist);
 tc_status launch_normals_unsort(tc_context *ctx, const DeviceIndex &ix, const float *d_sorted6, float *d_out6);
@@ -221,9 +230,12 @@ tc_status comm_allgather(tc_comm *comm, void *d_buf, size_t bytes_per_rank);    
 tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p2plane, const float *d_src, size_t ns, const float *d_tgt,
                           size_t nt, const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
                           float conv_thr, tc_icp_result *res);
+// tgt_prebuilt: an index of the target built by the caller (a cloud handle; with its cell-sorted normals when p2plane), else
+// the target is indexed into ctx->tgt_index
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters,
-                  float max_dist, float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss = 0);
+                  float max_dist, float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss = 0,
+                  DeviceIndex *tgt_prebuilt = nullptr);
 tc_status icp_run_gicp(tc_context *ctx, const float *d_src, size_t ns, const float *d_tgt, size_t nt, const float *d_cov_src,
                        const float *d_cov_tgt, const float init[7], size_t max_iters, float max_dist, float conv_thr,
                        tc_icp_result *res, bool corr_on_device);
