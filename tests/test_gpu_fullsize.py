@@ -172,6 +172,6 @@ def test_config3_ten_million_points_through_the_sharded_entry(ctx):
         s2 = b2.reduce().clone(); b2.finish(1)
         bf = D.HipShardBackend(ctx, ds, dt, nrm, O.IDENTITY, None, 0.0)
         sf = bf.reduce().clone(); bf.finish(1)
-        assert float(sf[28]) == n and torch.allclose(s1 + s2, sf, rtol=1e-6, atol=1e-9)
+        assert float(sf[28]) == n and float((s1 + s2 - sf).abs().max()) <= 1e-7 * float(sf.abs().max())
     finally:
         comm.close()

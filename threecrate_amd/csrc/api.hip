@@ -21,17 +21,47 @@ tc_status fail(tc_context *ctx, tc_status st, const std::string &msg) {
     return st;
 }
 
+constexpr size_t kPoolMaxBytes = (size_t)32 << 30, kPoolMaxBlocks = 96;
+
+void recycle(tc_context *ctx, DevBuf &b) {
+    if (!b.p) return;
+    if (ctx->pool.size() >= kPoolMaxBlocks || ctx->pool_bytes + b.cap > kPoolMaxBytes) {
+        (void)hipFree(b.p);
+    } else {
+        ctx->pool.push_back(b);
+        ctx->pool_bytes += b.cap;
+    }
+    b.p = nullptr; b.cap = 0;
+}
+
 tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return TC_OK;
     if (b.p) {
         // buffers may still be referenced by work in flight on the stream
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return fail(ctx, TC_GPU, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
-        (void)hipFree(b.p);
-        b.p = nullptr; b.cap = 0;
+        recycle(ctx, b);
+    }
+    // best fit from the pool: the smallest block that holds the request without wasting more than the request itself
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); ++i) {
+        const size_t cap = ctx->pool[i].cap;
+        if (cap >= bytes && cap <= 2 * bytes + 4096 && (best < 0 || cap < ctx->pool[best].cap)) best = i;
+    }
+    if (best >= 0) {
+        b = ctx->pool[best];
+        ctx->pool_bytes -= b.cap;
+        ctx->pool.erase(ctx->pool.begin() + best);
+        return TC_OK;
     }
     size_t want = std::max<size_t>(bytes + bytes / 4, 256);
     hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess && !ctx->pool.empty()) {          // out of memory with blocks parked in the pool: release them, try again
+        (void)hipGetLastError();
+        for (auto &pb : ctx->pool) (void)hipFree(pb.p);
+        ctx->pool.clear(); ctx->pool_bytes = 0;
+        e = hipMalloc(&b.p, want);
+    }
     if (e != hipSuccess) {
         b.p = nullptr;
         return fail(ctx, TC_GPU, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
@@ -82,6 +112,10 @@ float normals_cell_factor(size_t k, bool large) {
 float normals_target_ppo(size_t k) {
     const double K1 = (double)k + 1.0;
     return (float)((K1 + 3.1 * std::sqrt(K1) + 2.0) / 11.3);
+}
+
+void recycle_index(tc_context *ctx, DeviceIndex &ix) {
+    for (DevBuf *b : {&ix.pts, &ix.cell_start, &ix.normals, &ix.vor, &ix.cell_of, &ix.slot, &ix.arrival, &ix.fill, &ix.blocksum}) recycle(ctx, *b);
 }
 
 void free_index(DeviceIndex &ix) {
@@ -177,6 +211,7 @@ void tc_context_destroy(tc_context *ctx) {
     free_index(ctx->tgt_index); free_index(ctx->src_index); free_index(ctx->vox_index);
     free_buf(ctx->in_a); free_buf(ctx->in_b); free_buf(ctx->in_c); free_buf(ctx->out_a); free_buf(ctx->bbox);
     free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->gicp_src_cov); free_buf(ctx->overflow);
+    for (auto &pb : ctx->pool) (void)hipFree(pb.p);
     for (auto e : ctx->chunk_events) (void)hipEventDestroy(e);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     for (auto &t : ctx->timers) for (auto &p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }

@@ -29,7 +29,6 @@ namespace {
 
 using namespace tc;
 
-void release(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
 // One cell edge for both uses when their wishes are close (k = 16 normals want 1.01 x the point spacing, the 1-NN search of ICP
 // 1.13): the index is built with the ICP edge then -- measured on the 1 M-point benchmark cloud the normals lose less on the
@@ -64,7 +63,7 @@ tc_status cloud_create(tc_context *ctx, const float *p, size_t n, bool from_host
         if (s == TC_OK && hipMemcpyAsync(c->xyz.p, p, n * 3 * sizeof(float), from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                                          ctx->stream) != hipSuccess) s = fail(ctx, TC_GPU, "cloud upload failed");
         if (s == TC_OK && from_host && hipStreamSynchronize(ctx->stream) != hipSuccess) s = fail(ctx, TC_GPU, "cloud upload failed");   // the caller's buffer is free on return
-        if (s != TC_OK) { release(c->xyz); delete c; return s; }
+        if (s != TC_OK) { recycle(ctx, c->xyz); delete c; return s; }
     }
     *out = c;
     return TC_OK;
@@ -166,8 +165,9 @@ void tc_cloud_destroy(tc_cloud *c) {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
-    release(c->xyz); release(c->normals6);
-    tc::free_index(c->ix);
+    // the blocks go back to the context's pool: the next frame's handle takes them without a hipMalloc
+    tc::recycle(c->ctx, c->xyz); tc::recycle(c->ctx, c->normals6);
+    tc::recycle_index(c->ctx, c->ix);
     delete c;
 }
 

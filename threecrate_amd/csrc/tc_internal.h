@@ -136,6 +136,10 @@ struct tc_context {
     uint32_t prof_tick = 0;
     std::vector<tc::KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
+    // device blocks given back by destroyed handles (tc_cloud, tc_search_index), reused by the next allocation of a similar
+    // size: a handle per frame must not cost a hipMalloc / hipFree pair per buffer per frame (milliseconds)
+    std::vector<tc::DevBuf> pool;
+    size_t pool_bytes = 0;
     hipEvent_t order_event = nullptr;       // tc_context_wait_stream
     std::vector<hipEvent_t> chunk_events;   // hipEventDisableTiming events of the ICP loop's chunk polling, reused across calls
 
@@ -176,6 +180,8 @@ tc_status fail(tc_context *ctx, tc_status st, const std::string &msg);
     } while (0)
 
 tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes);
+// hand a block back to the context's pool (the caller has made sure no work in flight uses it)
+void recycle(tc_context *ctx, DevBuf &b);
 
 // profiling scope: records hipEvents around one kernel launch on ctx->stream
 struct ProfScope {
@@ -211,6 +217,7 @@ float normals_cell_factor(size_t k, bool large);
 float normals_target_ppo(size_t k);
 float icp_cell_factor();
 void free_index(DeviceIndex &ix);
+void recycle_index(tc_context *ctx, DeviceIndex &ix);       // blocks back to the context's pool
 tc_status launch_radius_all(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, float radius, uint32_t *d_counts,
                             const unsigned long long *d_offsets, uint32_t *d_idx, float *d_dist);
 tc_status launch_normals_unsort(tc_context *ctx, const DeviceIndex &ix, const float *d_sorted6, float *d_out6);
