@@ -404,6 +404,14 @@ __device__ __forceinline__ void accumulate_gicp(float (&acc)[TC_ICP_SUMS_P2PLANE
 //      wave-reduced into the block's f64 LDS row, so that nothing but that row survives the group.
 constexpr int kIcpGroup = 4;
 constexpr int kRefineBlocks = 256;          // blocks of the refine pass = rows handed to the finalize step
+// The refine list: one count per wave of a main block (kMaxPartialBlocks x 4 words), then the entries, 32 bytes each:
+//   {x, y, z (the transformed query), source index} {best known d2, its position, -, -}
+// so that the refine pass starts from ONE 32-byte read instead of entry -> source record + previous match -> transform.
+constexpr int kRefineEntryWords = 8;
+__host__ __device__ __forceinline__ uint4 *refine_entries(uint32_t *rlist) {
+    uintptr_t a = reinterpret_cast<uintptr_t>(rlist + kMaxPartialBlocks * (kIcpBlock / 64));
+    return reinterpret_cast<uint4 *>((a + 15) & ~(uintptr_t)15);
+}
 
 // MODE: 0 point-to-point, 1 point-to-plane (tgt_nrm = target normals in cell order), 2 GICP (tgt_nrm = target
 // covariances, two float4 per cell-sorted position; src_cov = source covariances in the source's sorted order)
@@ -424,8 +432,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     // prefix, so the list -- and with it every sum -- is deterministic, without atomics, LDS or barriers.
     constexpr int kWavesPerBlock = kIcpBlock / 64;
     const uint32_t wave_cap = chunk / kWavesPerBlock;
-    uint2 *__restrict__ const wseg = reinterpret_cast<uint2 *>(rlist + kMaxPartialBlocks * kWavesPerBlock) +
-                                     ((size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * wave_cap;
+    uint4 *__restrict__ const wseg = refine_entries(rlist) + 2 * ((size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * wave_cap;
     uint32_t wcnt = 0;                                     // this wave's entries so far (wave-uniform)
     const GridGeom &g = tgt.g;
     const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
@@ -506,7 +513,9 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
                 const unsigned long long kp = pj != 0xFFFFFFFFu ? (((unsigned long long)__float_as_uint(ub2p) << 32) | pj) : ~0ull;
                 const unsigned long long kb = bestg != 0xFFFFFFFFu ? (((unsigned long long)__float_as_uint(best) << 32) | bestg) : ~0ull;
                 const unsigned long long km = kb < kp ? kb : kp;
-                wseg[wcnt + __popcll(rmask & ((1ull << lane) - 1ull))] = make_uint2(j, km != ~0ull ? (uint32_t)km : 0xFFFFFFFFu);
+                uint4 *ent = wseg + 2 * (size_t)(wcnt + __popcll(rmask & ((1ull << lane) - 1ull)));
+                ent[0] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), j);
+                ent[1] = make_uint4((uint32_t)(km >> 32), km != ~0ull ? (uint32_t)km : 0xFFFFFFFFu, 0u, 0u);
             }
             wcnt += __popcll(rmask);
             bool valid = in && !refine && bestg != 0xFFFFFFFFu;
@@ -678,8 +687,7 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     if (threadIdx.x < TC_ICP_SUMS_STRIDE)
         for (uint32_t r = mr0; r < mr1; ++r) folded += main_rows[(size_t)r * TC_ICP_SUMS_STRIDE + threadIdx.x];
     const GridGeom &g = tgt.g;
-    const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
-    const float t[3] = {st->t[0], st->t[1], st->t[2]};
+    const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};      // (GICP: the rotation of the pair terms)
     const float max_dist = st->max_dist;
     // refine list = the main blocks' segments; exclusive scan of their counts (every block computes
     // the same scan), then query i -> (segment, local index) by binary search: balanced and
@@ -715,7 +723,7 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
         __syncthreads();
     }
     const uint32_t count = seg_off[n_segs];
-    const uint2 *__restrict__ entries = reinterpret_cast<const uint2 *>(rlist + kMaxPartialBlocks * kSegPerRow);     // (source index, best known position)
+    const uint4 *__restrict__ entries = refine_entries(rlist);
     if (blockIdx.x == 0 && threadIdx.x == 0) {             // statistics
         st->refine_total += count;
         st->refine_max = max(st->refine_max, count);
@@ -735,8 +743,8 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     float *const acc = lacc[threadIdx.x / kRG];
     if (lg < NACC) acc[lg] = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (uint32_t i = group; i < count; i += ngroups) {
-        // segment of query i: last b with seg_off[b] <= i; kRG-ary search, one pivot per lane of the group
+    // entry of query i: segment = last b with seg_off[b] <= i (kRG-ary search, one pivot per lane of the group)
+    auto locate = [&](uint32_t i) -> size_t {
         uint32_t lo = 0, nleft = n_segs;
         while (nleft > 1) {
             const uint32_t stride = (nleft + kRG - 1) / kRG;
@@ -746,12 +754,16 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
             lo += k * stride;
             nleft = min(stride, nleft - k * stride);
         }
-        const uint2 ent = entries[(size_t)lo * seg_stride + (i - seg_off[lo])];
-        const uint32_t j = ent.x, pj = ent.y;
-        const float4 s = src[j];
-        const float4 p = tgt.pts[pj != 0xFFFFFFFFu ? pj : 0u];
-        float x, y, z;
-        iso_apply(q, t, s.x, s.y, s.z, x, y, z);
+        return (size_t)lo * seg_stride + (i - seg_off[lo]);
+    };
+    // the entry of a group's NEXT query is requested before the current one is searched (one round trip less per query)
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+    if (group < count) { const size_t a = locate(group); n0 = entries[2 * a]; n1 = entries[2 * a + 1]; }
+    for (uint32_t i = group; i < count; i += ngroups) {
+        const uint4 e0 = n0, e1 = n1;
+        if (i + ngroups < count) { const size_t a = locate(i + ngroups); n0 = entries[2 * a]; n1 = entries[2 * a + 1]; }
+        const uint32_t j = e0.w, pj = e1.y;
+        const float x = __uint_as_float(e0.x), y = __uint_as_float(e0.y), z = __uint_as_float(e0.z);
         const float qx = fminf(fmaxf(x, g.minx), g.maxx), qy = fminf(fmaxf(y, g.miny), g.maxy),
                     qz = fminf(fmaxf(z, g.minz), g.maxz);
         const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx), cy = cell_coord(qy, g.miny, g.inv_h, g.gy),
@@ -760,9 +772,9 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
                     fz = (qz - g.minz) * g.inv_h - (float)cz;
         const float mf = fmaxf(fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz)), 0.0f);
         const float out2 = outside_d2(x, y, z, qx, qy, qz, g.clamped);
-        // start: the best real point the main pass knows (previous match or its ring-1 result); ring 1 is done
+        // start: the best real point the main pass knows (previous match or its ring-1 result, with its distance); ring 1 is done
         unsigned long long bestkey = ~0ull;
-        if (pj != 0xFFFFFFFFu) bestkey = ((unsigned long long)__float_as_uint(d2_nc(p.x, p.y, p.z, x, y, z)) << 32) | pj;
+        if (pj != 0xFFFFFFFFu) bestkey = ((unsigned long long)e1.x << 32) | pj;
         for (int R = 2;; ++R) {
             bool touched;
             const unsigned long long lk = (R == 2) ? refine_shell<2>(tgt, cs_rsrc, pt_rsrc, 2, lg, x, y, z, cx, cy, cz, bestkey, touched)
@@ -1338,8 +1350,8 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
         if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &(*out.tix).geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
     out.l = plan_launch(ns);
     if (tc_status s = ensure(ctx, ctx->partials, ((size_t)(kMaxPartialBlocks + kRefineBlocks) * TC_ICP_SUMS_STRIDE + 2) * sizeof(double))) return s;
-    // corr | corr_pos | refine counts (one per wave of a main block) | refine entries (uint2, chunk / 4 per wave)
-    if (tc_status s = ensure(ctx, ctx->corr, (2 * ns + (size_t)kMaxPartialBlocks * (kIcpBlock / 64) + 2 * (size_t)out.l.nblocks * out.l.chunk) * sizeof(uint32_t))) return s;
+    // corr | corr_pos | refine counts (one per wave of a main block) | refine entries (32 bytes each, chunk / 4 per wave)
+    if (tc_status s = ensure(ctx, ctx->corr, (2 * ns + (size_t)kMaxPartialBlocks * (kIcpBlock / 64) + 4 + kRefineEntryWords * (size_t)out.l.nblocks * out.l.chunk) * sizeof(uint32_t))) return s;
     out.tv = view_of((*out.tix));
     return TC_OK;
 }

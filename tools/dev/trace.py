@@ -4,7 +4,7 @@ import numpy as np, torch, threecrate_amd as tc
 from threecrate_amd import synth
 n = 1000000
 ctx = tc.GpuContext(0)
-src, tgt, T = synth.registration_pair(n, seed=1, transform=synth.harness_transform())
+src, tgt, T = synth.registration_pair(n, seed=1, transform=synth.harness_transform(), noise_sigma=1e-4)
 dt, ds = torch.from_numpy(tgt).cuda(), torch.from_numpy(src).cuda()
 nrm = ctx.estimate_normals(dt, 16)
 for rep in range(2):

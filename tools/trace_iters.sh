@@ -15,7 +15,7 @@ for f in glob.glob(out + "/t/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-for pat in ("icp_correspond", "icp_refine"):
+for pat in ("icp_correspond", "icp_refine", "icp_finalize"):
     d = [(e - s) / 1e3 for s, e, k in rows if pat in k]
     d = d[-50:]
     print(pat, "last call, us per launch:")
