@@ -117,7 +117,10 @@ void        tc_normal_config_default(tc_normal_config *cfg);   /* normals.rs:28-
  * estimate_normals (normals.rs:238-247) = cfg{k}, estimate_normals_radius (normals.rs:368-380)
  * = cfg{k=10, radius, consistent, viewpoint None}; gpu_estimate_normals
  * (threecrate-gpu/src/normals.rs:443-461) has the same meaning.
- * xyz: n x 3 f32.  out: n x 6 f32 (NormalPoint3f).  n == 0 -> TC_OK before the k check. */
+ * xyz: n x 3 f32.  out: n x 6 f32 (NormalPoint3f).  n == 0 -> TC_OK before the k check.
+ * Limits of this backend (the reference has none): k_neighbors <= 128 (the k + 1 nearest incl. the point itself live in a
+ * 129-entry register list; the k-NN / radius exports below return up to 129 entries per query) -> TC_UNSUPPORTED beyond.
+ * Non-finite points (NaN / +-inf coordinates) are inert: never a neighbour, their own normal is the default (0, 0, 1). */
 tc_status tc_estimate_normals(tc_context *ctx, const float *xyz, size_t n,
                               const tc_normal_config *cfg, float *out_normal_points);
 /* same with xyz / out already resident in device memory (HBM) */

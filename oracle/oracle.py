@@ -29,6 +29,8 @@ class _IcpResult(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("TC_ORACLE_LIB"):          # e.g. the ASan / UBSan build (oracle/Makefile `asan`, tools/sanitize_cpu.sh)
+        return os.environ["TC_ORACLE_LIB"]
     so = os.path.join(_HERE, "libtc_oracle.so")
     src = os.path.join(_HERE, "tc_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
@@ -81,6 +83,8 @@ def lib():
         L.tco_p2plane_partial.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_void_p, f32p, f32p, f32p, C.c_float, f64p, u32p]
         L.tco_p2p_partial.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_void_p, f32p, f32p, C.c_float, f64p, u32p]
         L.tco_symmetric_eigen3.argtypes = [f32p, f32p, f32p]
+        L.tco_symmetric_eigen3_batch.argtypes = [f32p, C.c_size_t, f32p, f32p]
+        L.tco_symmetric_eigen3_batch.restype = None
         L.tco_svd3.argtypes = [f32p, f32p, f32p, f32p]
         L.tco_cholesky6_solve.argtypes = [f32p, f32p, f32p]
         L.tco_lu6_solve.argtypes = [f32p, f32p, f32p]
@@ -324,6 +328,14 @@ def symmetric_eigen3(m):
     ev, q = np.zeros(3, np.float32), np.zeros(9, np.float32)
     lib().tco_symmetric_eigen3(_p(a), _p(ev), _p(q))
     return ev, q.reshape(3, 3)
+
+
+def symmetric_eigen3_batch(m):
+    """(n, 3, 3) symmetric f32 -> (evals (n, 3), evecs (n, 3, 3) with eigenvectors as columns)"""
+    a = _f32(m).reshape(-1, 9)
+    ev, q = np.zeros((len(a), 3), np.float32), np.zeros((len(a), 9), np.float32)
+    lib().tco_symmetric_eigen3_batch(_p(a), len(a), _p(ev), _p(q))
+    return ev, q.reshape(-1, 3, 3)
 
 
 def svd3(m):

@@ -1114,6 +1114,12 @@ static int kabsch(const float *vs, const float *vq, size_t n, float out[7]) {
     out[4] = cq[0] - rc[0]; out[5] = cq[1] - rc[1]; out[6] = cq[2] - rc[2];
     return 1;
 }
+/* batch form of tco_symmetric_eigen3 for the differential tests on real covariance matrices (tests/test_oracle_pinning.py) */
+void tco_symmetric_eigen3_batch(const float *m9, size_t n, float *evals3, float *evecs9) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) tco_symmetric_eigen3(&m9[9 * i], &evals3[3 * i], &evecs9[9 * i]);
+}
+
 void tco_kabsch(const float *s, const float *q, size_t n, float out7[7], int *ok) { *ok = kabsch(s, q, n, out7); }
 
 /* compute_mse (registration.rs:206-218) */

@@ -16,6 +16,22 @@
  * source absent from /root/reference) and std::collections::BinaryHeap.
  * Those are restated from their published algorithms (see tc_oracle.c).
  *
+ * WHAT "RESTATED" MEANS, ROUTINE BY ROUTINE (so that nobody reads "bit-identical to the oracle" as "bit-identical to
+ * threecrate"; nalgebra's source is not in this container):
+ *   operation-by-operation restatements of the published nalgebra 0.34 code paths (same scaling, same Householder /
+ *   Givens formulas, same deflation rules, same order of operations, f32):
+ *       sym_eigen3 (Matrix3::symmetric_eigen), cholesky6 / lu6 (Matrix6::cholesky, ::lu().solve), quaternion and isometry
+ *       products, axis-angle quaternions, kd-tree build / k-NN / radius search and BinaryHeap order (nearest_neighbor.rs itself)
+ *   ALGORITHMIC restatements -- same mathematical result, NOT nalgebra's instruction sequence:
+ *       svd3            Golub-Kahan-Reinsch bidiagonalisation + implicit-shift QR written from the textbook algorithm
+ *                       (nalgebra's SVD is a different arrangement of the same method); singular values sorted descending
+ *                       with U, V^T permuted like Matrix::svd
+ *       quat_from_matrix  direct Shepperd branch conversion instead of nalgebra's iterative UnitQuaternion::from_matrix
+ *                       (for an orthonormal R both give R's quaternion to ~1e-7)
+ *   Both groups are checked at the operation level against LAPACK (f64) on random inputs (tests/test_oracle_linalg.py) AND on
+ *   the matrices the benchmark actually produces -- all 10^6 neighbourhood covariances of the 1 M-point cloud, the
+ *   per-iteration 6x6 systems and 3x3 cross-covariances of its registration (tests/test_oracle_pinning.py).
+ *
  * PARITY STATUS: the reference is Rust and cannot be built or imported in this
  * image (no rustc/cargo), and its own tests hold no golden vectors -- only
  * tolerance-level known-answer assertions.  The oracle is pinned against every
@@ -108,6 +124,7 @@ int tco_p2p_partial(const float *src, size_t j0, size_t j1, const tco_kdtree *tg
 
 /* ---- small linear algebra exposed for the LAPACK cross-checks ---- */
 void tco_symmetric_eigen3(const float m[9] /*row-major*/, float evals[3], float evecs[9] /*columns, row-major*/);
+void tco_symmetric_eigen3_batch(const float *m9, size_t n, float *evals3, float *evecs9);
 void tco_svd3(const float m[9], float u[9], float s[3], float vt[9]);
 int  tco_cholesky6_solve(const float a[36], const float b[6], float x[6]); /* 0 = not PD */
 int  tco_lu6_solve(const float a[36], const float b[6], float x[6]);       /* 0 = singular */

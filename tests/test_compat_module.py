@@ -77,21 +77,6 @@ def test_module_functions_match_the_oracle():
     assert idx[0] == 7 and len(idx) == 5 and np.allclose(dist, np.sort(d)[:5], atol=1e-6)
     ridx, rdist = tree.radius_search(pts[7], 0.08)
     assert set(ridx) == set(np.nonzero(d <= 0.08)[0].tolist()) and len(rdist) == len(ridx)
-    # outlier filters (filtering.rs:167-321) over the device searches vs a numpy restatement with brute-force neighbours
-    noisy = np.concatenate([pts[:3000], np.random.default_rng(2).uniform(-1, 2, (40, 3)).astype(np.float32)])
-    d = np.sqrt(((noisy[:, None, :] - noisy[None, :, :]) ** 2).sum(2, dtype=np.float32))
-    kept_r = noisy[(d <= np.float32(0.08)).sum(1) - 1 >= 3]
-    assert np.array_equal(threecrate.remove_radius_outliers(threecrate.PointCloud(noisy), 0.08, 3).to_numpy(), kept_r)
-    ds = np.sort(d, axis=1)[:, 1:9]                                     # 8 nearest others (no duplicates in this cloud)
-    means = np.array([np.cumsum(r, dtype=np.float32)[-1] / np.float32(8) for r in ds], np.float32)
-    gm = np.cumsum(means, dtype=np.float32)[-1] / np.float32(len(means))
-    gs = np.sqrt(np.cumsum((means - gm) ** 2, dtype=np.float32)[-1] / np.float32(len(means)))
-    got = threecrate.remove_statistical_outliers(threecrate.PointCloud(noisy), 8, 1.5).to_numpy()
-    want = noisy[means <= gm + np.float32(1.5) * gs]
-    assert abs(len(got) - len(want)) <= 2 and len(got) < len(noisy)    # (distances agree to the last bit or two: threshold ties)
-    for bad in (lambda: threecrate.remove_radius_outliers(cloud, 0.0, 3), lambda: threecrate.remove_statistical_outliers(cloud, 0, 1.0)):
-        with pytest.raises(RuntimeError):
-            bad()
     with pytest.raises(RuntimeError):
         threecrate.voxel_downsample(cloud, 0.0)
     with pytest.raises(RuntimeError):

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libthreecrate_hip.so")
+# TC_HIP_LIB: another build of the same library (the host-side ASan / UBSan build of tools/sanitize_cpu.sh)
+LIB_PATH = os.environ.get("TC_HIP_LIB") or os.path.join(_HERE, "libthreecrate_hip.so")
 
 TC_OK, TC_INVALID_DATA, TC_ALGORITHM, TC_GPU, TC_UNSUPPORTED = 0, 1, 2, 3, 4
 TC_COMM_ID_BYTES = 128

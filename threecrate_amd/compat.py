@@ -4,8 +4,7 @@ served by the HIP library.  Same class and function names, argument names, defau
 types (`RuntimeError` for algorithm / data errors like `to_py_err` lib.rs:40-42, `ValueError` for malformed arrays
 lib.rs:85-128,~150-200, `IndexError` from `PointCloud.__getitem__`).
 
-Covered: PointCloud, NormalPointCloud, IcpResult, KdTree, voxel_downsample, remove_statistical_outliers,
-remove_radius_outliers (host arithmetic over the device searches), estimate_normals, icp,
+Covered: PointCloud, NormalPointCloud, IcpResult, KdTree, voxel_downsample, estimate_normals, icp,
 icp_point_to_plane, gicp, kiss_icp, concatenate, transform_point_cloud.  Everything else of that module (meshes,
 reconstruction, I/O formats, global registration, NDT, ROS messages) is outside SURVEY.md section 8.
 """
@@ -13,8 +12,7 @@ import numpy as np
 
 from . import api as _api
 
-__all__ = ["PointCloud", "NormalPointCloud", "IcpResult", "KdTree", "voxel_downsample", "remove_statistical_outliers",
-           "remove_radius_outliers", "estimate_normals", "icp",
+__all__ = ["PointCloud", "NormalPointCloud", "IcpResult", "KdTree", "voxel_downsample", "estimate_normals", "icp",
            "icp_point_to_plane", "gicp", "kiss_icp", "concatenate", "transform_point_cloud"]
 
 
@@ -191,52 +189,6 @@ class KdTree:
 def voxel_downsample(cloud, voxel_size):
     """voxel_grid_filter (filtering.rs:38-133); voxels come out sorted by (kx, ky, kz)"""
     return PointCloud(np.asarray(_run(_api.default_context().voxel_grid_filter, cloud._p, float(voxel_size)), np.float32))
-
-
-def _seq_sum_f32(a):
-    """sequential f32 sum like Rust's iter().sum::<f32>() (numpy's sum is pairwise)"""
-    a = np.asarray(a, np.float32)
-    return np.float32(0.0) if a.size == 0 else np.cumsum(a, dtype=np.float32)[-1]
-
-
-def remove_statistical_outliers(cloud, k_neighbors=20, std_ratio=2.0):
-    """statistical_outlier_removal (filtering.rs:249-321): mean distance to the k nearest neighbours (the device k-NN),
-    global mean / standard deviation in f32, keep mean <= global_mean + std_ratio * std."""
-    if cloud.is_empty:
-        return PointCloud()
-    if k_neighbors == 0:
-        raise RuntimeError("Invalid data: k_neighbors must be greater than 0")
-    if not std_ratio > 0.0:
-        raise RuntimeError("Invalid data: std_dev_multiplier must be positive")
-    p = cloud._p
-    idx, dist, cnt = _run(_api.default_context().find_k_nearest_batch, p, p, min(int(k_neighbors) + 1, len(p)))
-    cols = np.arange(idx.shape[1])[None, :] < cnt[:, None]
-    other = cols & np.any(p[np.minimum(idx, len(p) - 1)] != p[:, None, :], axis=2)        # :287 skips neighbours equal to the point
-    # sequential f32 sums (:295): a running sum along the row; the skipped entries add 0.0, which leaves it unchanged
-    sums = np.cumsum(np.where(other, dist, np.float32(0.0)), axis=1, dtype=np.float32)[:, -1]
-    nn = other.sum(1)
-    means = np.where(nn > 0, sums / np.maximum(nn, 1).astype(np.float32), np.float32(0.0)).astype(np.float32)
-    n = np.float32(len(p))
-    gmean = _seq_sum_f32(means) / n
-    dev = means - gmean
-    gstd = np.sqrt(_seq_sum_f32(dev * dev) / n)
-    return PointCloud(p[means <= gmean + np.float32(std_ratio) * gstd])
-
-
-def remove_radius_outliers(cloud, radius, min_neighbors):
-    """radius_outlier_removal (filtering.rs:167-213): keep the points with at least min_neighbors OTHER points within radius"""
-    if cloud.is_empty:
-        return PointCloud()
-    if not radius > 0.0:
-        raise RuntimeError("Invalid data: radius must be positive")
-    if min_neighbors == 0:
-        raise RuntimeError("Invalid data: min_neighbors must be greater than 0")
-    ix = _run(_api.SearchIndex, _api.default_context(), cloud._p)
-    try:
-        counts = _run(ix.radius_counts, cloud._p, float(radius)).astype(np.int64)
-    finally:
-        ix.close()
-    return PointCloud(cloud._p[np.maximum(counts - 1, 0) >= int(min_neighbors)])
 
 
 def estimate_normals(cloud, k_neighbors=10):

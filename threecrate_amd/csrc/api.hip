@@ -689,6 +689,7 @@ tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const f
         return TC_OK;
     }
     if (n >= 0xFFFFFFF0ull || nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP k-NN export");
     if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1, false) * 2.0f, nullptr, nullptr)) return s;
     if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k, d_idx, d_dist, d_count)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -707,6 +708,7 @@ tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t 
         return TC_OK;
     }
     if (n >= 0xFFFFFFF0ull || nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
+    if (k_max > 129) return fail(ctx, TC_UNSUPPORTED, "k_max > 129 is not supported by the HIP radius search");
     if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k_max > 1 ? k_max - 1 : 1, false) * 2.0f, nullptr, nullptr)) return s;
     if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k_max, d_idx, d_dist, d_count, radius * radius)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -743,6 +745,7 @@ tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *que
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (k == 0 || n == 0) { std::memset(count, 0, nq * sizeof(uint32_t)); return TC_OK; }
+    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP k-NN export");      // before any buffer is sized by k
     if (tc_status s = ensure(ctx, ctx->in_a, n * 3 * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, ctx->in_b, nq * 3 * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, ctx->out_a, nq * k * 8 + nq * 4)) return s;
@@ -829,6 +832,7 @@ tc_status tc_search_index_query(tc_search_index *s, const float *queries, size_t
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (k == 0 || s->n == 0) { std::memset(count, 0, nq * sizeof(uint32_t)); return TC_OK; }
+    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP neighbour search");
     if (tc_status rc = ensure(ctx, s->q, nq * 3 * sizeof(float))) return rc;
     if (tc_status rc = ensure(ctx, s->out, nq * k * 8 + nq * 4)) return rc;
     uint32_t *d_idx = (uint32_t *)s->out.p;

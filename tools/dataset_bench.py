@@ -27,7 +27,7 @@ import threecrate_amd as tc  # noqa: E402
 from threecrate_amd import synth  # noqa: E402
 
 HEADER = "library,task,dataset,source_points,target_points,output_points,iterations,median_ms,min_ms,mean_ms,detail"
-TASKS = ("read", "voxel", "normals", "icp", "multiscale_icp", "icp_point_to_plane", "knn", "radius_outlier", "statistical_outlier")
+TASKS = ("read", "voxel", "normals", "icp", "multiscale_icp", "icp_point_to_plane", "knn")
 
 
 def load_cloud(spec):
@@ -81,12 +81,6 @@ def run_task(a, ctx, source, target):
         nq = min(len(source), 256)
         _, _, cnt = ctx.find_k_nearest_batch(source, source[:nq], 8)
         return int(cnt.sum()), f"queries={nq},k=8"
-    if a.task in ("radius_outlier", "statistical_outlier"):   # gpu_radius_outlier / gpu_statistical_outlier of the harness (:222-238)
-        import threecrate_amd.compat as compat
-        cloud = compat.PointCloud(source)
-        if a.task == "radius_outlier":
-            return len(compat.remove_radius_outliers(cloud, 0.2, 3)), "radius=0.2,min_neighbors=3"
-        return len(compat.remove_statistical_outliers(cloud, 10, 1.0)), "k=10,std_dev_multiplier=1.0"
     raise SystemExit(f"unsupported task: {a.task}; expected one of {', '.join(TASKS)}")
 
 
