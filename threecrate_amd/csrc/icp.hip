@@ -421,7 +421,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
-    double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov, const float *__restrict__ vor) {
+    double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov, const float4 *__restrict__ vor) {
     constexpr bool P2PLANE = MODE == 1;
     constexpr int NACC = MODE == 0 ? TC_ICP_SUMS_P2P : TC_ICP_SUMS_P2PLANE;
     if (st->done) return;
@@ -453,6 +453,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
         float px[kIcpGroup], py[kIcpGroup], pz[kIcpGroup], ubp[kIcpGroup];
         uint32_t pjv[kIcpGroup], mv[kIcpGroup];
         bool fin[kIcpGroup];
+        float4 pv[kIcpGroup];                 // the previous matches' records: reused in stage 4 when the match did not change
         {   // ---- stage 1 + 2 ----
             float4 sv[kIcpGroup];
 #pragma unroll
@@ -465,23 +466,23 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
                 pjv[u] = pj;
                 fin[u] = in && sv[u].x < 3.0e38f;              // a non-finite source point (placeholder record, grid.hip) has no match
             }
-            float4 pv[kIcpGroup];
-            float vrv[kIcpGroup];
+            // the previous match's record: from `vor` when it exists -- the same x, y, z with the inscribed-ball bound in w, ONE
+            // 16-byte gather instead of record + bound from two arrays (the pass is bound by cache-line accesses as much as by
+            // instructions) -- else from the index (its w is the original index: no bound yet)
+            const float4 *__restrict__ prec = vor != nullptr ? vor : tgt.pts;
 #pragma unroll
-            for (int u = 0; u < kIcpGroup; ++u) {
-                pv[u] = tgt.pts[pjv[u] != 0xFFFFFFFFu ? pjv[u] : 0u];
-                vrv[u] = (vor != nullptr && pjv[u] != 0xFFFFFFFFu) ? vor[pjv[u]] : 0.0f;
-            }
+            for (int u = 0; u < kIcpGroup; ++u) pv[u] = prec[pjv[u] != 0xFFFFFFFFu ? pjv[u] : 0u];
 #pragma unroll
             for (int u = 0; u < kIcpGroup; ++u) {
                 iso_apply(q, t, sv[u].x, sv[u].y, sv[u].z, px[u], py[u], pz[u]);
                 // warm start: the previous match is a real target point, its distance bounds the new nearest-neighbour distance
                 const float d = pjv[u] != 0xFFFFFFFFu ? d2_nc(pv[u].x, pv[u].y, pv[u].z, px[u], py[u], pz[u]) : INFINITY;
+                const float vr = (vor != nullptr && pjv[u] != 0xFFFFFFFFu) ? pv[u].w : 0.0f;
                 // Inscribed-ball test (exact): vor[p] = a quarter of the squared distance from target point p to its nearest OTHER
                 // target point (shaved).  |T s - p| < d_nn(p) / 2 puts every other target point t at |T s - t| >= d_nn(p) - |T s - p|
                 // > |T s - p|: the previous match is still THE nearest neighbour, nothing has to be searched.  The flag travels
                 // in the sign bit of the (non-negative) bound.
-                ubp[u] = (d < vrv[u]) ? -d : d;
+                ubp[u] = (d < vr) ? -d : d;
             }
         }
         // ---- stage 3 ----
@@ -533,7 +534,8 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int u = 0; u < kIcpGroup; ++u) {
                 const uint32_t m = mv[u] != 0xFFFFFFFFu ? mv[u] : 0u;
-                cv[u] = tgt.pts[m];
+                cv[u] = pv[u];
+                if (mv[u] != pjv[u]) cv[u] = tgt.pts[m];          // only a CHANGED match is gathered again
                 nv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (MODE == 1) nv[u] = tgt_nrm[m];
             }
@@ -873,7 +875,7 @@ __global__ void __launch_bounds__(kIcpBlock) icp_final_mse_kernel(GridView tgt, 
 // along some axis, also in a clamped grid: the boundary cells are part of the block when they are adjacent).  Squared distances
 // computed like every other one here (d2_nc: relative error 4 ulp at most, the subtraction of two floats is exact to half an
 // ulp of the DIFFERENCE), so the 1e-4 shave keeps the inscribed-ball test strict.  Duplicate points get 0: never skipped.
-__global__ void __launch_bounds__(256) icp_target_nn_bound_kernel(GridView tgt, float *__restrict__ vor, const IcpState *__restrict__ st) {
+__global__ void __launch_bounds__(256) icp_target_nn_bound_kernel(GridView tgt, float4 *__restrict__ vor, const IcpState *__restrict__ st) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const GridGeom &g = tgt.g;
     if (p >= g.n || (st && st->done)) return;
@@ -892,7 +894,7 @@ __global__ void __launch_bounds__(256) icp_target_nn_bound_kernel(GridView tgt, 
                 m = (j != p) ? fminf(m, v) : m;            // fminf ignores a NaN candidate
             }
         }
-    vor[p] = 0.25f * 0.9999f * m;
+    vor[p] = make_float4(q.x, q.y, q.z, 0.25f * 0.9999f * m);       // record + bound in one 16-byte gather of the main pass
 }
 
 // ---- small f64 solvers (one lane) -----------------------------------------------------------
@@ -1266,7 +1268,7 @@ static TileGeom plan_tiles(const GridGeom &g, size_t ns) {
 static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, const float4 *nrm, const float4 *src,
                              uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr_pos, uint32_t *rlist,
                              double *partials, bool do_sum, bool do_apply, bool do_reduce, const float4 *src_cov = nullptr,
-                             const float *vor = nullptr) {
+                             const float4 *vor = nullptr) {
     hipStream_t s = ctx->stream;
     const int dbg = debug_flags();
     double *refine_rows = partials + (size_t)l.nblocks * TC_ICP_SUMS_STRIDE;
@@ -1297,17 +1299,17 @@ static size_t vor_after() {
     static const size_t v = [] { const char *e = getenv("TC_VOR_AFTER"); return e ? (size_t)atoi(e) : (size_t)6; }();
     return v;
 }
-static tc_status launch_target_nn_bounds(tc_context *ctx, DeviceIndex &ix, const GridView &tv, const IcpState *st, const float **out) {
+static tc_status launch_target_nn_bounds(tc_context *ctx, DeviceIndex &ix, const GridView &tv, const IcpState *st, const float4 **out) {
     *out = nullptr;
-    if (ix.vor_valid) { *out = (const float *)ix.vor.p; return TC_OK; }      // a cloud handle that has been a target before
-    if (tc_status s = ensure(ctx, ix.vor, (size_t)ix.geom.n * sizeof(float))) return s;
+    if (ix.vor_valid) { *out = (const float4 *)ix.vor.p; return TC_OK; }      // a cloud handle that has been a target before
+    if (tc_status s = ensure(ctx, ix.vor, (size_t)ix.geom.n * sizeof(float4))) return s;
     ProfScope ps(ctx, "icp_target_nn_bounds");
     // (st == nullptr: unconditional; otherwise skipped once the registration is done)
     const bool persistent = &ix != &ctx->tgt_index;          // a cloud handle's index: the bounds are kept for its later registrations
-    hipLaunchKernelGGL(icp_target_nn_bound_kernel, dim3((ix.geom.n + 255) / 256), dim3(256), 0, ctx->stream, tv, (float *)ix.vor.p,
+    hipLaunchKernelGGL(icp_target_nn_bound_kernel, dim3((ix.geom.n + 255) / 256), dim3(256), 0, ctx->stream, tv, (float4 *)ix.vor.p,
                        persistent ? nullptr : st);
     ix.vor_valid = persistent;
-    *out = (const float *)ix.vor.p;
+    *out = (const float4 *)ix.vor.p;
     return TC_OK;
 }
 
@@ -1447,7 +1449,7 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     const float4 *nrm = (const float4 *)(*su.tix).normals.p;
 
     size_t enq = 0;
-    const float *vor = nullptr;
+    const float4 *vor = nullptr;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
             if (enq++ == vor_after())
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
@@ -1522,7 +1524,7 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     const float4 *src = (const float4 *)ctx->src_index.pts.p + lo;
     const float4 *nrm = (const float4 *)(*su.tix).normals.p;
     size_t enq = 0;
-    const float *vor = nullptr;
+    const float4 *vor = nullptr;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
             if (enq++ == vor_after())
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;

@@ -116,7 +116,7 @@ struct DeviceIndex {
     DevBuf pts;         // float4 * n   (cell-sorted, w = original index bits)
     DevBuf cell_start;  // u32 * (ncell+1)
     DevBuf normals;     // float4 * n   (cell-sorted target normals; optional)
-    DevBuf vor;         // float * n    (ICP target: inscribed-ball bounds, icp_target_nn_bound_kernel; optional)
+    DevBuf vor;         // float4 * n   (ICP target: x, y, z + inscribed-ball bound, icp_target_nn_bound_kernel; optional)
     bool vor_valid = false;     // vor belongs to the current contents of pts (build_index resets it)
     DevBuf cell_of;     // u32 * n      (scratch: cell id per original point)
     DevBuf slot;        // u32 * n      (scratch: atomic scatter order)
