@@ -416,16 +416,25 @@ def test_frame_stream_matches_per_frame_calls(ctx):
     res, m = fs.finish()
     assert m.items_queued == 5 and m.items_processed == 5 and m.items_dropped == 0 and 1 <= m.max_depth_seen <= 2
     assert len(res) == 4 and all(r.status == 0 for r in res)
-    # the same pipeline, call by call
+    # the same pipeline, call by call through the cloud handles the stream uses internally (bit for bit), and through the
+    # handle-free calls (another grid for the target -> the same pairs summed in another tree: equal to rounding)
     prev = ctx.voxel_grid_filter(frames[0], 0.25)
+    prev_h = tc.Cloud(ctx, prev)
+    prev_h.estimate_normals(16, out=False)
     for i in range(1, 5):
         cur = ctx.voxel_grid_filter(frames[i], 0.25)
-        nrm = ctx.estimate_normals(prev, 16)
-        r = ctx.icp_point_to_plane_detailed(cur, prev, nrm, None, 30, 2.0, 1e-6, correspondences=False)
+        cur_h = tc.Cloud(ctx, cur)
+        r = cur_h.icp_point_to_plane(prev_h, None, 30, 2.0, 1e-6)
         assert res[i - 1].n_points == len(cur) and res[i - 1].n_points_in == len(frames[i])
         assert res[i - 1].iterations == r.iterations and res[i - 1].converged == r.converged
         assert np.array_equal(res[i - 1].transformation, r.transformation) and res[i - 1].mse == r.mse
-        prev = cur
+        nrm = ctx.estimate_normals(prev, 16)
+        p = ctx.icp_point_to_plane_detailed(cur, prev, nrm, None, 30, 2.0, 1e-6, correspondences=False)
+        assert frob(p.transformation, r.transformation, O.isometry_to_matrix) <= 1e-5 and abs(p.iterations - r.iterations) <= 1
+        cur_h.estimate_normals(16, out=False)
+        prev_h.close()
+        prev, prev_h = cur, cur_h
+    prev_h.close()
     # try_send never blocks: with a queue of 1 and a burst of frames some are dropped, none are lost silently
     fs = tc.FrameStream(ctx, max_points=130000, voxel_size=0.25, max_iterations=30, max_correspondence_distance=2.0,
                         backpressure=tc.BackpressureConfig(max_queue_depth=1))

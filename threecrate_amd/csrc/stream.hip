@@ -38,7 +38,7 @@ struct tc_frame_stream {
     hipEvent_t landed[2] = {nullptr, nullptr};
     float *d_raw[2] = {nullptr, nullptr};       // frames as received
     float *d_frame[2] = {nullptr, nullptr};     // filtered: current / previous
-    float *d_nrm = nullptr;                     // NormalPoint3f of the previous frame
+    tc_cloud *prev_h = nullptr;                 // the previous frame: points + index + cell-sorted normals
     std::vector<tc_frame_result> results;
     tc_frame_stream_metrics metrics{};
     tc_status worker_status = TC_OK;
@@ -60,7 +60,6 @@ void worker_main(tc_frame_stream *s) {
     if (hipSetDevice(ctx->device) != hipSuccess) { s->worker_status = TC_GPU; return; }
     const tc_frame_stream_config &c = s->cfg;
     int cur = 0;                    // index into d_frame: current; the other one holds the previous frame
-    size_t n_prev = 0;
     bool have_prev = false;
     int pre_slot = -1, pre_buf = -1;            // a frame whose copy has already been issued
     int raw = 0;
@@ -108,11 +107,14 @@ void worker_main(tc_frame_stream *s) {
         if (c.voxel_size <= 0.0f) (void)hipStreamSynchronize(ctx->stream);
         release_slot(s, slot);
         r.n_points = n_cur;
+        // Every frame lives in a cloud handle (tc_cloud_*): it is indexed ONCE, when its normals are estimated, and that index +
+        // the cell-sorted normals are what the NEXT frame registers against (the handle-free calls would index it twice).
+        tc_cloud *cur_h = nullptr;
+        if (st == TC_OK) st = tc_cloud_upload_device(ctx, s->d_frame[cur], n_cur, &cur_h);
         if (st == TC_OK && have_prev) {
             tc_icp_result ir{};
             const float ident[7] = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
-            st = tc_icp_point_to_plane_detailed_device(ctx, s->d_frame[cur], n_cur, s->d_frame[cur ^ 1], n_prev, s->d_nrm + 3 /* normal of NormalPoint3f */, n_prev, 6, ident,
-                                                       c.max_iterations, c.max_correspondence_distance, c.convergence_threshold, &ir);
+            st = tc_cloud_icp_point_to_plane(cur_h, s->prev_h, ident, c.max_iterations, c.max_correspondence_distance, c.convergence_threshold, &ir);
             std::memcpy(r.transformation, ir.transformation, sizeof(r.transformation));
             r.mse = ir.mse; r.iterations = ir.iterations; r.converged = ir.converged;
         }
@@ -121,7 +123,13 @@ void worker_main(tc_frame_stream *s) {
             tc_normal_config nc;
             tc_normal_config_default(&nc);
             nc.k_neighbors = c.k_neighbors;
-            st = tc_estimate_normals_device(ctx, s->d_frame[cur], n_cur, &nc, s->d_nrm);
+            st = tc_cloud_estimate_normals_device(cur_h, &nc, nullptr);
+        }
+        if (st == TC_OK) {
+            tc_cloud_destroy(s->prev_h);              // (its blocks go back to the context's pool: no allocation per frame)
+            s->prev_h = cur_h;
+        } else {
+            tc_cloud_destroy(cur_h);
         }
         r.status = st;
         {
@@ -129,7 +137,7 @@ void worker_main(tc_frame_stream *s) {
             if (have_prev || st != TC_OK) s->results.push_back(r);
             s->metrics.items_processed += 1;
         }
-        if (st == TC_OK) { have_prev = true; n_prev = n_cur; cur ^= 1; }
+        if (st == TC_OK) { have_prev = true; cur ^= 1; }
     }
 }
 
@@ -199,7 +207,6 @@ tc_status tc_frame_stream_create(tc_context *ctx, const tc_frame_stream_config *
         if (hipMalloc((void **)&s->d_raw[b], bytes) != hipSuccess) return bail("device frame");
         if (hipMalloc((void **)&s->d_frame[b], bytes) != hipSuccess) return bail("device frame");
     }
-    if (hipMalloc((void **)&s->d_nrm, cfg->max_points * 6 * sizeof(float)) != hipSuccess) return bail("device normals");
     s->worker = std::thread(worker_main, s);
     *out = s;
     return TC_OK;
@@ -245,7 +252,7 @@ void tc_frame_stream_destroy(tc_frame_stream *s) {
         if (s->d_raw[b]) (void)hipFree(s->d_raw[b]);
         if (s->d_frame[b]) (void)hipFree(s->d_frame[b]);
     }
-    if (s->d_nrm) (void)hipFree(s->d_nrm);
+    if (s->prev_h) tc_cloud_destroy(s->prev_h);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     delete s;
 }
