@@ -203,7 +203,7 @@ def aux_modes(args):
         t_normals = (time.perf_counter() - tn0) / 3.0
 
         def step():
-            return D.sharded_icp_point_to_plane(ctx, src, tgt, nrm, None, ICP_ITERS, None, 0.0, comm=comm, correspondences=True)
+            return D.sharded_icp_point_to_plane(ctx, src, tgt, nrm, None, ICP_ITERS, None, 0.0, comm=comm, correspondences="device")
         for _ in range(max(args.warmup, 1)):
             step()
         torch.cuda.synchronize()
@@ -229,7 +229,7 @@ def aux_modes(args):
                               "config": {"workload": f"{n}-pt uniform cloud [0,10)x[0,10)x[0,1) (BASELINE configs[3]), 50-iter p2plane ICP, "
                                                      "source sharded spatially over the ranks, correspondences gathered",
                                          "points": n, "parallelism": f"shard{world}"},
-                              "transform_frobenius_error_vs_truth": err, "n_correspondences": int((r.corr_target != 0xFFFFFFFF).sum()),
+                              "transform_frobenius_error_vs_truth": err, "n_correspondences": int((r.corr_target != -1).sum()),
                               "sharded_normals_ms": 1e3 * t_normals, "sharded_normals_mpts_per_s": n / t_normals / 1e6}))
         comm.close()
     else:

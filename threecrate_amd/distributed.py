@@ -205,7 +205,7 @@ def _icp_args(ctx, source, target, init, max_correspondence_distance):
 
 def _finish(ctx, r, corr, correspondences):
     import torch
-    if corr is not None:
+    if corr is not None and correspondences != "device":      # "device": the dense per-source index stays as written (int32 bits, -1 = none)
         corr = corr.to(torch.int64) & 0xFFFFFFFF
     return ctx._result(r, 0, corr, correspondences)
 
