@@ -1,10 +1,21 @@
-//! Raw declarations of include/threecrate_hip.h (keep in sync with the header; tc_abi_version() == 1).
+//! Raw declarations of include/threecrate_hip.h (keep in sync with the header; tc_abi_version() == 2).
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)] pub struct tc_context { _private: [u8; 0] }
 #[repr(C)] pub struct tc_frame_stream { _private: [u8; 0] }
 #[repr(C)] pub struct tc_search_index { _private: [u8; 0] }
+#[repr(C)] pub struct tc_comm { _private: [u8; 0] }
+#[repr(C)] pub struct tc_cloud { _private: [u8; 0] }
+
+pub const TC_COMM_ID_BYTES: usize = 128;
+pub const TC_SHARD_SPATIAL: c_int = 0;
+pub const TC_SHARD_LOCAL: c_int = 1;
+pub const TC_COLL_SUM_F64: c_int = 0;
+pub const TC_COLL_SUM_U32: c_int = 1;
+pub const TC_COLL_ALLGATHER_U8: c_int = 2;
+/// `int (*tc_host_collective_fn)(void *user, int op, void *host_buf, size_t count)`
+pub type tc_host_collective_fn = Option<unsafe extern "C" fn(user: *mut c_void, op: c_int, host_buf: *mut c_void, count: usize) -> c_int>;
 
 pub const TC_OK: c_int = 0;
 pub const TC_INVALID_DATA: c_int = 1;
@@ -112,4 +123,37 @@ extern "C" {
                                   metrics: *mut tc_frame_stream_metrics) -> c_int;
     pub fn tc_frame_stream_destroy(s: *mut tc_frame_stream);
     pub fn tc_read_kitti_bin(path: *const c_char, out_xyz: *mut f32, capacity_points: usize, n_points: *mut usize) -> c_int;
+    // ---- stream ordering, communicator, one registration over several GPUs ----
+    pub fn tc_context_wait_stream(ctx: *mut tc_context, other_hip_stream: *mut c_void) -> c_int;
+    pub fn tc_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn tc_comm_create(ctx: *mut tc_context, nranks: c_int, rank: c_int, id: *const u8, out: *mut *mut tc_comm) -> c_int;
+    pub fn tc_comm_adopt(ctx: *mut tc_context, nccl_comm: *mut c_void, nranks: c_int, rank: c_int, out: *mut *mut tc_comm) -> c_int;
+    pub fn tc_comm_create_host(ctx: *mut tc_context, nranks: c_int, rank: c_int, f: tc_host_collective_fn, user: *mut c_void,
+                               out: *mut *mut tc_comm) -> c_int;
+    pub fn tc_comm_create_local(ctx: *mut tc_context, out: *mut *mut tc_comm) -> c_int;
+    pub fn tc_comm_rank(comm: *const tc_comm) -> c_int;
+    pub fn tc_comm_size(comm: *const tc_comm) -> c_int;
+    pub fn tc_comm_destroy(comm: *mut tc_comm);
+    pub fn tc_sharded_icp_point_to_plane_device(ctx: *mut tc_context, comm: *mut tc_comm, shard_mode: c_int, d_src: *const f32, ns: usize,
+                                                d_tgt: *const f32, nt: usize, d_normals: *const f32, n_normals: usize, stride: usize,
+                                                init: *const f32, max_iters: usize, max_dist: f32, conv_thr: f32, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_sharded_icp_detailed_device(ctx: *mut tc_context, comm: *mut tc_comm, shard_mode: c_int, d_src: *const f32, ns: usize,
+                                          d_tgt: *const f32, nt: usize, init: *const f32, max_iters: usize, max_dist: f32, conv_thr: f32,
+                                          res: *mut tc_icp_result) -> c_int;
+    pub fn tc_sharded_estimate_normals_device(ctx: *mut tc_context, comm: *mut tc_comm, d_xyz: *const f32, n: usize,
+                                              cfg: *const tc_normal_config, d_out: *mut f32) -> c_int;
+    // ---- device-resident cloud handles ----
+    pub fn tc_cloud_upload(ctx: *mut tc_context, xyz: *const f32, n: usize, out: *mut *mut tc_cloud) -> c_int;
+    pub fn tc_cloud_upload_device(ctx: *mut tc_context, d_xyz: *const f32, n: usize, out: *mut *mut tc_cloud) -> c_int;
+    pub fn tc_cloud_size(cloud: *const tc_cloud) -> usize;
+    pub fn tc_cloud_points_device(cloud: *const tc_cloud) -> *const f32;
+    pub fn tc_cloud_normals_device(cloud: *const tc_cloud) -> *const f32;
+    pub fn tc_cloud_estimate_normals(cloud: *mut tc_cloud, cfg: *const tc_normal_config, out: *mut f32) -> c_int;
+    pub fn tc_cloud_estimate_normals_device(cloud: *mut tc_cloud, cfg: *const tc_normal_config, d_out: *mut f32) -> c_int;
+    pub fn tc_cloud_set_normals_device(cloud: *mut tc_cloud, d_normals: *const f32, n_normals: usize, stride: usize) -> c_int;
+    pub fn tc_cloud_icp_point_to_plane(source: *mut tc_cloud, target: *mut tc_cloud, init: *const f32, max_iters: usize, max_dist: f32,
+                                       conv_thr: f32, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_cloud_icp_detailed(source: *mut tc_cloud, target: *mut tc_cloud, init: *const f32, max_iters: usize, max_dist: f32,
+                                 conv_thr: f32, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_cloud_destroy(cloud: *mut tc_cloud);
 }

@@ -80,6 +80,16 @@ fn result_from(r: &ffi::tc_icp_result, corr: &[u32], n_valid: usize) -> ICPResul
     }
 }
 
+/// `Option<f32>` -> the ABI's encoding (< 0 = None).  A negative `Some(d)` must not alias `None`: the reference rejects every
+/// pair then (`distance > d` always holds, registration.rs:100-101) and fails with "Insufficient correspondences".
+fn encode_max_dist(d: Option<f32>) -> Result<f32> {
+    match d {
+        None => Ok(-1.0),
+        Some(v) if v < 0.0 => Err(Error::Algorithm("Insufficient correspondences found".to_string())),
+        Some(v) => Ok(v),
+    }
+}
+
 fn empty_result(corr: &mut Vec<u32>) -> ffi::tc_icp_result {
     ffi::tc_icp_result { transformation: [0.0; 7], mse: 0.0, iterations: 0, converged: 0, n_correspondences: 0, corr_target: corr.as_mut_ptr() }
 }
@@ -128,7 +138,7 @@ pub fn icp_detailed(ctx: &HipContext, source: &PointCloud<Point3f>, target: &Poi
     let i7 = iso_to7(&init);
     ctx.check(unsafe {
         ffi::tc_icp_detailed(ctx.0, xyz(source), ns, xyz(target), target.points.len(), i7.as_ptr(), max_iters,
-                             max_correspondence_distance.unwrap_or(-1.0), convergence_threshold, &mut r)
+                             encode_max_dist(max_correspondence_distance)?, convergence_threshold, &mut r)
     })?;
     Ok(result_from(&r, &corr, ns))
 }
@@ -151,7 +161,7 @@ pub fn icp_point_to_point(ctx: &HipContext, source: &PointCloud<Point3f>, target
     let i7 = iso_to7(&init);
     ctx.check(unsafe {
         ffi::tc_icp_point_to_point(ctx.0, xyz(source), ns, xyz(target), target.points.len(), i7.as_ptr(), max_iterations,
-                                   convergence_threshold, max_correspondence_distance.unwrap_or(-1.0), &mut r)
+                                   convergence_threshold, encode_max_dist(max_correspondence_distance)?, &mut r)
     })?;
     Ok(result_from(&r, &corr, ns))
 }
@@ -167,7 +177,7 @@ pub fn icp_point_to_plane_detailed(ctx: &HipContext, source: &PointCloud<Point3f
     ctx.check(unsafe {
         ffi::tc_icp_point_to_plane_detailed(ctx.0, xyz(source), ns, xyz(target), target.points.len(),
                                             target_normals.as_ptr() as *const f32, target_normals.len(), 3, i7.as_ptr(), max_iters,
-                                            max_correspondence_distance.unwrap_or(-1.0), convergence_threshold, &mut r)
+                                            encode_max_dist(max_correspondence_distance)?, convergence_threshold, &mut r)
     })?;
     Ok(result_from(&r, &corr, ns))
 }
@@ -305,4 +315,90 @@ pub fn gpu_icp(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointClo
 /// `gpu_estimate_normals(&ctx, &mut cloud, k)`
 pub fn gpu_estimate_normals(ctx: &HipContext, cloud: &mut PointCloud<Point3f>, k: usize) -> Result<PointCloud<NormalPoint3f>> {
     estimate_normals(ctx, cloud, k)
+}
+
+
+// ---- device-resident cloud handles (include/threecrate_hip.h "tc_cloud": SURVEY.md 8b) ---------------------------------
+
+/// A cloud that lives in HBM, is indexed once and keeps its normals in the layout the ICP kernels read.
+/// `let prev = HipCloud::upload(&ctx, &frame0)?; prev.estimate_normals(16)?; let cur = HipCloud::upload(&ctx, &frame1)?;
+///  let r = cur.icp_point_to_plane(&prev, Isometry3::identity(), 50, None, 1e-6)?;`
+pub struct HipCloud<'a> { raw: *mut ffi::tc_cloud, ctx: &'a HipContext }
+
+impl<'a> HipCloud<'a> {
+    pub fn upload(ctx: &'a HipContext, cloud: &PointCloud<Point3f>) -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        ctx.check(unsafe { ffi::tc_cloud_upload(ctx.0, xyz(cloud), cloud.points.len(), &mut raw) })?;
+        Ok(HipCloud { raw, ctx })
+    }
+    pub fn len(&self) -> usize { unsafe { ffi::tc_cloud_size(self.raw) } }
+    pub fn is_empty(&self) -> bool { self.len() == 0 }
+    /// `estimate_normals` (normals.rs:238-241); the normals stay with the handle, nothing is copied back
+    pub fn estimate_normals(&self, k: usize) -> Result<()> {
+        let mut cfg = unsafe { std::mem::zeroed::<ffi::tc_normal_config>() };
+        unsafe { ffi::tc_normal_config_default(&mut cfg) };
+        cfg.k_neighbors = k as u64;
+        self.ctx.check(unsafe { ffi::tc_cloud_estimate_normals(self.raw, &cfg, std::ptr::null_mut()) })
+    }
+    /// `icp_point_to_plane_detailed` (registration.rs:508-516) with `self` as the source and the target handle's normals
+    pub fn icp_point_to_plane(&self, target: &HipCloud, init: Isometry3<f32>, max_iters: usize, max_correspondence_distance: Option<f32>,
+                              convergence_threshold: f32) -> Result<ICPResult> {
+        let mut none = Vec::new();
+        let mut r = empty_result(&mut none);
+        r.corr_target = std::ptr::null_mut();            // (device memory when wanted: see the header)
+        let i7 = iso_to7(&init);
+        self.ctx.check(unsafe {
+            ffi::tc_cloud_icp_point_to_plane(self.raw, target.raw, i7.as_ptr(), max_iters, encode_max_dist(max_correspondence_distance)?,
+                                             convergence_threshold, &mut r)
+        })?;
+        Ok(result_from(&r, &[], 0))
+    }
+}
+
+impl Drop for HipCloud<'_> {
+    fn drop(&mut self) { unsafe { ffi::tc_cloud_destroy(self.raw) } }
+}
+
+// ---- one registration over the GPUs of a node: one process or thread per GPU ------------------------------
+
+/// RCCL communicator of this rank, bound to the context's stream.  Rank 0 calls `HipComm::unique_id()`, the host distributes the
+/// 128 bytes (pipe, file, MPI ...), every rank calls `HipComm::create`.
+pub struct HipComm<'a> { raw: *mut ffi::tc_comm, ctx: &'a HipContext }
+
+impl<'a> HipComm<'a> {
+    pub fn unique_id() -> Result<[u8; ffi::TC_COMM_ID_BYTES]> {
+        let mut id = [0u8; ffi::TC_COMM_ID_BYTES];
+        match unsafe { ffi::tc_comm_unique_id(id.as_mut_ptr()) } {
+            ffi::TC_OK => Ok(id),
+            _ => Err(Error::Unsupported("RCCL is not available to libthreecrate_hip".to_string())),
+        }
+    }
+    pub fn create(ctx: &'a HipContext, nranks: i32, rank: i32, id: &[u8; ffi::TC_COMM_ID_BYTES]) -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        ctx.check(unsafe { ffi::tc_comm_create(ctx.0, nranks, rank, id.as_ptr(), &mut raw) })?;
+        Ok(HipComm { raw, ctx })
+    }
+    pub fn rank(&self) -> i32 { unsafe { ffi::tc_comm_rank(self.raw) } }
+    pub fn size(&self) -> i32 { unsafe { ffi::tc_comm_size(self.raw) } }
+
+    /// `icp_point_to_plane_detailed` of ONE cloud pair over all ranks: every rank passes the same device-resident clouds
+    /// (pointers to n x 3 floats in HBM), the library shards the source spatially and runs one ncclAllReduce of the packed
+    /// 6x6 system per iteration on the compute stream.  Every rank returns the same result.
+    #[allow(clippy::too_many_arguments)]
+    pub unsafe fn icp_point_to_plane_device(&self, d_source: *const f32, n_source: usize, d_target: *const f32, n_target: usize,
+                                            d_target_normals: *const f32, normal_stride: usize, init: Isometry3<f32>, max_iters: usize,
+                                            max_correspondence_distance: Option<f32>, convergence_threshold: f32) -> Result<ICPResult> {
+        let mut none = Vec::new();
+        let mut r = empty_result(&mut none);
+        r.corr_target = std::ptr::null_mut();
+        let i7 = iso_to7(&init);
+        self.ctx.check(ffi::tc_sharded_icp_point_to_plane_device(self.ctx.0, self.raw, ffi::TC_SHARD_SPATIAL, d_source, n_source, d_target,
+                                                                  n_target, d_target_normals, n_target, normal_stride, i7.as_ptr(), max_iters,
+                                                                  encode_max_dist(max_correspondence_distance)?, convergence_threshold, &mut r))?;
+        Ok(result_from(&r, &[], 0))
+    }
+}
+
+impl Drop for HipComm<'_> {
+    fn drop(&mut self) { unsafe { ffi::tc_comm_destroy(self.raw) } }
 }
