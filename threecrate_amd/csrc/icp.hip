@@ -416,7 +416,9 @@ __host__ __device__ __forceinline__ uint4 *refine_entries(uint32_t *rlist) {
 // MODE: 0 point-to-point, 1 point-to-plane (tgt_nrm = target normals in cell order), 2 GICP (tgt_nrm = target
 // covariances, two float4 per cell-sorted position; src_cov = source covariances in the source's sorted order)
 // 4 waves per SIMD = the launch geometry (one round of 1024 blocks of 4 waves on 1024 SIMDs): the register allocator may use up
-// to 128 VGPRs and must not use more (a 3-wave kernel needs a second round of blocks: +20-40 %)
+// to 128 VGPRs and must not use more (a 3-wave kernel needs a second round of blocks: +20-40 %).  Measured the other way too:
+// pinned to 5 / 6 waves (96 / 80 VGPRs, 96 / 192 bytes of scratch) with 5 / 6 blocks per CU the pass takes 54.6 / 68.4 us
+// instead of 46.5: the kernel is register limited, spills cost more than the extra waves hide.
 template <int MODE>
 __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
