@@ -564,7 +564,7 @@ def test_dataset_bench_emits_reference_csv_row(tmp_path, capsys):
     rec = np.concatenate([pts, np.zeros((len(pts), 1), np.float32)], axis=1).astype("<f4")
     path = tmp_path / "000000.bin"
     rec.tofile(path)
-    for task in ("voxel", "normals", "icp", "multiscale_icp", "knn", "radius_outlier", "statistical_outlier"):
+    for task in ("voxel", "normals", "icp", "multiscale_icp", "knn"):
         mod.main(["--task", task, "--dataset", "unit,test", "--source", str(path), "--iterations", "2", "--warmups", "1",
                   "--max-points", "2000", "--max-icp-iters", "5"])
         out = capsys.readouterr().out.strip().splitlines()
