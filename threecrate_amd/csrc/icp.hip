@@ -423,8 +423,11 @@ template <int MODE>
 __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
-    double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov, const float4 *__restrict__ vor) {
+    double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov, const float4 *__restrict__ vor,
+    unsigned long long *__restrict__ blk_times) {
     constexpr bool P2PLANE = MODE == 1;
+    unsigned long long t_begin = 0;
+    if (blk_times) t_begin = __builtin_amdgcn_s_memrealtime();          // TC_DEBUG & 1024: per-block start / end stamps (100 MHz)
     constexpr int NACC = MODE == 0 ? TC_ICP_SUMS_P2P : TC_ICP_SUMS_P2PLANE;
     if (st->done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
@@ -444,6 +447,11 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane < TC_ICP_SUMS_STRIDE) red[w][lane] = 0.0;          // each wave owns one row
 
+    // One contiguous chunk per block.  Measured alternatives (TC_DEBUG & 1024 stamps every block): with one round of 984 blocks
+    // the slowest block takes 1.17x (clouds moving) to 1.6x (aligned) the median, all of them start within 0.4 us.  That spread is
+    // NOT the work: spreading every block's four 256-point sub-chunks over its XCD's whole slab left it unchanged (p10 / p50 / max
+    // 39.8 / 42.9 / 49.2 us), the eight XCDs finish within 2 us of each other; it is how blocks share a CU.  Smaller blocks in
+    // several rounds lose more than the tail gives back (512 points per block: 48.7 us, 256: 55.6 us vs 46.9 us).
     const uint32_t lb = xcd_remap_icp(blockIdx.x, gridDim.x);
     const uint32_t beg = lb * chunk;
     const uint32_t end = min(beg + chunk, ns);
@@ -568,6 +576,10 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
         partials[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = sum;
     }
     if (lane == 0) rlist[blockIdx.x * kWavesPerBlock + w] = wcnt;
+    if (blk_times && threadIdx.x == 0) {
+        blk_times[2 * blockIdx.x] = t_begin;
+        blk_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // Refine pass: the listed queries (a few thousand per iteration: Poisson tail, queries outside the
@@ -1279,7 +1291,7 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
             ProfScope ps(ctx, mode == 1 ? "icp_correspond_reduce_p2plane" : mode == 2 ? "icp_correspond_reduce_gicp" : "icp_correspond_reduce_p2p", true);
             auto kern = mode == 1 ? icp_correspond_reduce_kernel<1> : mode == 2 ? icp_correspond_reduce_kernel<2> : icp_correspond_reduce_kernel<0>;
             hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st, corr_pos, rlist, partials, dbg, src_cov,
-                               (dbg & 4) ? nullptr : vor);
+                               (dbg & 4) ? nullptr : vor, (dbg & 1024) ? (unsigned long long *)ctx->dbg_times.p : nullptr);
         }
         ProfScope ps(ctx, "icp_refine");
         auto kern = mode == 1 ? icp_refine_kernel<1> : mode == 2 ? icp_refine_kernel<2> : icp_refine_kernel<0>;
@@ -1452,6 +1464,8 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
 
     size_t enq = 0;
     const float4 *vor = nullptr;
+    if (debug_flags() & 1024)
+        if (tc_status s = ensure(ctx, ctx->dbg_times, 2 * (size_t)kMaxPartialBlocks * sizeof(unsigned long long))) return s;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
             if (enq++ == vor_after())
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
@@ -1474,6 +1488,26 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     }
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
     TC_HIP_TRY(ctx, hipGetLastError());
+    if ((debug_flags() & 1024) && ctx->dbg_times.p) {          // block schedule of the LAST main pass of the call
+        std::vector<unsigned long long> h(2 * (size_t)su.l.nblocks);
+        (void)hipMemcpy(h.data(), ctx->dbg_times.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t b = 0; b < su.l.nblocks; ++b) { t0 = std::min(t0, h[2 * b]); t1 = std::max(t1, h[2 * b + 1]); }
+        std::vector<double> dur, endt, startt;
+        for (size_t b = 0; b < su.l.nblocks; ++b) { dur.push_back((h[2 * b + 1] - h[2 * b]) * 0.01); endt.push_back((h[2 * b + 1] - t0) * 0.01); startt.push_back((h[2 * b] - t0) * 0.01); }
+        std::sort(dur.begin(), dur.end()); std::sort(endt.begin(), endt.end()); std::sort(startt.begin(), startt.end());
+        auto q = [](const std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+        fprintf(stderr, "[tc] main pass blocks: %u; span %.1f us; block duration us min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f; start p50 %.1f p99 %.1f max %.1f; end p10 %.1f p50 %.1f p90 %.1f\n",
+                su.l.nblocks, (t1 - t0) * 0.01, dur.front(), q(dur, 0.1), q(dur, 0.5), q(dur, 0.9), q(dur, 0.99), dur.back(), q(startt, 0.5), q(startt, 0.99), startt.back(),
+                q(endt, 0.1), q(endt, 0.5), q(endt, 0.9));
+        fprintf(stderr, "[tc]   per XCD (block & 7): mean duration / last end, us:");
+        for (int x = 0; x < 8; ++x) {
+            double sum = 0, last = 0; int cnt = 0;
+            for (size_t b = x; b < su.l.nblocks; b += 8) { sum += (h[2 * b + 1] - h[2 * b]) * 0.01; last = std::max(last, (h[2 * b + 1] - t0) * 0.01); ++cnt; }
+            fprintf(stderr, " %.1f/%.1f", sum / std::max(cnt, 1), last);
+        }
+        fprintf(stderr, "\n");
+    }
     if (debug_flags() & 64)
         fprintf(stderr, "[tc] icp: %u iterations, refine queries total %u max %u  exit ring hist %u %u %u %u %u %u %u %u\n", hs->iterations,
                 hs->refine_total, hs->refine_max, hs->refine_ring_hist[0], hs->refine_ring_hist[1], hs->refine_ring_hist[2], hs->refine_ring_hist[3],

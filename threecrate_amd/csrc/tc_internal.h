@@ -153,6 +153,7 @@ struct tc_context {
     tc::DevBuf partials;            // double * kMaxPartialBlocks * TC_ICP_SUMS_STRIDE
     tc::DevBuf corr;                // u32 * n_source
     tc::DevBuf gicp_src_cov;        // GICP: source covariances in the sorted source order (2 float4 per point)
+    tc::DevBuf dbg_times;           // TC_DEBUG & 1024: per-block stamps of the main pass
     tc::DevBuf overflow;            // scratch (voxel filter: occupied-cell flags / output slots)
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
