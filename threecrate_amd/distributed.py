@@ -301,6 +301,11 @@ def stepwise_sharded_icp_point_to_plane(ctx, source, target, target_normals, ini
         raise InvalidData("Max iterations must be positive")
     sl = source
     if not source_is_local_slice:
+        # every rank sees the same n: fewer source points than ranks would leave a rank with an empty slice, which the step-wise
+        # session rejects -- on THAT rank only, while the others wait in the all-reduce.  Refuse on all ranks together
+        # (the in-library path, sharded_icp_point_to_plane, accepts empty shards).
+        if source.shape[0] < world:
+            raise InvalidData(f"the step-wise sharded loop needs at least one source point per rank ({source.shape[0]} points, {world} ranks)")
         lo, hi = shard_range(source.shape[0], rank, world)
         sl = source[lo:hi]
     be = HipShardBackend(ctx, sl, target, target_normals, IDENTITY if init is None else init,
