@@ -18,3 +18,16 @@ def test_randomized_differential_run(ctx):
     lines = []
     cases, bad = fuzz.run(15.0, 7, ctx, fuzz.SMALL, log=lines.append)
     assert cases > 100 and bad == 0, "\n".join(lines[-40:])
+
+
+@pytest.mark.gpu
+def test_inscribed_ball_test_never_changes_a_result():
+    """tools/dev/vor_fuzz.py: the same seeded sequence of registrations on odd clouds (slabs, surfaces, lattices, duplicates,
+    non-finite points, handles and plain calls, 3-25 iterations) with the inscribed-ball bounds from the first iteration on and
+    without them: bit-identical transforms, mse, iteration counts and correspondences."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vor_fuzz", os.path.join(os.path.dirname(__file__), "..", "tools", "dev", "vor_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, bad = mod.compare(12.0, 5)
+    assert n >= 10 and bad == 0
