@@ -91,6 +91,7 @@ typedef struct tc_kernel_stat {
     char     name[48];
     uint64_t launches;
     double   total_ms;
+    double   min_ms, max_ms;     /* shortest / longest timed launch (ABI version 2) */
 } tc_kernel_stat;
 
 /* ---- context: GpuContext::new (threecrate-gpu/src/device.rs:16-50) ---- */

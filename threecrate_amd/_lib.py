@@ -77,7 +77,7 @@ class FrameStreamMetricsC(C.Structure):
 
 
 class KernelStatC(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("min_ms", C.c_double), ("max_ms", C.c_double)]
 
 
 # every symbol include/threecrate_hip.h declares (tests/test_abi_symbols.py checks the header against this)

@@ -200,9 +200,12 @@ class GpuContext:
     def profile_reset(self):
         self._L.tc_profile_reset(self._h)
 
-    def profile_read(self):
+    def profile_read(self, minmax=False):
+        """{kernel name: (launches, total ms)}; minmax=True: (launches, total ms, shortest launch ms, longest launch ms)"""
         buf = (_lib.KernelStatC * 64)()
         n = self._L.tc_profile_read(self._h, buf, 64)
+        if minmax:
+            return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms), float(buf[i].min_ms), float(buf[i].max_ms)) for i in range(min(n, 64))}
         return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(n, 64))}
 
     # ---- normals ----

@@ -75,7 +75,7 @@ ProfScope::ProfScope(tc_context *c, const char *name, bool dominant) : ctx(c) {
     if (ctx->profiling == 2 && (!dominant || (ctx->prof_tick++ & 3u) != 0)) return;
     for (size_t i = 0; i < ctx->timers.size(); ++i)
         if (ctx->timers[i].name == name) { idx = (int)i; break; }
-    if (idx < 0) { ctx->timers.push_back(KernelTimer{name, {}, 0, 0.0}); idx = (int)ctx->timers.size() - 1; }
+    if (idx < 0) { ctx->timers.push_back(KernelTimer{name, {}, 0, 0.0, 1e300, 0.0}); idx = (int)ctx->timers.size() - 1; }
     auto get = [&]() {
         hipEvent_t e = nullptr;
         if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
@@ -937,7 +937,10 @@ static void profile_collect(tc_context *ctx) {
     for (auto &t : ctx->timers) {
         for (auto &p : t.pending) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t.total_ms += ms; t.launches += 1; }
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                t.total_ms += ms; t.launches += 1;
+                t.min_ms = std::min(t.min_ms, (double)ms); t.max_ms = std::max(t.max_ms, (double)ms);
+            }
             ctx->event_pool.push_back(p.first);
             ctx->event_pool.push_back(p.second);
         }
@@ -948,7 +951,7 @@ static void profile_collect(tc_context *ctx) {
 void tc_profile_reset(tc_context *ctx) {
     if (!ctx) return;
     profile_collect(ctx);
-    for (auto &t : ctx->timers) { t.launches = 0; t.total_ms = 0.0; }
+    for (auto &t : ctx->timers) { t.launches = 0; t.total_ms = 0.0; t.min_ms = 1e300; t.max_ms = 0.0; }
 }
 
 size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap) {
@@ -961,6 +964,8 @@ size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap) {
             std::strncpy(out[n].name, t.name.c_str(), sizeof(out[n].name) - 1);
             out[n].launches = t.launches;
             out[n].total_ms = t.total_ms;
+            out[n].min_ms = t.launches ? t.min_ms : 0.0;
+            out[n].max_ms = t.max_ms;
         }
         ++n;
     }

@@ -106,6 +106,7 @@ struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     uint64_t launches = 0;
     double   total_ms = 0.0;
+    double   min_ms = 1e300, max_ms = 0.0;
 };
 
 // One indexed cloud living in device memory.
