@@ -75,10 +75,11 @@ def timed(fn, warmups, reps):
 def cpu_baseline(n_points, tgt, src, gpu_normals=None):
     """The oracle (CPU restatement of threecrate-algorithms, kind="port") timed on this box's host cores with the
     reference harness protocol (warm-ups, repeated whole calls, median: docs/benchmarks.md:29) on a BOUNDED sample of
-    the same workload: the full k=16 normals call on the 1M cloud (1 warm-up + 3 timed), the kd-tree build on its own
+    the same workload: the full k=16 normals call on the 1M cloud (2 warm-ups + 5 timed, median), the kd-tree build on its own
     (single-threaded BY DESIGN: nearest_neighbor.rs:37-58 is a sequential recursion -- it is inside every normals /
-    ICP call of the reference), and p2plane ICP calls of 1 and 4 iterations (3 timed each; the difference / 3 = one
-    steady iteration, extrapolated to 50).  A 1-thread figure comes from a 100k-point subset."""
+    ICP call of the reference), and p2plane ICP calls of 1 and 4 iterations (5 timed each; the difference / 3 = one
+    steady iteration, extrapolated to 50: the full 50-iteration call would take ~17 s a time).  A 1-thread figure comes
+    from a 100k-point subset.  About 25 s of CPU work in all."""
     import numpy as np
     from oracle import oracle as O
     omp_max = O.num_threads()
@@ -98,10 +99,11 @@ def cpu_baseline(n_points, tgt, src, gpu_normals=None):
             continue
     threads = max(1, min(omp_max, int(quota + 0.5))) if quota else omp_max
     _est, _icp = O.estimate_normals, O.icp_point_to_plane_detailed
-    t_norm, nrm = timed(lambda: _est(tgt, K_NORMALS, threads=threads), 1, 3)
+    # the reference harness' protocol: 2 warm-ups, 5 timed whole calls, median (docs/benchmarks.md:29)
+    t_norm, nrm = timed(lambda: _est(tgt, K_NORMALS, threads=threads), 2, 5)
     t_tree, _ = timed(lambda: O.KdTree(tgt), 0, 3)
-    t1, _ = timed(lambda: _icp(src, tgt, nrm[:, 3:], None, 1, None, 0.0, threads=threads), 1, 3)
-    t4, _ = timed(lambda: _icp(src, tgt, nrm[:, 3:], None, 4, None, 0.0, threads=threads), 0, 3)
+    t1, _ = timed(lambda: _icp(src, tgt, nrm[:, 3:], None, 1, None, 0.0, threads=threads), 2, 5)
+    t4, _ = timed(lambda: _icp(src, tgt, nrm[:, 3:], None, 4, None, 0.0, threads=threads), 0, 5)
     t_iter = max((t4 - t1) / 3.0, 1e-9)
     t_build = max(t1 - t_iter, 0.0)
     job = t_norm + t_build + ICP_ITERS * t_iter
@@ -132,9 +134,9 @@ def cpu_baseline(n_points, tgt, src, gpu_normals=None):
         "value": ICP_ITERS / job, "unit": "ICP it/s (whole job: normals + 50 it)", "cores": threads, "kind": "port",
         "sched_affinity_cpus": affinity, "omp_max_threads": omp_max, "cgroup_cpu_quota_cores": quota,
         "normals_query_mpts_per_s_by_threads_100k_subset": scaling,
-        "sample": f"oracle on the same {n_points}-pt pair, {threads} threads (= the container's CPU quota; the box shows {affinity} CPUs): k={K_NORMALS} normals call median of 3 after 1 warm-up "
+        "sample": f"oracle on the same {n_points}-pt pair, {threads} threads (= the container's CPU quota; the box shows {affinity} CPUs): k={K_NORMALS} normals call median of 5 after 2 warm-ups "
                   f"({t_norm:.2f} s, of which the single-threaded kd-tree build is {t_tree:.2f} s) + ICP: p2plane calls of 1 and 4 "
-                  f"iterations, median of 3 each -> {t_iter:.3f} s per steady iteration, {t_build:.2f} s per-call setup (kd-tree "
+                  f"iterations, median of 5 each -> {t_iter:.3f} s per steady iteration, {t_build:.2f} s per-call setup (kd-tree "
                   f"build + first gather), extrapolated to {ICP_ITERS} iterations",
         "normals_mpts_per_s": n_points / t_norm / 1e6,
         "normals_mpts_per_s_excluding_kdtree_build": n_points / max(t_norm - t_tree, 1e-9) / 1e6,
