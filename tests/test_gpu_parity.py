@@ -782,3 +782,28 @@ def test_non_finite_points_are_inert(ctx):
     b = ctx.icp_point_to_plane_detailed(src_clean, tgt_clean, nrm[mask], None, 10, None, 0.0)
     assert frob(a.transformation, b.transformation, O.isometry_to_matrix) <= 1e-6
     assert np.array_equal(a.correspondences, np.stack([remap[b.correspondences[:, 0]], remap[b.correspondences[:, 1]]], axis=1))
+
+
+def test_device_inputs_are_ordered_after_the_torch_stream(ctx):
+    """the *_device entry points read their inputs on the CONTEXT's stream; the Python mirror makes that
+    stream wait for torch's current stream first (tc_context_wait_stream).  Here the input is produced by torch work that is
+    still queued behind a few hundred milliseconds of matmuls when the library is called: without the ordering the index would be
+    built from whatever the buffer held before (the recycled block of `stale`)."""
+    n = 400_000
+    good = torch.from_numpy(synth.uniform_cloud(n, 61)).cuda()
+    ref = ctx.estimate_normals(good, 12)
+    torch.cuda.synchronize()
+    for trial in range(3):
+        stale = torch.full((n, 3), 7.0 + trial, device="cuda")             # same size: the allocator hands its block to `late`
+        del stale
+        a = torch.randn(4096, 4096, device="cuda")
+        for _ in range(60):                                                # keeps torch's stream busy
+            a = (a @ a) * 1e-4
+        late = good + 0.0                                                  # queued BEHIND the matmuls on torch's stream
+        got = ctx.estimate_normals(late, 12)                               # called while `late` is not written yet
+        assert torch.equal(got, ref)
+        src = good[: n // 2] + 0.001
+        r1 = ctx.icp_detailed(src, late, None, 3, None, 0.0, correspondences=False)
+        torch.cuda.synchronize()
+        r2 = ctx.icp_detailed(src, good, None, 3, None, 0.0, correspondences=False)
+        assert np.array_equal(r1.transformation, r2.transformation)
