@@ -251,12 +251,16 @@ __global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restric
     uint32_t i = slot[p];
     uint32_t c = cell_of[i];
     uint32_t s = cell_start[c], e = cell_start[c + 1];
+    // rank = the number of points of the cell with a smaller original index: quadratic in the cell's population, which is ~1.5 on
+    // the clouds this index is sized for.  65536 points in ONE cell (a block of exact duplicates, a cluster far below the cell
+    // edge) still rank in ~0.3 ms; beyond that the atomic arrival order is kept -- the only place where two runs may differ
+    // (DESIGN.md section 3), on inputs whose every neighbour search is quadratic anyway.
     uint32_t rank;
-    if (e - s <= 4096u) {
+    if (e - s <= 65536u) {
         rank = 0;
         for (uint32_t j = s; j < e; ++j) rank += (slot[j] < i) ? 1u : 0u;
     } else {
-        rank = p - s;   // pathological cell: keep the atomic order (documented in DESIGN.md)
+        rank = p - s;
     }
     float4 r;
     r.x = xyz[3 * (size_t)i]; r.y = xyz[3 * (size_t)i + 1]; r.z = xyz[3 * (size_t)i + 2];

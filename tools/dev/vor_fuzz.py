@@ -26,8 +26,7 @@ def child(budget, seed):
         elif kind == 1: p = rng.random((n, 3)) * np.array([10.0, 3.0, 0.2])
         elif kind == 2: u = rng.random((n, 2)); p = np.stack([u[:, 0], u[:, 1], 0.1 * np.sin(6 * u[:, 0]) + 1e-4 * rng.normal(size=n)], 1)
         elif kind == 3: p = np.round(rng.random((n, 3)) * 16) / 16 + 1e-5 * rng.normal(size=(n, 3))
-        else: p = rng.random((n, 3)); p[: min(n // 8, 1500)] = p[0]      # exact duplicates (below the 4096 per cell from which on the index keeps
-                                                                          # the atomic arrival order inside a cell: run-to-run differences by design)
+        else: p = rng.random((n, 3)); p[: n // 8] = p[0]      # exact duplicates (up to 18 750 in one cell: ranked deterministically up to 65 536)
         tgt = (p * rng.choice([1e-2, 1.0, 50.0])).astype(np.float32)
         ext = float(np.linalg.norm(tgt.max(0) - tgt.min(0))) + 1e-6
         spacing = ext / max(n, 2) ** (1 / 3)
