@@ -125,7 +125,8 @@ void free_index(DeviceIndex &ix) {
 
 // build == false: `ix` already indexes this cloud (a cloud handle)
 tc_status normals_on_index(tc_context *ctx, DeviceIndex &ix, bool build, float cell_factor_override, const float *d_xyz, size_t n,
-                           const tc_normal_config *cfg, float *d_out, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm) {
+                           const tc_normal_config *cfg, float *d_out, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm,
+                           bool with_bounds) {
     if (build) {
         // radius mode: ring 2 must cover the radius ball, so the cell edge is at least radius / 2
         const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
@@ -142,7 +143,17 @@ tc_status normals_on_index(tc_context *ctx, DeviceIndex &ix, bool build, float c
         const float extent = std::sqrt(ex * ex + ey * ey + ez * ez);
         vp[0] = cx + 0.0f; vp[1] = cy + 0.0f; vp[2] = cz + extent;
     }
-    return launch_normals(ctx, ix, d_xyz, *cfg, vp, d_out, p_begin, p_end, slice_out, d_sorted_nrm);
+    // the inscribed-ball bounds of the ICP main pass fall out of the same k-NN lists (k-NN mode, whole cloud, the list must hold
+    // the query and at least one other record)
+    float4 *d_vor = nullptr;
+    const bool knn_mode = !(cfg->has_radius && cfg->radius > 0.0f);
+    if (with_bounds && knn_mode && p_begin == 0 && p_end >= n) {
+        if (tc_status s = ensure(ctx, ix.vor, n * sizeof(float4))) return s;
+        d_vor = (float4 *)ix.vor.p;
+    }
+    if (tc_status s = launch_normals(ctx, ix, d_xyz, *cfg, vp, d_out, p_begin, p_end, slice_out, d_sorted_nrm, d_vor)) return s;
+    ix.vor_valid = d_vor != nullptr;
+    return TC_OK;
 }
 
 static tc_status normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, float *d_out,

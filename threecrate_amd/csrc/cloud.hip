@@ -126,8 +126,9 @@ static tc_status cloud_normals(tc_cloud *c, const tc_normal_config *cfg, float *
     }
     c->has_normals = false;
     c->has_normals6 = false;
+    // (+ the inscribed-ball bounds of the cloud as an ICP target: they fall out of the same k-NN lists)
     if (tc_status s = normals_on_index(ctx, c->ix, false, 0.0f, (const float *)c->xyz.p, c->n, cfg, d_out6, 0, (size_t)-1, false,
-                                       (float4 *)c->ix.normals.p)) return s;
+                                       (float4 *)c->ix.normals.p, true)) return s;
     c->has_normals = true;
     c->has_normals6 = want6;
     if (out) TC_HIP_TRY(ctx, hipMemcpyAsync(out, d_out6, c->n * 6 * sizeof(float), out_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));

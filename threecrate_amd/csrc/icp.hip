@@ -1463,11 +1463,13 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     const float4 *nrm = (const float4 *)(*su.tix).normals.p;
 
     size_t enq = 0;
-    const float4 *vor = nullptr;
+    // bounds that already exist (a cloud handle whose normals were estimated here, or that has been a target before) serve from
+    // the first iteration on; otherwise they are computed once the registration has run for a while
+    const float4 *vor = su.tix->vor_valid ? (const float4 *)su.tix->vor.p : nullptr;
     if (debug_flags() & 1024)
         if (tc_status s = ensure(ctx, ctx->dbg_times, 2 * (size_t)kMaxPartialBlocks * sizeof(unsigned long long))) return s;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
-            if (enq++ == vor_after())
+            if (enq++ == vor_after() && !vor)
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor);
             return TC_OK;
@@ -1560,9 +1562,11 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     const float4 *src = (const float4 *)ctx->src_index.pts.p + lo;
     const float4 *nrm = (const float4 *)(*su.tix).normals.p;
     size_t enq = 0;
-    const float4 *vor = nullptr;
+    // bounds that already exist (a cloud handle whose normals were estimated here, or that has been a target before) serve from
+    // the first iteration on; otherwise they are computed once the registration has run for a while
+    const float4 *vor = su.tix->vor_valid ? (const float4 *)su.tix->vor.p : nullptr;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
-            if (enq++ == vor_after())
+            if (enq++ == vor_after() && !vor)
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, true, false, true, nullptr, vor);
             if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;

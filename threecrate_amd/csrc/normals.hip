@@ -44,6 +44,8 @@ struct NormalParams {
     float    radius;
     const float *xyz;       // the caller's AoS input (positions of non-finite points are copied from here)
     float4 *sorted_nrm;     // optional: the normal of cell-sorted position p -> sorted_nrm[p] (a cloud handle keeps them: the ICP target layout)
+    float4 *vor_out;        // optional: {x, y, z, inscribed-ball bound} per position (icp.hip: the bound is a quarter of the squared
+                            // distance to the nearest OTHER record = the second entry of the k-NN list, for free here)
     uint32_t p_begin, p_end;    // cell-sorted positions handled by this launch (a multi-GPU shard: SURVEY 8e)
     int      slice_out;         // 1: record of position p goes to row p - p_begin (sorted order) instead of its original index
 };
@@ -425,6 +427,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         // (normals.rs:197-202), and the orientation test `dot < 0` is false for NaN (:216).  Finite points never see these
         // points as neighbours here (the reference's kd-tree places them wherever its NaN comparisons fall).
         if (prm.sorted_nrm) prm.sorted_nrm[p] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (prm.vor_out) prm.vor_out[p] = make_float4(q.x, q.y, q.z, 0.0f);
         if (out6) {
             float *o = out6 + 6 * (size_t)(prm.slice_out ? p - prm.p_begin : orig);
             o[0] = prm.xyz[3 * (size_t)orig]; o[1] = prm.xyz[3 * (size_t)orig + 1]; o[2] = prm.xyz[3 * (size_t)orig + 2];
@@ -507,6 +510,8 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     }
 
 #undef TC_KTH
+    // d[0] is the query itself (0), d[1] the squared distance to its nearest OTHER record (0 for an exact duplicate: never kept)
+    if (prm.vor_out) prm.vor_out[p] = make_float4(q.x, q.y, q.z, 0.25f * 0.9999f * d[1]);
     float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
     if (RADIUS && use_radius) {
         const double nn = (double)cnt_r + 1.0;                     // + the query itself (normals.rs:338-340)
@@ -816,7 +821,7 @@ tc_status launch_normals_unsort(tc_context *ctx, const DeviceIndex &ix, const fl
 }
 
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_xyz, const tc_normal_config &cfg, const float vp[3],
-                         float *d_out6, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm) {
+                         float *d_out6, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm, float4 *d_vor) {
     if (cfg.k_neighbors + 1 > 129) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 128 is not supported by the HIP backend");
     NormalParams prm;
     prm.k = (uint32_t)cfg.k_neighbors;
@@ -827,6 +832,7 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     prm.radius = prm.has_radius ? cfg.radius : 0.0f;
     prm.xyz = d_xyz;
     prm.sorted_nrm = d_sorted_nrm;
+    prm.vor_out = d_vor;
     prm.p_begin = (uint32_t)p_begin;
     prm.p_end = (uint32_t)std::min<size_t>(p_end, ix.geom.n);
     prm.slice_out = slice_out ? 1 : 0;

@@ -211,10 +211,11 @@ tc_status range_filter_device(tc_context *ctx, const float *d_xyz, size_t n, flo
 // normals.hip
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_xyz, const tc_normal_config &cfg,
                          const float vp[3], float *d_out6, size_t p_begin = 0, size_t p_end = (size_t)-1, bool slice_out = false,
-                         float4 *d_sorted_nrm = nullptr);
+                         float4 *d_sorted_nrm = nullptr, float4 *d_vor = nullptr);
 // api.hip: index (into `ix`) + normals of a device-resident cloud
 tc_status normals_on_index(tc_context *ctx, DeviceIndex &ix, bool build, float cell_factor_override, const float *d_xyz, size_t n,
-                           const tc_normal_config *cfg, float *d_out6, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm);
+                           const tc_normal_config *cfg, float *d_out6, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm,
+                           bool with_bounds = false);
 float normals_cell_factor(size_t k, bool large);
 float normals_target_ppo(size_t k);
 float icp_cell_factor();
