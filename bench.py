@@ -204,8 +204,15 @@ def aux_modes(args):
         torch.cuda.synchronize()
         t_normals = (time.perf_counter() - tn0) / 3.0
 
+        # the target is a map many scans are registered against: every rank keeps it in a handle (index, cell-sorted normals and
+        # inscribed-ball bounds built once, not once per registration); --plain-calls: rebuilt inside every call
+        th = tc.Cloud(ctx, tgt)
+        th.set_normals(nrm)
+
         def step():
-            return D.sharded_icp_point_to_plane(ctx, src, tgt, nrm, None, ICP_ITERS, None, 0.0, comm=comm, correspondences="device")
+            if args.plain_calls:
+                return D.sharded_icp_point_to_plane(ctx, src, tgt, nrm, None, ICP_ITERS, None, 0.0, comm=comm, correspondences="device")
+            return D.sharded_icp_against_cloud(ctx, src, th, None, ICP_ITERS, None, 0.0, comm=comm, correspondences="device")
         for _ in range(max(args.warmup, 1)):
             step()
         torch.cuda.synchronize()
@@ -230,9 +237,11 @@ def aux_modes(args):
                               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": f"{n}-pt uniform cloud [0,10)x[0,10)x[0,1) (BASELINE configs[3]), 50-iter p2plane ICP, "
                                                      "source sharded spatially over the ranks, correspondences gathered",
-                                         "points": n, "parallelism": f"shard{world}"},
+                                         "points": n, "parallelism": f"shard{world}",
+                                         "target": "rebuilt per call" if args.plain_calls else "tc_cloud handle (indexed once)"},
                               "transform_frobenius_error_vs_truth": err, "n_correspondences": int((r.corr_target != -1).sum()),
                               "sharded_normals_ms": 1e3 * t_normals, "sharded_normals_mpts_per_s": n / t_normals / 1e6}))
+        th.close()
         comm.close()
     else:
         frames = [synth.kitti_shaped_cloud(seed=i) for i in range(4)]

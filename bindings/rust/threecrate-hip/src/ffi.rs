@@ -155,5 +155,8 @@ extern "C" {
                                        conv_thr: f32, res: *mut tc_icp_result) -> c_int;
     pub fn tc_cloud_icp_detailed(source: *mut tc_cloud, target: *mut tc_cloud, init: *const f32, max_iters: usize, max_dist: f32,
                                  conv_thr: f32, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_cloud_sharded_icp(comm: *mut tc_comm, shard_mode: c_int, point_to_plane: c_int, d_source: *const f32, n_source: usize,
+                                target: *mut tc_cloud, init: *const f32, max_iters: usize, max_dist: f32, conv_thr: f32,
+                                res: *mut tc_icp_result) -> c_int;
     pub fn tc_cloud_destroy(cloud: *mut tc_cloud);
 }

@@ -313,6 +313,14 @@ tc_status tc_sharded_icp_detailed_device(tc_context *ctx, tc_comm *comm, int sha
 tc_status tc_sharded_estimate_normals_device(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n,
                                              const tc_normal_config *config, float *d_out_normal_points);
 
+/* One registration over the ranks of a communicator (see tc_sharded_icp_point_to_plane_device) against a TARGET HANDLE: every
+ * rank holds the same target cloud in its own handle, whose index, cell-sorted normals and inscribed-ball bounds are built once
+ * per handle instead of once per call (a map many scans are registered against).  point_to_plane != 0 needs normals in the handle.
+ * The source is a device buffer, sharded per shard_mode; corr_target (device, optional) as in the buffer-based entry points. */
+tc_status    tc_cloud_sharded_icp(tc_comm *comm, int shard_mode, int point_to_plane, const float *d_source, size_t n_source,
+                                  tc_cloud *target, const float init[7], size_t max_iters, float max_correspondence_distance,
+                                  float convergence_threshold, tc_icp_result *result);
+
 /* ---- multiscale ICP ----
  * multiscale_icp_point_to_point(source, target, init, &MultiScaleIcpConfig) -> Result<ICPResult>
  * (threecrate-algorithms/src/registration.rs:704-789; config :26-71): per level voxel_grid_filter both

@@ -68,6 +68,17 @@ def test_one_rank_sharded_entry_equals_fused_loop(ctx, kind):
         assert (a.converged, a.iterations, a.mse) == (b.converged, b.iterations, b.mse) and np.array_equal(a.transformation, b.transformation)
         # normals: slice + all-gather + unsort == the single call
         assert torch.equal(D.sharded_estimate_normals(ctx, dt, 16, comm=comm), nrm)
+        # against a target HANDLE (index, normals, bounds built once): the handle-based single-GPU call, bit for bit, twice
+        th, sh = tc.Cloud(ctx, dt), tc.Cloud(ctx, ds)
+        th.estimate_normals(16, out=False)
+        for _ in range(2):
+            b = sh.icp_point_to_plane(th, None, 12, None, 0.0, correspondences=True)
+            a = D.sharded_icp_against_cloud(ctx, ds, th, None, 12, None, 0.0, comm=comm, correspondences=True)
+            assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse and np.array_equal(a.correspondences, b.correspondences)
+        b = sh.icp_detailed(th, None, 5, 0.05, 0.0)
+        a = D.sharded_icp_against_cloud(ctx, ds, th, None, 5, 0.05, 0.0, point_to_plane=False, comm=comm)
+        assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse
+        th.close(); sh.close()
     finally:
         comm.close()
 

@@ -91,7 +91,7 @@ EXPORTS = [
     "tc_icp_shard_apply", "tc_icp_shard_finish", "tc_icp_shard_destroy",
     "tc_cloud_upload", "tc_cloud_upload_device", "tc_cloud_size", "tc_cloud_points_device", "tc_cloud_normals_device",
     "tc_cloud_estimate_normals", "tc_cloud_estimate_normals_device", "tc_cloud_set_normals_device", "tc_cloud_icp_point_to_plane",
-    "tc_cloud_icp_detailed", "tc_cloud_destroy",
+    "tc_cloud_icp_detailed", "tc_cloud_sharded_icp", "tc_cloud_destroy",
     "tc_comm_unique_id", "tc_comm_create", "tc_comm_adopt", "tc_comm_create_host", "tc_comm_create_local", "tc_comm_rank", "tc_comm_size",
     "tc_comm_destroy", "tc_sharded_icp_point_to_plane_device", "tc_sharded_icp_detailed_device", "tc_sharded_estimate_normals_device",
     "tc_multiscale_icp_point_to_point", "tc_gicp", "tc_gicp_device", "tc_kiss_icp", "tc_kiss_icp_device", "tc_knn", "tc_knn_device", "tc_radius_search", "tc_radius_search_device",
@@ -184,6 +184,7 @@ def load():
     L.tc_cloud_set_normals_device.argtypes = [vp, f32p, sz, sz]
     L.tc_cloud_icp_point_to_plane.argtypes = [vp, vp, f32p, sz, f, f, resp]
     L.tc_cloud_icp_detailed.argtypes = [vp, vp, f32p, sz, f, f, resp]
+    L.tc_cloud_sharded_icp.argtypes = [vp, i, i, f32p, sz, vp, f32p, sz, f, f, resp]
     L.tc_cloud_destroy.argtypes = [vp]
     L.tc_cloud_destroy.restype = None
     L.tc_comm_unique_id.argtypes = [vp]

@@ -77,6 +77,8 @@ tc_status adopt_normals(tc_cloud *c, const float *d_normals, size_t stride) {
     return TC_OK;
 }
 
+tc_status prepare_target(tc_cloud *tgt, bool p2plane);
+
 tc_status cloud_icp(tc_cloud *src, tc_cloud *tgt, bool p2plane, const float init[7], size_t max_iters, float max_dist, float conv_thr,
                     tc_icp_result *res) {
     if (!src || !tgt || !res || !init) return TC_INVALID_DATA;
@@ -89,18 +91,45 @@ tc_status cloud_icp(tc_cloud *src, tc_cloud *tgt, bool p2plane, const float init
                                           "tc_cloud_estimate_normals or tc_cloud_set_normals_device first)");
     if (max_iters == 0) return fail(ctx, TC_INVALID_DATA, "Max iterations must be positive");
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = prepare_target(tgt, p2plane)) return s;
+    return icp_run(ctx, p2plane, (const float *)src->xyz.p, src->n, (const float *)tgt->xyz.p, tgt->n, nullptr, 0, init, max_iters, max_dist,
+                   conv_thr, res, true, 0, &tgt->ix);
+}
+
+// the target side of a registration against a handle: index (built once), cell-sorted normals
+tc_status prepare_target(tc_cloud *tgt, bool p2plane) {
+    tc_context *ctx = tgt->ctx;
     if (tc_status s = ensure_index(tgt, icp_cell_factor(), 2.5f, 0.0f)) return s;
     if (p2plane && !tgt->has_normals) {          // the index was rebuilt since the normals were made: re-sort them
         if (tc_status s = gather_normals(ctx, tgt->ix, (const float *)tgt->normals6.p + 3, 6)) return s;
         tgt->has_normals = true;
     }
-    return icp_run(ctx, p2plane, (const float *)src->xyz.p, src->n, (const float *)tgt->xyz.p, tgt->n, nullptr, 0, init, max_iters, max_dist,
-                   conv_thr, res, true, 0, &tgt->ix);
+    return TC_OK;
 }
 
 }  // namespace
 
 extern "C" {
+
+// One registration over the ranks of a communicator against a TARGET HANDLE (every rank holds the same cloud in its own handle:
+// index, normals and inscribed-ball bounds are built once per handle, not once per call -- a map that many scans are registered
+// against).  The source is a plain device buffer, sharded as in tc_sharded_icp_point_to_plane_device.
+tc_status tc_cloud_sharded_icp(tc_comm *comm, int shard_mode, int point_to_plane, const float *d_source, size_t n_source, tc_cloud *target,
+                               const float init[7], size_t max_iters, float max_dist, float conv_thr, tc_icp_result *result) {
+    if (!comm || !target || !result || !init) return TC_INVALID_DATA;
+    tc_context *ctx = target->ctx;
+    if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
+    if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
+    const bool may_be_empty = shard_mode == TC_SHARD_LOCAL && comm->nranks > 1;
+    if ((n_source == 0 && !may_be_empty) || target->n == 0) return fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");
+    if (point_to_plane && !target->has_normals && !target->has_normals6)
+        return fail(ctx, TC_INVALID_DATA, "target_normals length must equal the number of target points (the target handle has no normals)");
+    if (max_iters == 0) return fail(ctx, TC_INVALID_DATA, "Max iterations must be positive");
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (tc_status s = prepare_target(target, point_to_plane != 0)) return s;
+    return icp_run_sharded(ctx, comm, shard_mode, point_to_plane != 0, d_source, n_source, (const float *)target->xyz.p, target->n, nullptr, 0, init,
+                           max_iters, max_dist, conv_thr, result, &target->ix);
+}
 
 tc_status tc_cloud_upload(tc_context *ctx, const float *xyz, size_t n, tc_cloud **out) { return cloud_create(ctx, xyz, n, true, out); }
 tc_status tc_cloud_upload_device(tc_context *ctx, const float *d_xyz, size_t n, tc_cloud **out) { return cloud_create(ctx, d_xyz, n, false, out); }

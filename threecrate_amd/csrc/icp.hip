@@ -1544,11 +1544,11 @@ __global__ void __launch_bounds__(256) icp_zero_u32_kernel(uint32_t *__restrict_
 
 tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p2plane, const float *d_src, size_t ns, const float *d_tgt,
                           size_t nt, const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
-                          float conv_thr, tc_icp_result *res) {
+                          float conv_thr, tc_icp_result *res, DeviceIndex *tgt_prebuilt) {
     const int mode = p2plane ? 1 : 0;
     const int W = comm ? comm->nranks : 1, rank = comm ? comm->rank : 0;
     IcpSetup su;
-    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, 0)) return s;
+    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, 0, tgt_prebuilt)) return s;
     hipStream_t st = ctx->stream;
     IcpState *dstate = (IcpState *)ctx->state.p;
     // this rank's range of the tile-major sorted source: a spatially compact shard (TC_SHARD_SPATIAL), or everything it was given

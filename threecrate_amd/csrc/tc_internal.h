@@ -239,7 +239,7 @@ tc_status comm_allgather(tc_comm *comm, void *d_buf, size_t bytes_per_rank);    
 // icp.hip
 tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p2plane, const float *d_src, size_t ns, const float *d_tgt,
                           size_t nt, const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
-                          float conv_thr, tc_icp_result *res);
+                          float conv_thr, tc_icp_result *res, DeviceIndex *tgt_prebuilt = nullptr);
 // tgt_prebuilt: an index of the target built by the caller (a cloud handle; with its cell-sorted normals when p2plane), else
 // the target is indexed into ctx->tgt_index
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,

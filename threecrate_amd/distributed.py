@@ -242,6 +242,34 @@ def sharded_icp_point_to_plane(ctx, source, target, target_normals, init=None, m
             comm.close()
 
 
+def sharded_icp_against_cloud(ctx, source, target_cloud, init=None, max_iters=50, max_correspondence_distance=None,
+                              convergence_threshold=1e-6, point_to_plane=True, group=None, source_is_local_slice=False, comm=None,
+                              correspondences=False):
+    """The same registration against a TARGET HANDLE (tc.Cloud, the same cloud on every rank): tc_cloud_sharded_icp.  Index, normals
+    and inscribed-ball bounds of the target are built once per handle instead of once per call."""
+    import torch
+    own = comm is None
+    comm = comm or Comm.from_group(ctx, group)
+    try:
+        s = source.detach().to(torch.float32).contiguous().reshape(-1, 3)
+        from .api import IDENTITY
+        i7 = np.ascontiguousarray(np.asarray(IDENTITY if init is None else init, np.float32).reshape(7))
+        md = ctx._max_dist(max_correspondence_distance)
+        if md is None:
+            ctx._reject_all(max(s.shape[0], 1 if source_is_local_slice else 0), len(target_cloud), max_iters)
+        r = _lib.IcpResultC()
+        corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
+        r.corr_target = corr.data_ptr() if corr is not None else None
+        ctx._order(s.device)
+        ctx._check(_lib.load().tc_cloud_sharded_icp(comm._h, _lib.TC_SHARD_LOCAL if source_is_local_slice else _lib.TC_SHARD_SPATIAL,
+                                                    1 if point_to_plane else 0, s.data_ptr(), s.shape[0], target_cloud._h, i7.ctypes.data,
+                                                    max_iters, md, convergence_threshold, C.byref(r)))
+        return _finish(ctx, r, None if corr is None else corr[: s.shape[0]], correspondences)
+    finally:
+        if own:
+            comm.close()
+
+
 def sharded_icp_detailed(ctx, source, target, init=None, max_iters=50, max_correspondence_distance=None,
                          convergence_threshold=1e-6, group=None, source_is_local_slice=False, comm=None, correspondences=False):
     """icp_detailed (registration.rs:258-370, point-to-point) over all ranks: tc_sharded_icp_detailed_device."""
