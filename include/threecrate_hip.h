@@ -10,6 +10,9 @@
  *                          icp_point_to_point / icp_point_to_plane(_detailed)
  *   threecrate-gpu:        GpuContext::new, gpu_estimate_normals, gpu_icp,
  *                          gpu_icp_point_to_plane, gpu_batch_icp
+ * plus what the reference does not have and an MI355X node needs: device-resident cloud handles (tc_cloud_*: one index build
+ * per cloud), a communicator (tc_comm_*: RCCL bound at run time) and ONE registration / ONE cloud's normals over the GPUs of a
+ * node (tc_sharded_*, tc_cloud_sharded_icp) with the per-iteration all-reduce inside the library.
  *
  * Memory layouts (threecrate-core):
  *   Point3f         = 3 x f32, AoS               (threecrate-core/src/point.rs:8)
