@@ -97,6 +97,34 @@ def test_icp_point_to_plane_matches_oracle(ctx, n):
     assert frob(g.transformation, r.transformation, O.isometry_to_matrix) <= FROB_TOL
 
 
+def test_every_iteration_count_is_executed(ctx):
+    """registration.rs:278 / :533: a run that does not converge executes exactly max_iterations iterations.  The loop is enqueued
+    in chunks of 6, 2, 4, 8, 8, ... iterations: the counts below cross the chunk boundaries in every way (a miscounted number of
+    chunks once dropped the last one or two iterations of 13, 14, 21, 22, 29, 30, ...).  Point-to-point from a far start moves
+    by more than 100x the tolerance per iteration for the first 22 iterations: one iteration more or less cannot hide."""
+    src, tgt, T = synth.registration_pair(4000, seed=12, transform=synth.yaw_isometry((0.25, -0.1, 0.05), 0.1))
+    ref = {}
+    for n_it in range(1, 25):
+        g = ctx.icp_detailed(src, tgt, None, n_it, None, 0.0)
+        r = ref[n_it] = O.icp_detailed(src, tgt, None, n_it, None, 0.0)
+        assert g.iterations == r.iterations == n_it and not g.converged
+        # a far start amplifies the rounding of the reference's sequential f32 sums: where the plain tolerance does not hold the
+        # distance is bounded by the oracle's own sensitivity to the order of its input (H1), and stays far below one iteration
+        fro = frob(g.transformation, r.transformation, O.isometry_to_matrix)
+        if fro > FROB_TOL:
+            noise = h1.reference_order_noise(lambda s_: O.icp_detailed(s_, tgt, None, n_it, None, 0.0), src)
+            assert fro <= 2.0 * noise + FROB_TOL and fro <= 10 * FROB_TOL, (n_it, fro, noise)
+        assert abs(g.mse - r.mse) <= 1e-9 + 1e-3 * abs(r.mse), n_it
+    for n_it in range(2, 23):
+        assert frob(ref[n_it].transformation, ref[n_it - 1].transformation, O.isometry_to_matrix) > 100 * FROB_TOL
+    # beyond that the device's own count guards the loop (a run that did not converge must report max_iterations executed
+    # iterations, or the call fails): every count up to 70, both variants
+    nrm = O.estimate_normals(tgt, 10)[:, 3:]
+    for n_it in range(1, 71):
+        assert ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, n_it, None, 0.0, correspondences=False).iterations == n_it
+        assert ctx.icp_detailed(src, tgt, None, n_it, None, 0.0, correspondences=False).iterations == n_it
+
+
 def test_icp_with_init_and_max_distance(ctx):
     src, tgt, T = synth.registration_pair(15000, seed=4)
     init = synth.yaw_isometry((0.002, 0.001, -0.001), 0.001)

@@ -182,9 +182,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *p) {
 }
 
 // exact 1-NN of (x, y, z); ub2 = a valid upper bound of the squared NN distance (or +inf)
+// -DTC_PHASE_STAMPS builds (tools/dev/build_variant.sh): wave 0 of every main-pass block adds up the shader clock (s_memtime)
+// it spends in each phase; TC_DEBUG & 1024 prints the means.  Nothing of it exists in a normal build.
+#ifdef TC_PHASE_STAMPS
+#define TC_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tl; tl = t_; } while (0)
+#define TC_STAMP_ARGS , unsigned long long (&ph)[8], unsigned long long &tl
+#define TC_STAMP_PASS , ph, tl
+#else
+#define TC_STAMP(i) do { } while (0)
+#define TC_STAMP_ARGS
+#define TC_STAMP_PASS
+#endif
 __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, float y, float z, float ub2,
                                                  float &best, uint32_t &bestj, bool &refine, float max_dist,
-                                                 uint2 (*spans)[kIcpBlock]) {
+                                                 uint2 (*spans)[kIcpBlock] TC_STAMP_ARGS) {
     const GridGeom &g = gv.g;
     int cx, cy, cz;
     float mf, out2;
@@ -206,9 +217,8 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     const float az2[3] = {lo_z * lo_z, 0.0f, hi_z * hi_z};
     const float ub = ub2 - out2;     // budget left inside the box (|p-q|^2 >= |p-q'|^2 + |q-q'|^2)
     // One unaligned 16-byte window of cell_start per row, [row + cx - 1, row + cx + 2], issued for all
-    // nine rows back to back and without branches (one round trip): it holds the start of the left,
-    // own and right cell and the end of the right cell.  A row the ball does not reach reads window 0
-    // and becomes the empty span.  (cell_start is padded by kCellStartPad entries.)
+    // nine rows back to back (one round trip): it holds the start of the left, own and right cell and
+    // the end of the right cell.  (cell_start is padded by kCellStartPad entries.)
     const __amdgpu_buffer_rsrc_t cs_rsrc = raw_rsrc(gv.cell_start - 1);      // window of cell c starts at entry c - 1 (zeros in front of the array)
     // per-axis facts shared by the nine rows; row starts by adding uniform strides to the centre row
     // (no per-row integer multiplies: v_mul_lo_u32 is quarter rate)
@@ -227,7 +237,13 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         // x window: the left / right cell only if the ball reaches it
         const bool left = has_l && !(r2 + ax2[0] > ub), right = has_r && !(r2 + ax2[2] > ub);
         const int row = row_c + dz * stride_z + dy * stride_y;
-        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(cs_rsrc, on ? (uint32_t)row << 2 : 0u, 0, 0);
+        // (a lane whose ball does not reach the row takes no part in the read: the pass is bound by what goes through the
+        // texture path as much as by instructions -- 44.2 -> 41.2 us per pass against reading a dummy window branch-free.  Measured
+        // on top of it and lost: two 4-byte reads instead of the window (42.5), an 8-byte read for the lanes whose ball stays
+        // inside their own column of cells (47.0), masking the 2nd .. 4th record read of a candidate step (46.4): extra exec
+        // regions cost more than the bytes they save)
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (on) w = __builtin_amdgcn_raw_buffer_load_b128(cs_rsrc, (uint32_t)row << 2, 0, 0);
         // window = starts of the cells cx-1 .. cx+2; span = [start of cell cx - left, start of cell cx + right + 1)
         s0[k] = left ? w.x : w.y;
         e0[k] = right ? w.w : w.z;
@@ -235,6 +251,7 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     }
 #pragma unroll
     for (int k = 0; k < kSpanRows; ++k) spans[k][threadIdx.x] = make_uint2(s0[k], e0[k]);
+    TC_STAMP(1);
     // Flattened walk over the surviving spans, four records per step (four independent gathers in
     // flight per lane); a lane switches to its next span as soon as the current one is exhausted.
     // A step may read up to three records past its span: real target points of the next cells (or
@@ -273,6 +290,7 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         bestj = upd ? im : bestj;
         j += 4;
     }
+    TC_STAMP(2);
     const bool covers = (cx - 1 <= 0) && (cx + 1 >= g.gx - 1) && (cy - 1 <= 0) && (cy + 1 >= g.gy - 1) &&
                         (cz - 1 <= 0) && (cz + 1 >= g.gz - 1);
     const float bound = (1.0f + mf - 2e-3f) * g.h;
@@ -455,6 +473,9 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     const uint32_t lb = xcd_remap_icp(blockIdx.x, gridDim.x);
     const uint32_t beg = lb * chunk;
     const uint32_t end = min(beg + chunk, ns);
+#ifdef TC_PHASE_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#endif
     for (uint32_t gb = beg; gb < end; gb += kIcpGroup * kIcpBlock) {
         // A group = kIcpGroup points per lane, in four stages.  The converged phase of a registration is LATENCY bound (a kept
         // match needs ~150 instructions and three dependent memory round trips), so the loads of the group's points go out
@@ -496,6 +517,10 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             }
         }
         // ---- stage 3 ----
+#ifdef TC_PHASE_STAMPS
+        { float sink = px[0] + py[1] + pz[2] + ubp[3] + ubp[0] + ubp[1] + ubp[2]; asm volatile("" :: "v"(sink)); }
+#endif
+        TC_STAMP(0);
 #pragma unroll
         for (int u = 0; u < kIcpGroup; ++u) {
             const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
@@ -509,7 +534,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             float best = INFINITY;
             uint32_t bestg = 0xFFFFFFFFu;
             bool refine = false;
-            if (__ballot(in && !keep) != 0ull) nn_search_pruned(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans);
+            if (__ballot(in && !keep) != 0ull) nn_search_pruned(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans TC_STAMP_PASS);
             if (keep) { best = ub2p; bestg = pj; }
             refine = refine && in && !keep;
             if ((dbg & 8) && lane == 0) {          // statistics: wave trips / trips without a search
@@ -534,6 +559,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             const uint32_t newv = valid ? bestg : 0xFFFFFFFFu;
             if (j < end && !refine && (!warm || newv != pj)) corr_pos[j] = newv;     // an unchanged match is not written again
             mv[u] = (dbg & 16) ? 0xFFFFFFFFu : newv;                             // dbg & 16: timing experiments only (no sums)
+            TC_STAMP(3);
         }
         // ---- stage 4 ----: per-pair terms of the group -> per-lane f32 sums -> the wave's f64 row
         float acc[NACC];
@@ -563,8 +589,13 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
                 }
             }
         }
+#ifdef TC_PHASE_STAMPS
+        { float sink = 0.f; for (int i = 0; i < NACC; ++i) sink += acc[i]; asm volatile("" :: "v"(sink)); }
+#endif
+        TC_STAMP(4);
         // per-group fold: transposing wave reduction (f32, fixed tree) -> this wave's f64 row
         wave_fold_transposed<NACC>(acc, red[w], lane);
+        TC_STAMP(5);
     }
     __syncthreads();
     if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
@@ -579,6 +610,10 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     if (blk_times && threadIdx.x == 0) {
         blk_times[2 * blockIdx.x] = t_begin;
         blk_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#ifdef TC_PHASE_STAMPS
+        TC_STAMP(6);
+        for (int i = 0; i < 8; ++i) blk_times[2 * kMaxPartialBlocks + 8 * blockIdx.x + i] = ph[i];
+#endif
     }
 }
 
@@ -1329,7 +1364,10 @@ static tc_status launch_target_nn_bounds(tc_context *ctx, DeviceIndex &ix, const
 
 // ~1.45 pts/cell.  Scanned again after the main / refine split (50-iteration ICP, 1 M points): 0.8 -> 6.55 ms, 0.9 -> 5.55,
 // 1.0 -> 5.00, 1.13 -> 4.75, 1.25 -> 4.72, 1.4 -> 4.72 (flat: the main pass grows as the refine pass shrinks)
-float icp_cell_factor() { return 1.13f; }   // ~1.45 pts/cell: ring 1 is exact for ~99.8 % of uniform queries
+float icp_cell_factor() {             // (TC_ICP_CELL_FACTOR: tuning experiments)
+    static const float v = [] { const char *e = getenv("TC_ICP_CELL_FACTOR"); return e ? (float)atof(e) : 1.13f; }();
+    return v;
+}   // ~1.45 pts/cell: ring 1 is exact for ~99.8 % of uniform queries
 
 struct IcpSetup {
     IcpLaunch l;
@@ -1408,12 +1446,19 @@ tc_status icp_run_gicp(tc_context *ctx, const float *d_src, size_t ns, const flo
 // when chunk c did not finish the job: a first chunk of 6 and a second of 2 make a registration that converges within 6
 // iterations -- scan-to-scan odometry -- pay 8 iterations of launches instead of 16 (that was 1/3 of a LiDAR frame's time).
 // The events live in the context (created once, reused by every call).
+// A run that did not converge has executed exactly max_iters iterations (registration.rs:278 / :533): the device counts them
+static tc_status check_iteration_count(tc_context *ctx, const IcpState *hs, size_t max_iters) {
+    if (hs->status == TC_OK && !hs->converged && hs->iterations != max_iters)
+        return fail(ctx, TC_GPU, "internal error: the ICP loop executed " + std::to_string(hs->iterations) + " of " + std::to_string(max_iters) + " iterations");
+    return TC_OK;
+}
+
 template <typename F>
 static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate, F &&enqueue_iteration) {
     hipStream_t st = ctx->stream;
     auto chunk_len = [](size_t c) -> size_t { return c == 0 ? 6 : c == 1 ? 2 : c == 2 ? 4 : 8; };
     size_t nchunks = 0;
-    for (size_t covered = 0; covered < max_iters; covered += chunk_len(nchunks)) ++nchunks;
+    for (size_t covered = 0; covered < max_iters; ++nchunks) covered += chunk_len(nchunks);
     int32_t *flags = (int32_t *)((char *)ctx->pinned + 1024);
     const size_t max_flags = 200;                                  // pinned bytes 1024 .. 2048 hold them (the bbox partials follow)
     size_t it = 0;
@@ -1467,7 +1512,7 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     // the first iteration on; otherwise they are computed once the registration has run for a while
     const float4 *vor = su.tix->vor_valid ? (const float4 *)su.tix->vor.p : nullptr;
     if (debug_flags() & 1024)
-        if (tc_status s = ensure(ctx, ctx->dbg_times, 2 * (size_t)kMaxPartialBlocks * sizeof(unsigned long long))) return s;
+        if (tc_status s = ensure(ctx, ctx->dbg_times, 10 * (size_t)kMaxPartialBlocks * sizeof(unsigned long long))) return s;
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
             if (enq++ == vor_after() && !vor)
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
@@ -1502,6 +1547,15 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
         fprintf(stderr, "[tc] main pass blocks: %u; span %.1f us; block duration us min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f; start p50 %.1f p99 %.1f max %.1f; end p10 %.1f p50 %.1f p90 %.1f\n",
                 su.l.nblocks, (t1 - t0) * 0.01, dur.front(), q(dur, 0.1), q(dur, 0.5), q(dur, 0.9), q(dur, 0.99), dur.back(), q(startt, 0.5), q(startt, 0.99), startt.back(),
                 q(endt, 0.1), q(endt, 0.5), q(endt, 0.9));
+#ifdef TC_PHASE_STAMPS
+        {
+            std::vector<unsigned long long> hp(8 * (size_t)su.l.nblocks);
+            (void)hipMemcpy(hp.data(), (unsigned long long *)ctx->dbg_times.p + 2 * kMaxPartialBlocks, hp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            double m[8] = {0};
+            for (size_t b = 0; b < su.l.nblocks; ++b) for (int i = 0; i < 8; ++i) m[i] += (double)hp[8 * b + i] / su.l.nblocks;
+            fprintf(stderr, "[tc]   wave 0 phases, mean s_memtime ticks: stage1-2 %.0f  windows %.0f  loop %.0f  post %.0f  stage4 %.0f  fold %.0f  end %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+        }
+#endif
         fprintf(stderr, "[tc]   per XCD (block & 7): mean duration / last end, us:");
         for (int x = 0; x < 8; ++x) {
             double sum = 0, last = 0; int cnt = 0;
@@ -1520,6 +1574,7 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
                     : p2plane ? "Insufficient correspondences for point-to-plane ICP (need >= 6) or ill-conditioned system"
                             : "Insufficient correspondences found");
     }
+    if (tc_status s = check_iteration_count(ctx, hs, max_iters)) return s;
     for (int i = 0; i < 4; ++i) res->transformation[i] = hs->q[i];
     for (int i = 0; i < 3; ++i) res->transformation[4 + i] = hs->t[i];
     res->mse = hs->mse;
@@ -1598,6 +1653,7 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     if (hs->status != TC_OK)
         return fail(ctx, (tc_status)hs->status, p2plane ? "Insufficient correspondences for point-to-plane ICP (need >= 6) or ill-conditioned system"
                                                         : "Insufficient correspondences found");
+    if (tc_status s = check_iteration_count(ctx, hs, max_iters)) return s;
     for (int i = 0; i < 4; ++i) res->transformation[i] = hs->q[i];
     for (int i = 0; i < 3; ++i) res->transformation[4 + i] = hs->t[i];
     res->mse = hs->mse;

@@ -1,0 +1,18 @@
+#!/bin/bash
+# dev: build a variant of the library with extra compiler flags (A/B experiments on the GPU box):
+#   bash tools/dev/build_variant.sh <name> "<extra flags>"   ->  threecrate_amd/variants/libthreecrate_hip_<name>.so
+# (git-ignored, travels with gpurun; select it with TC_HIP_LIB=threecrate_amd/variants/libthreecrate_hip_<name>.so)
+set -eu
+NAME=$1; EXTRA=${2:-}
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+SRC=$ROOT/threecrate_amd/csrc
+OBJ=$ROOT/build/var_$NAME
+mkdir -p "$OBJ" "$ROOT/threecrate_amd/variants"
+pids=()
+for f in api grid normals icp voxel stream comm cloud; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result $EXTRA -c "$SRC/$f.hip" -o "$OBJ/$f.o" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/threecrate_amd/variants/libthreecrate_hip_$NAME.so" "$OBJ"/*.o -lpthread -ldl
+echo "built threecrate_amd/variants/libthreecrate_hip_$NAME.so"

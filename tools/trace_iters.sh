@@ -20,5 +20,5 @@ for pat in ("icp_correspond", "icp_refine", "icp_finalize"):
     d = d[-50:]
     print(pat, "last call, us per launch:")
     print("  " + " ".join(f"{x:.0f}" for x in d))
-    print(f"  mean {sum(d)/len(d):.1f}")
+    print(f"  mean {sum(d)/len(d):.1f}   launches 2-37 {sum(d[1:37])/36:.1f}   last 8 {sum(d[-8:])/8:.1f}")
 PY
