@@ -94,7 +94,35 @@ def lib():
         L.tco_isometry_mul.argtypes = [f32p, f32p, f32p]
         L.tco_isometry_to_matrix.argtypes = [f32p, f32p]
         L.tco_num_threads.restype = C.c_int
+        L.tco_set_max_threads.argtypes = [C.c_int]
+        L.tco_set_max_threads.restype = None
+        L.tco_set_max_threads(effective_cpus())
     return _LIB
+
+
+def effective_cpus():
+    """CPUs this process can actually run on: the scheduler affinity capped by the container's CPU bandwidth quota (cgroup v2
+    cpu.max / v1 cfs quota).  A GPU box shows 256 CPUs under a 16-core quota: 256 runnable OpenMP threads there are throttled,
+    not run (a 60-iteration ICP on 1500 points takes seconds instead of milliseconds)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
 
 
 def _f32(a, shape_last=None):

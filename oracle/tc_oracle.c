@@ -297,9 +297,14 @@ size_t tco_brute_knn(const float *xyz, size_t n, const float q[3], size_t k, uin
     return m;
 }
 
+/* threads a call with `threads <= 0` uses: OpenMP's maximum, capped by tco_set_max_threads (oracle.py passes the container's
+   CPU quota: a box that shows 256 CPUs under a 16-core quota runs 256 runnable threads 10x slower than 16) */
+static int g_max_threads = 0;
+void tco_set_max_threads(int n) { g_max_threads = n > 0 ? n : 0; }
 int tco_num_threads(void) {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    int mx = omp_get_max_threads();
+    return (g_max_threads > 0 && g_max_threads < mx) ? g_max_threads : mx;
 #else
     return 1;
 #endif
@@ -1084,19 +1089,35 @@ static void find_correspondences(const float *tsrc, size_t ns, const tco_kdtree 
     }
 }
 
+/* DIAGNOSTIC switch, see the comment above p2plane_solve (default 0 = the reference's arithmetic) */
+static int g_exact_sums = 0;
+void tco_set_exact_sums(int on) { g_exact_sums = on; }
+
 /* compute_transformation (registration.rs:144-203) */
 static int kabsch(const float *vs, const float *vq, size_t n, float out[7]) {
     float nf = (float)n;
     float cs[3] = { 0, 0, 0 }, cq[3] = { 0, 0, 0 };
+    float h[3][3] = { {0, 0, 0}, {0, 0, 0}, {0, 0, 0} };
+    if (g_exact_sums) {          /* the same f32 terms, added in f64 */
+        double dcs[3] = { 0, 0, 0 }, dcq[3] = { 0, 0, 0 }, dh[3][3] = { {0, 0, 0}, {0, 0, 0}, {0, 0, 0} };
+        for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) { dcs[c] += (double)vs[3 * i + c]; dcq[c] += (double)vq[3 * i + c]; }
+        for (int c = 0; c < 3; ++c) { cs[c] = (float)dcs[c] / nf; cq[c] = (float)dcq[c] / nf; }
+        for (size_t i = 0; i < n; ++i) {
+            float p[3] = { vs[3 * i] - cs[0], vs[3 * i + 1] - cs[1], vs[3 * i + 2] - cs[2] };
+            float q[3] = { vq[3 * i] - cq[0], vq[3 * i + 1] - cq[1], vq[3 * i + 2] - cq[2] };
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) dh[r][c] += (double)(p[r] * q[c]);
+        }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) h[r][c] = (float)dh[r][c];
+    } else {
     for (size_t i = 0; i < n; ++i) { cs[0] = cs[0] + vs[3 * i]; cs[1] = cs[1] + vs[3 * i + 1]; cs[2] = cs[2] + vs[3 * i + 2]; }
     cs[0] /= nf; cs[1] /= nf; cs[2] /= nf;
     for (size_t i = 0; i < n; ++i) { cq[0] = cq[0] + vq[3 * i]; cq[1] = cq[1] + vq[3 * i + 1]; cq[2] = cq[2] + vq[3 * i + 2]; }
     cq[0] /= nf; cq[1] /= nf; cq[2] /= nf;
-    float h[3][3] = { {0, 0, 0}, {0, 0, 0}, {0, 0, 0} };
     for (size_t i = 0; i < n; ++i) {
         float p[3] = { vs[3 * i] - cs[0], vs[3 * i + 1] - cs[1], vs[3 * i + 2] - cs[2] };
         float q[3] = { vq[3 * i] - cq[0], vq[3 * i + 1] - cq[1], vq[3 * i + 2] - cq[2] };
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) h[r][c] += p[r] * q[c];
+    }
     }
     float U[3][3], w[3], Vt[3][3];
     svd3(h, U, w, Vt);
@@ -1116,7 +1137,7 @@ static int kabsch(const float *vs, const float *vq, size_t n, float out[7]) {
 }
 /* batch form of tco_symmetric_eigen3 for the differential tests on real covariance matrices (tests/test_oracle_pinning.py) */
 void tco_symmetric_eigen3_batch(const float *m9, size_t n, float *evals3, float *evecs9) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(tco_num_threads())
     for (long long i = 0; i < (long long)n; ++i) tco_symmetric_eigen3(&m9[9 * i], &evals3[3 * i], &evecs9[9 * i]);
 }
 
@@ -1126,10 +1147,13 @@ void tco_kabsch(const float *s, const float *q, size_t n, float out7[7], int *ok
 static float compute_mse(const float *vs, const float *vq, size_t n) {
     if (n == 0) return 0.0f;
     float sum = 0.0f;
+    double dsum = 0.0;
     for (size_t i = 0; i < n; ++i) {
         float dx = vs[3 * i] - vq[3 * i], dy = vs[3 * i + 1] - vq[3 * i + 1], dz = vs[3 * i + 2] - vq[3 * i + 2];
         sum += dx * dx + dy * dy + dz * dz;
+        dsum += (double)(dx * dx + dy * dy + dz * dz);
     }
+    if (g_exact_sums) return (float)(dsum / (double)n);
     return sum / (float)n;
 }
 
@@ -1213,10 +1237,10 @@ void tco_icp(const float *src, size_t ns, const float *tgt, size_t nt,
  * (terms below half an ulp of the running sum are even dropped outright).  With the switch on, the SAME f32 per-pair terms are
  * added in f64, i.e. the sums the reference's formula defines, without its accumulation error.  Tests use it to show that a
  * transform which is 2e-5 away from the reference's on a 10^6-point surface is that far away because of the reference's own
- * accumulation error, not because of different pairs or a different solve (tests/test_gpu_fullsize.py). */
-static int g_exact_sums = 0;
-void tco_set_exact_sums(int on) { g_exact_sums = on; }
-
+ * accumulation error, not because of different pairs or a different solve (tests/test_gpu_fullsize.py).
+ * The switch (defined above compute_transformation) also covers the Kabsch sums and both mse sums, i.e. every sum over the
+ * pairs of an iteration: tools/dev/loop_fuzz.py uses it to tell a stop decision taken within the reference's own rounding
+ * (|prev_mse - mse| < threshold) from a defect. */
 /* compute_transformation_point_to_plane (registration.rs:395-450) */
 static int p2plane_solve(const float *vs, const float *vq, const float *vn, size_t n, float out[7]) {
     float ata[36]; float atb[6];
@@ -1256,11 +1280,14 @@ static int p2plane_solve(const float *vs, const float *vq, const float *vn, size
 static float p2plane_mse(const float *vs, const float *vq, const float *vn, size_t n) {
     if (n == 0) return 0.0f;
     float sum = 0.0f;
+    double dsum = 0.0;
     for (size_t i = 0; i < n; ++i) {
         float d[3] = { vq[3 * i] - vs[3 * i], vq[3 * i + 1] - vs[3 * i + 1], vq[3 * i + 2] - vs[3 * i + 2] };
         float dd = vn[3 * i] * d[0] + vn[3 * i + 1] * d[1] + vn[3 * i + 2] * d[2];
         sum += dd * dd;
+        dsum += (double)(dd * dd);
     }
+    if (g_exact_sums) return (float)(dsum / (double)n);
     return sum / (float)n;
 }
 

@@ -133,7 +133,8 @@ void tco_kabsch(const float *s, const float *q, size_t n, float out7[7], int *ok
 void tco_isometry_apply(const float T[7], const float p[3], float out[3]);
 void tco_isometry_mul(const float a[7], const float b[7], float out[7]);
 void tco_isometry_to_matrix(const float T[7], float m16[16] /* row-major 4x4 */);
-int  tco_num_threads(void);
+int  tco_num_threads(void);            /* threads a call with threads <= 0 uses */
+void tco_set_max_threads(int n);       /* cap for that (0: OpenMP's maximum) */
 
 #ifdef __cplusplus
 }

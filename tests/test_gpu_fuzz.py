@@ -16,7 +16,7 @@ def test_randomized_differential_run(ctx):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     lines = []
-    cases, bad = fuzz.run(15.0, 7, ctx, fuzz.SMALL, log=lines.append)
+    cases, bad = fuzz.run(15.0, 7, ctx, fuzz.SMALL, log=lambda *a: lines.append(" ".join(map(str, a))))
     assert cases > 100 and bad == 0, "\n".join(lines[-40:])
 
 
@@ -31,3 +31,19 @@ def test_inscribed_ball_test_never_changes_a_result():
     spec.loader.exec_module(mod)
     n, bad = mod.compare(12.0, 5)
     assert n >= 10 and bad == 0
+
+
+@pytest.mark.gpu
+def test_loop_control_differential_run(ctx):
+    """tools/dev/loop_fuzz.py: iteration counts 1..60, convergence thresholds from 0 to 1e-2 (stops after any number of iterations,
+    in the middle of any chunk of the enqueue schedule), with / without a maximum correspondence distance, initial guesses,
+    point-to-point and point-to-plane, plain calls and cloud handles, against the oracle.  Where a run parts from the oracle's,
+    both sides are replayed iteration by iteration and the first step at which they part must be decided by rounding: pairs that
+    are each the nearest under the side's own transform, a stop whose margin is within what the transforms' distance explains,
+    a residual at the rounding floor of the coordinates."""
+    spec = importlib.util.spec_from_file_location("tc_loop_fuzz", os.path.join(ROOT, "tools", "dev", "loop_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    cases, bad = mod.run(15.0, 11, ctx, log=lambda *a: lines.append(" ".join(map(str, a))))
+    assert cases > 300 and bad == 0, "\n".join(lines[-40:])
