@@ -47,3 +47,18 @@ def test_loop_control_differential_run(ctx):
     lines = []
     cases, bad = mod.run(15.0, 11, ctx, log=lambda *a: lines.append(" ".join(map(str, a))))
     assert cases > 300 and bad == 0, "\n".join(lines[-40:])
+
+
+@pytest.mark.gpu
+def test_normals_parameter_space_differential_run(ctx):
+    """tools/dev/normals_fuzz.py: k from 1 to 128 (and k >= n), radius mode from far below to far above the point spacing with
+    its k-NN fallback, viewpoints, orientation on / off, plain calls / device tensors / handles, clouds of 2 .. 6000 points incl.
+    lattices with ties everywhere and exact duplicates.  Every normal beyond 1e-4 cosine of the oracle's must be explained by
+    the input: a tie at the neighbourhood boundary, a degenerate smallest eigen-pair, or a covariance at which the reference's
+    own eigen-solver is discontinuous (tests/h1.py reference_solver_spread)."""
+    spec = importlib.util.spec_from_file_location("tc_normals_fuzz", os.path.join(ROOT, "tools", "dev", "normals_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    cases, bad = mod.run(15.0, 13, ctx, log=lambda *a: lines.append(" ".join(map(str, a))))
+    assert cases > 300 and bad == 0, "\n".join(lines[-40:])

@@ -1,0 +1,140 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+"""dev: randomized differential run of estimate_normals against the oracle over its whole parameter space: k from 1 to 128
+(and k >= n), radius mode with radii from far below to far above the point spacing (k-NN fallback when the ball holds too few
+points, normals.rs:315), explicit viewpoints, orientation on / off, plain calls / cloud handles / device tensors, clouds from 2
+to 6000 points incl. slabs, surfaces, near-collinear sets, lattices with exact ties and exact duplicates.  Every normal beyond
+1e-4 cosine of the oracle's must be EXPLAINED by the input (tests/h1.py: an exact tie at the neighbourhood boundary or a
+degenerate smallest eigen-pair); positions must be copied through bit for bit; errors must match.
+usage: python tools/dev/normals_fuzz.py [seconds] [seed] [case]"""
+import time
+import numpy as np
+import threecrate_amd as tc
+from oracle import oracle as O
+from tests import h1
+
+
+def explain_offender(p, i, k, radius, tree):
+    """the neighbourhood the reference builds for point i (normals.rs:135-155, :309-340) and why its normal may legitimately
+    differ: an exact tie at the k-NN boundary (the set is implementation defined), a degenerate smallest eigen-pair, or a
+    covariance at which the reference's eigen-solver is discontinuous (tests/h1.py)"""
+    n = len(p)
+    d2 = h1.d2_f32(p, p[i])
+    order = np.argsort(d2, kind="stable")
+    def knn_set(kk):            # the kk nearest OTHER points (ties: any); + whether the boundary is tied
+        kk = min(kk, n - 1)
+        others = order[order != i]
+        tie = kk < len(others) and d2[others[kk - 1]] == d2[others[kk]] if kk >= 1 else False
+        # (the reference asks the tree for kk + 1 points and drops the query: with more than kk exact duplicates of the query
+        # the query itself may be missing from the answer -- also a tie, at distance 0)
+        return others[:kk], bool(tie)
+    tie = False
+    if radius is not None:
+        ridx, rdist = tree.find_radius_neighbors(p[i], radius)
+        nb = np.array([int(t) for t in ridx if int(t) != i], np.int64)
+        # a neighbour exactly ON the sphere, or within rounding of it: in or out is decided by the last bit of the distance
+        edge = np.abs(np.sqrt(d2.astype(np.float64)) - radius) <= 4e-7 * max(radius, 1e-30)
+        edge[i] = False
+        tie = bool(edge.any())
+        if len(nb) < k: nb, t2 = knn_set(k); tie = tie or t2
+    else:
+        nb, tie = knn_set(k)
+    if len(nb) < 3: nb, t2 = knn_set(max(k, 5)); tie = tie or t2
+    if tie: return True, "tie at the neighbourhood boundary"
+    nbh = np.concatenate([nb, [i]])
+    if len(nbh) < 3: return True, "fewer than 3 points: default normal on both sides is checked elsewhere"
+    ev = np.linalg.eigvalsh(np.cov(p[nbh].astype(np.float64).T, bias=True))
+    gap = float((ev[1] - ev[0]) / max(ev[2], 1e-300))
+    if gap < h1.EIGEN_GAP_BOUND: return True, f"degenerate eigen-pair (gap {gap:.1e})"
+    spread = h1.reference_solver_spread(p[nbh])
+    if spread > 1e-4: return True, f"reference solver discontinuous here (spread {spread:.1e})"
+    return False, f"gap {gap:.2e} solver spread {spread:.1e} neighbourhood of {len(nbh)}"
+
+
+def run(budget, seed, ctx, log=print, only_case=None):
+    t_end = time.time() + budget
+    cases = bad = explained = 0
+    while time.time() < t_end:
+        cases += 1
+        if only_case is not None:
+            if cases > 1: break
+            cases = only_case
+        rng = np.random.default_rng([seed, cases])
+        n = int(rng.choice([2, 3, 7, 40, 300, 1500, 6000]))
+        kind = int(rng.integers(0, 6))
+        if kind == 0: p = rng.random((n, 3))
+        elif kind == 1: p = rng.random((n, 3)) * np.array([10.0, 3.0, 0.2])
+        elif kind == 2: u = rng.random((n, 2)); p = np.stack([u[:, 0], u[:, 1], 0.1 * np.sin(6 * u[:, 0]) + 1e-4 * rng.normal(size=n)], 1)
+        elif kind == 3: t = rng.random(n); p = np.stack([t, 2 * t, -t], 1) + 1e-3 * rng.normal(size=(n, 3))
+        elif kind == 4: p = np.round(rng.random((n, 3)) * 8) / 8
+        else: p = rng.random((n, 3)); p[: n // 4] = p[0]
+        p = (p * rng.choice([1e-2, 1.0, 50.0])).astype(np.float32)
+        spacing = float(np.linalg.norm(p.max(0) - p.min(0))) / max(n, 2) ** (1.0 / 3.0) + 1e-12
+        k = int(rng.choice([1, 2, 3, 5, 10, 16, 17, 31, 32, 33, 64, 100, 127, 128, int(rng.integers(1, 129))]))
+        radius = None if rng.random() < 0.6 else float(spacing * rng.choice([0.05, 0.5, 1.5, 4.0, 50.0]))
+        orient = bool(rng.random() < 0.7)
+        vp = None if rng.random() < 0.6 else tuple((p.mean(0) + (p.std(0) + 1e-3) * rng.normal(0, 3, 3)).tolist())
+        mode = int(rng.integers(0, 3))           # 0 plain host call, 1 device tensor, 2 cloud handle
+        tag = f"case {cases}: n {n} kind {kind} k {k} radius {radius} orient {orient} viewpoint {vp is not None} mode {mode}"
+        try:
+            cfg = tc.NormalEstimationConfig(k_neighbors=k, radius=radius, consistent_orientation=orient, viewpoint=vp)
+            try:
+                if mode == 0: g = ctx.estimate_normals_with_config(p, cfg)
+                elif mode == 1:
+                    import torch
+                    g = ctx.estimate_normals_with_config(torch.from_numpy(p).cuda(), cfg).cpu().numpy()
+                else:
+                    h = tc.Cloud(ctx, p)
+                    try: g = h.estimate_normals(k, cfg)
+                    finally: h.close()
+                gerr = None
+            except tc.Error as e:
+                g, gerr = None, type(e).__name__ + ": " + str(e)
+            try:
+                r = O.estimate_normals(p, k, radius=radius, consistent_orientation=orient, viewpoint=vp)
+                rerr = None
+            except O.OracleError as e:
+                r, rerr = None, str(e)
+            if (g is None) != (r is None):
+                bad += 1; log("ERROR MISMATCH", tag, "| gpu:", gerr, "| oracle:", rerr); continue
+            if g is None: continue
+            if g.shape != r.shape or not np.array_equal(g[:, :3], r[:, :3]):
+                bad += 1; log("POSITIONS DIFFER", tag); continue
+            if not np.isfinite(g).all() and np.isfinite(r).all():
+                bad += 1; log("NON-FINITE NORMALS", tag); continue
+            c = h1.cos_abs(g[:, 3:], r[:, 3:])
+            off = np.nonzero(~(c >= 1 - 1e-4))[0]
+            if len(off) == 0:
+                # orientation: where the normals agree they must agree in sign too (normals.rs:207-236), except a normal
+                # perpendicular to the view direction within rounding
+                sgn = np.sum(g[:, 3:].astype(np.float64) * r[:, 3:], axis=1)
+                flipped = np.nonzero(sgn < 0)[0]
+                if orient and len(flipped):
+                    if vp is not None: ctr = np.asarray(vp, np.float64)
+                    else:               # normals.rs:280-303: above the centre of the bounding box by its diagonal
+                        lo, hi = p.min(0).astype(np.float64), p.max(0).astype(np.float64)
+                        ctr = (lo + hi) / 2 + np.array([0.0, 0.0, np.linalg.norm(hi - lo)])
+                    d = ctr - p[flipped].astype(np.float64)
+                    dots = np.abs(np.sum(d * r[flipped, 3:], axis=1)) / np.maximum(np.linalg.norm(d, axis=1), 1e-30)
+                    if (dots > 0.02).any():          # (two normals within 1e-4 cosine are up to 0.0142 rad apart)
+                        bad += 1; log("ORIENTATION DIFFERS", tag, len(flipped), float(dots.max())); continue
+                    explained += 1
+                continue
+            # every offender (a sample of 200 where ties are everywhere) through the per-point explanation
+            sample = off if len(off) <= 200 else rng.choice(off, 200, replace=False)
+            tree = O.KdTree(p)
+            unexplained = [(int(i_), why) for i_, (ok, why) in ((i_, explain_offender(p, int(i_), k, radius, tree)) for i_ in sample) if not ok]
+            if unexplained:
+                bad += 1; log("UNEXPLAINED NORMALS", tag, len(unexplained), "of", len(sample), "sampled offenders, first:", unexplained[0], "1-|cos|", float(1 - c[unexplained[0][0]]))
+            else:
+                explained += 1
+        except Exception as e:
+            bad += 1; log("EXCEPTION", tag, type(e).__name__, str(e)[:300])
+    log(f"normals fuzz: {cases} cases, {bad} problems, {explained} with differences explained by ties / degenerate eigen-pairs")
+    return cases, bad
+
+
+if __name__ == "__main__":
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("FUZZ_DUMP_AFTER", "1500")), exit=True)
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0, tc.GpuContext(0),
+        only_case=int(sys.argv[3]) if len(sys.argv) > 3 else None)
