@@ -48,7 +48,15 @@ struct NormalParams {
                             // distance to the nearest OTHER record = the second entry of the k-NN list, for free here)
     uint32_t p_begin, p_end;    // cell-sorted positions handled by this launch (a multi-GPU shard: SURVEY 8e)
     int      slice_out;         // 1: record of position p goes to row p - p_begin (sorted order) instead of its original index
+#ifdef TC_PHASE_STAMPS
+    unsigned long long *stamps; // dev build: 8 per block (wave 0's shader clocks per phase)
+#endif
 };
+#ifdef TC_PHASE_STAMPS
+#define TC_NSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tl; tl = t_; } while (0)
+#else
+#define TC_NSTAMP(i) do { } while (0)
+#endif
 
 // ---- smallest-eigenvalue eigenvector of a symmetric 3x3 (f64) -------------------------------
 __device__ __forceinline__ void smallest_eigvec_sym3(double a00, double a01, double a02, double a11, double a12,
@@ -346,7 +354,16 @@ __device__ __forceinline__ void scan_block(const GridView &gv, int cx, int cy, i
         for (int y = y0; y <= y1; ++y) {
             const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
             const uint32_t s = gv.cell_start[row + x0], e = gv.cell_start[row + x1 + 1];
-            for (uint32_t j = s; j < e; ++j) f(j, gv.pts[j]);
+            // the record of step i + 1 is requested before step i is evaluated (the padding behind the array makes pts[e] readable):
+            // 1-3 % (k = 10 / 16 / 32: 410 -> 398, 535 -> 532, 1048 -> 1029 us)
+            if (s < e) {
+                float4 c = gv.pts[s];
+                for (uint32_t j = s; j < e; ++j) {
+                    const float4 cn = gv.pts[j + 1];
+                    f(j, c);
+                    c = cn;
+                }
+            }
         }
     }
 }
@@ -414,9 +431,14 @@ __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q,
     return touched;
 }
 
+
 template <int L, int BLOCK, bool RADIUS, bool EXT>
 __device__ __forceinline__ void normals_point(const GridView &gv, const NormalParams &prm, uint32_t p,
-                                              float *__restrict__ out6, uint32_t *ldsA, uint8_t *ldsB) {
+                                              float *__restrict__ out6, uint32_t *ldsA, uint8_t *ldsB
+#ifdef TC_PHASE_STAMPS
+                                              , unsigned long long (&ph)[8], unsigned long long &tl
+#endif
+                                              ) {
     const GridGeom &g = gv.g;
     const float4 q = gv.pts[p];
     const uint32_t orig = __float_as_uint(q.w);
@@ -474,7 +496,10 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         (OUT) = tk_;                                                                \
     } while (0)
     // ring R0: the whole block (no bound known yet)
+    TC_NSTAMP(0);
     scan_block(gv, cx, cy, cz, R, visit1);
+    { float sink_ = d[L - 1]; asm volatile("" :: "v"(sink_)); }
+    TC_NSTAMP(1);
     for (;;) {
         TC_KTH(tau);
         const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
@@ -510,6 +535,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     }
 
 #undef TC_KTH
+    TC_NSTAMP(2);
     // d[0] is the query itself (0), d[1] the squared distance to its nearest OTHER record (0 for an exact duplicate: never kept)
     if (prm.vor_out) prm.vor_out[p] = make_float4(q.x, q.y, q.z, 0.25f * 0.9999f * d[1]);
     float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
@@ -529,14 +555,21 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     for (int t = 0; t < L; ++t) n_lt += (d[t] < tau) ? 1u : 0u;
     const uint32_t quota = K1 - min(n_lt, K1);
     uint32_t cnt = 0, ties = 0;
-    // rescan only the cells within sqrt(tau) of the query (same visiting order as phase 1)
+    // rescan only the cells within sqrt(tau) of the query (same visiting order as phase 1).  (Measured instead: the plain,
+    // unpruned block scan for lanes that never grew their block: 554 vs 536 us -- the lanes of a wave walk the rows in lockstep
+    // either way; a centre-out flattened walk with live pruning, every lane opening its next row inside the candidate loop:
+    // 1.2 ms -- the row logic then runs divergently at every step; the same with the rows' spans computed by all lanes together
+    // in three batches (9 central rows, then 2 x 8 outer rows judged against the list's last entry), parked in LDS and walked
+    // flattened, lanes whose ring-2 block is not enough left to a second launch of this kernel: 648 us + 264 us for the second
+    // launch (0.2 % of the points, but a lone wave's 18 k dependent instructions ARE its duration): VALU instructions -17 %, SALU
+    // +117 % (exec-mask bookkeeping of the divergent loops): the per-candidate insertion is the cost, not the number of steps.)
     scan_pruned<EXT>(gv, q, cx, cy, cz, -1, R, tau, [&](uint32_t j, const float4 &c) {
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
         bool take = v < tau;
         if (!take && v == tau && ties < quota) { take = true; ++ties; }
         if (take && cnt < K1) { ldsA[cnt * BLOCK] = j; ++cnt; }
     });
-
+    TC_NSTAMP(3);
     // rank -> ascending-distance order (ties keep scan order)
     unsigned long long taken_lo = 0ull, taken_hi = 0ull, taken_x = 0ull;   // bitset over ranks 0..191 (L <= 129)
     auto is_taken = [&](uint32_t r) { return r < 64 ? ((taken_lo >> r) & 1ull) : r < 128 ? ((taken_hi >> (r - 64)) & 1ull) : ((taken_x >> (r - 128)) & 1ull); };
@@ -553,6 +586,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         ldsB[r * BLOCK] = (uint8_t)e;           // rank -> entry index (one byte; the positions stay in ldsA)
         if (j == p) self_r = (int)r;
     }
+    TC_NSTAMP(4);
     // normals.rs:147-153: drop self from the k+1 list (or the last entry when self is not in it)
     const int drop_r = (self_r >= 0) ? self_r : (int)cnt - 1;
     const uint32_t npts = cnt;   // (cnt - 1) neighbours + self
@@ -580,6 +614,8 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
             cxx += dx * dx; cxy += dx * dy; cxz += dx * dz; cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
         }
         cxx /= nf; cxy /= nf; cxz /= nf; cyy /= nf; cyz /= nf; czz /= nf;
+        { float sink_ = cxx + cxy + cxz + cyy + cyz + czz; asm volatile("" :: "v"(sink_)); }
+        TC_NSTAMP(5);
         float e0, e1, e2, x0, y0, z0, x1, y1, z1, x2, y2, z2;
         sym_eigen3_f32(cxx, cxy, cxz, cyy, cyz, czz, e0, e1, e2, x0, y0, z0, x1, y1, z1, x2, y2, z2);          // normals.rs:181
         // first index with the strictly smallest eigenvalue (normals.rs:186-191), its column of q
@@ -597,11 +633,14 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         const float dp = nrm_x * ux + nrm_y * uy + nrm_z * uz;
         if (dp < 0.0f) { nrm_x = -nrm_x; nrm_y = -nrm_y; nrm_z = -nrm_z; }
     }
+    { float sink_ = nrm_x + nrm_y + nrm_z; asm volatile("" :: "v"(sink_)); }
+    TC_NSTAMP(6);
     if (prm.sorted_nrm) prm.sorted_nrm[p] = make_float4(nrm_x, nrm_y, nrm_z, 0.0f);      // coalesced: lane = position
     if (out6) {
         float *o = out6 + 6 * (size_t)(prm.slice_out ? p - prm.p_begin : orig);
         o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = nrm_x; o[4] = nrm_y; o[5] = nrm_z;
     }
+    TC_NSTAMP(7);
 }
 
 // XCD-aware block remap: hardware deals blocks round-robin over the 8 XCDs, so give each XCD
@@ -619,7 +658,13 @@ __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, Nor
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t p = prm.p_begin + lb * BLOCK + threadIdx.x;
     if (p >= prm.p_end) return;
+#ifdef TC_PHASE_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+    normals_point<L, BLOCK, RADIUS, EXT>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x, ph, tl);
+    if (threadIdx.x == 0 && prm.stamps) for (int i = 0; i < 8; ++i) prm.stamps[8 * (size_t)blockIdx.x + i] = ph[i];
+#else
     normals_point<L, BLOCK, RADIUS, EXT>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+#endif
 }
 
 template <int L, int BLOCK, bool RADIUS = false>
@@ -836,6 +881,29 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     prm.p_begin = (uint32_t)p_begin;
     prm.p_end = (uint32_t)std::min<size_t>(p_end, ix.geom.n);
     prm.slice_out = slice_out ? 1 : 0;
+#ifdef TC_PHASE_STAMPS
+    prm.stamps = nullptr;
+    const size_t stamp_blocks = ((prm.p_end - prm.p_begin) / 64 + 16);
+    if (debug_flags() & 1024) {
+        if (tc_status s = ensure(ctx, ctx->dbg_times, 8 * stamp_blocks * sizeof(unsigned long long))) return s;
+        (void)hipMemsetAsync(ctx->dbg_times.p, 0, 8 * stamp_blocks * sizeof(unsigned long long), ctx->stream);
+        prm.stamps = (unsigned long long *)ctx->dbg_times.p;
+    }
+    struct StampDump {
+        tc_context *ctx; size_t nb; bool on;
+        ~StampDump() {
+            if (!on) return;
+            (void)hipStreamSynchronize(ctx->stream);
+            std::vector<unsigned long long> h(8 * nb);
+            (void)hipMemcpy(h.data(), ctx->dbg_times.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            double m[8] = {0}; size_t cnt = 0;
+            for (size_t b = 0; b < nb; ++b) { if (!h[8 * b + 1]) continue; ++cnt; for (int i = 0; i < 8; ++i) m[i] += (double)h[8 * b + i]; }
+            for (int i = 0; i < 8; ++i) m[i] /= std::max<size_t>(cnt, 1);
+            fprintf(stderr, "[tc] normals wave 0 phases, mean s_memtime ticks over %zu blocks: setup %.0f  block scan + list %.0f  continuation %.0f  collect %.0f  rank %.0f  centroid + covariance %.0f  eigen + orient %.0f  store %.0f\n",
+                    cnt, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+        }
+    } stamp_dump{ctx, stamp_blocks, prm.stamps != nullptr};
+#endif
     const GridView gv = view_of(ix);
     const uint32_t K1 = prm.k + 1;
     if (cfg.has_radius && cfg.radius > 0.0f) {   // radius <= 0 finds nothing (nearest_neighbor.rs:255): pure k-NN fallback
