@@ -727,10 +727,6 @@ __device__ __forceinline__ unsigned long long refine_shell(const GridView &tgt, 
 }
 
 template <int MODE>
-__device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
-                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE]);
-
-template <int MODE>
 __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src,
     IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
@@ -1151,46 +1147,43 @@ __device__ void finish_iteration(IcpState *st, float mse, uint32_t n) {
     st->prev_mse = mse;
 }
 
-// the first 256 threads of the calling block: fixed-order sum of the rows, solve, compose, bookkeeping
+constexpr int kFinalizeThreads = 512;
+// the calling block (kFinalizeThreads threads): fixed-order sum of the rows, solve, compose, bookkeeping
 template <int MODE>
 __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
                               int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE]) {
     constexpr bool P2PLANE = MODE != 0;        // GICP solves the same 6x6 system from the same 29 words (gicp.rs:258-281)
     if (do_sum) {
-        // 8 row groups x 32 columns (threads 0..255; a larger block's other threads only take part in
-        // the barriers); every group folds its rows in a fixed order with 4 independent loads in
-        // flight, then column t folds the 8 groups in order.
-        if (threadIdx.x < 256) {
+        // 16 row groups x 32 columns (512 threads): every group folds its rows in a fixed order, then column t folds the 16
+        // groups in order.  The usual case (kRefineBlocks = 256 rows) is ONE round of 16 loads in flight per thread (it was two
+        // rounds with 8 groups: the pass is the latency of its rounds)
+        constexpr int G = kFinalizeThreads / 32;
+        {
             const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             uint32_t b = grp;
             if (nblocks == 256) {
-                // the usual case (kRefineBlocks rows): 16 loads of the thread in flight at once (2 rounds),
-                // same summation order as the generic loop below
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {
-                    double v[16];
+                double v[256 / G];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) v[k] = partials[(size_t)(grp + 8 * (16 * h + k)) * TC_ICP_SUMS_STRIDE + col];
+                for (int k = 0; k < 256 / G; ++k) v[k] = partials[(size_t)(grp + G * k) * TC_ICP_SUMS_STRIDE + col];
 #pragma unroll
-                    for (int k = 0; k < 16; k += 4) { s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; s3 += v[k + 3]; }
-                }
+                for (int k = 0; k < 256 / G; k += 4) { s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; s3 += v[k + 3]; }
                 b = 256 + grp;
             }
-            for (; b + 24 < nblocks; b += 32) {
+            for (; b + 3 * G < nblocks; b += 4 * G) {
                 s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
-                s1 += partials[(size_t)(b + 8) * TC_ICP_SUMS_STRIDE + col];
-                s2 += partials[(size_t)(b + 16) * TC_ICP_SUMS_STRIDE + col];
-                s3 += partials[(size_t)(b + 24) * TC_ICP_SUMS_STRIDE + col];
+                s1 += partials[(size_t)(b + G) * TC_ICP_SUMS_STRIDE + col];
+                s2 += partials[(size_t)(b + 2 * G) * TC_ICP_SUMS_STRIDE + col];
+                s3 += partials[(size_t)(b + 3 * G) * TC_ICP_SUMS_STRIDE + col];
             }
-            for (; b < nblocks; b += 8) s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
+            for (; b < nblocks; b += G) s0 += partials[(size_t)b * TC_ICP_SUMS_STRIDE + col];
             sm[grp][col] = (s0 + s1) + (s2 + s3);
         }
         __syncthreads();
         double tot = 0.0;
         if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
 #pragma unroll
-            for (int gi = 0; gi < 8; ++gi) tot += sm[gi][threadIdx.x];
+            for (int gi = 0; gi < G; ++gi) tot += sm[gi][threadIdx.x];
             st->sums[threadIdx.x] = tot;
         }
         __syncthreads();
@@ -1262,10 +1255,10 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
+__global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
                                                            IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply) {
     if (st->done) return;
-    __shared__ double sm[8][TC_ICP_SUMS_STRIDE];
+    __shared__ double sm[kFinalizeThreads / 32][TC_ICP_SUMS_STRIDE];
 #ifdef TC_PHASE_STAMPS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     finalize_body<MODE>(partials, nblocks, st, g, do_sum, 0, sm);
@@ -1364,7 +1357,7 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
         ProfScope ps(ctx, "icp_finalize");
         const uint32_t rows = kRefineBlocks;      // the refine pass folded the main pass's rows into its own
         auto kern = mode == 0 ? icp_finalize_kernel<0> : icp_finalize_kernel<1>;
-        hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0, (do_apply && !(dbg & 32)) ? 1 : 0);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kFinalizeThreads), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0, (do_apply && !(dbg & 32)) ? 1 : 0);
     }
 }
 
