@@ -55,6 +55,18 @@ def launch_ranks(n):
     return rc
 
 
+def emit(obj):
+    """the ONE JSON line, last on stdout: native libraries (RCCL's version banner) write to C stdio, which is flushed after
+    Python's own buffer at exit -- push their output out first, then the line"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(obj), flush=True)
+
+
 def median(v):
     v = sorted(v)
     return v[len(v) // 2]
@@ -166,7 +178,7 @@ def dry_run(args):
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "dry run (launch path only)", "value": 0.0, "unit": "it/s", "n_gpus": world, "steps": args.steps,
+        emit(({"metric": "dry run (launch path only)", "value": 0.0, "unit": "it/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "dry_run": True, "max_wall_s": float(tw[0]), "pid": os.getpid(), "ppid": os.getppid()}))
     if world > 1:
         dist.destroy_process_group()
@@ -195,7 +207,9 @@ def aux_modes(args):
         n = args.points if args.points != N_POINTS else 10_000_000
         src_h, tgt_h, T = synth.registration_pair(n, seed=7, scale=(10.0, 10.0, 1.0), noise_sigma=NOISE_REL * 10.0)
         tgt, src = torch.from_numpy(tgt_h).to(dev), torch.from_numpy(src_h).to(dev)
-        comm = D.Comm.from_group(ctx)       # RCCL communicator owned by the library (id broadcast over the process group)
+        # RCCL communicator owned by the library (id broadcast over the process group); one rank: a real one-rank communicator,
+        # so that the line measures the same code path, exchange step included
+        comm = D.Comm.from_group(ctx) if world > 1 else D.Comm.rccl_single(ctx)
         nrm = D.sharded_estimate_normals(ctx, tgt, K_NORMALS, comm=comm)
         torch.cuda.synchronize()
         tn0 = time.perf_counter()
@@ -229,9 +243,16 @@ def aux_modes(args):
             tw = torch.tensor([wall, t_normals], dtype=torch.float64, device=dev)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             wall, t_normals = [float(v) for v in tw.tolist()]
+        # one more, untimed step with the library's per-kernel events on: what the iteration's kernels and its exchange step cost
+        ctx.profile_enable(1); ctx.profile_reset()
+        step()
+        torch.cuda.synchronize()
+        kern = {k: round(1e3 * ms / max(c, 1), 2) for k, (c, ms) in ctx.profile_read().items()
+                if k.startswith("icp_") or k.startswith("comm_")}
+        ctx.profile_enable(0)
         if rank == 0:
             err = float(np.linalg.norm(tc.isometry_to_matrix(r.transformation).astype(np.float64) - synth.isometry_matrix(T)))
-            print(json.dumps({"metric": "sharded point-to-plane ICP iterations/sec (one cloud, source sharded spatially, 1 ncclAllReduce/iteration in the library)",
+            emit(({"metric": "sharded point-to-plane ICP iterations/sec (one cloud, source sharded spatially, 1 ncclAllReduce/iteration in the library)",
                               "value": ICP_ITERS * args.steps / wall, "unit": "it/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
                               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -240,7 +261,8 @@ def aux_modes(args):
                                          "points": n, "parallelism": f"shard{world}",
                                          "target": "rebuilt per call" if args.plain_calls else "tc_cloud handle (indexed once)"},
                               "transform_frobenius_error_vs_truth": err, "n_correspondences": int((r.corr_target != -1).sum()),
-                              "sharded_normals_ms": 1e3 * t_normals, "sharded_normals_mpts_per_s": n / t_normals / 1e6}))
+                              "sharded_normals_ms": 1e3 * t_normals, "sharded_normals_mpts_per_s": n / t_normals / 1e6,
+                              "kernels_us_avg": kern, "allreduce_us_per_iteration": kern.get("comm_allreduce_f64")}))
         th.close()
         comm.close()
     else:
@@ -268,7 +290,7 @@ def aux_modes(args):
         run(max(args.warmup, 1) * 4)
         wall, res, m = run(nf)
         assert m.items_processed == nf and m.items_dropped == 0 and all(r.status == 0 for r in res)
-        print(json.dumps({"metric": "LiDAR frames/sec (host frames -> bounded queue -> voxel_grid_filter 0.2 m + k=16 normals + p2plane ICP <= 50 it, "
+        emit(({"metric": "LiDAR frames/sec (host frames -> bounded queue -> voxel_grid_filter 0.2 m + k=16 normals + p2plane ICP <= 50 it, "
                                     "default threshold; H2D copy overlapped with compute)",
                           "value": nf / wall, "unit": "frames/s", "n_gpus": 1, "steps": nf, "warmup": args.warmup,
                           "ms_per_step": 1e3 * wall / nf, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -511,7 +533,7 @@ def main():
                 tc.isometry_to_matrix(last.transformation).astype(np.float64) - synth.isometry_matrix(T_true)))
             del onrm
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        emit(out)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

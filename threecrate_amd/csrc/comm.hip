@@ -82,6 +82,7 @@ namespace tc {
 tc_status comm_allreduce_f64(tc_comm *c, double *d_buf, size_t count) {
     if (!c) return TC_OK;
     if (c->nccl) {        // (also with one rank: the call then is RCCL's in-place no-op, and a 1-GPU box exercises the real path)
+        ProfScope ps(c->ctx, "comm_allreduce_f64");      // tc_profile_enable(ctx, 1): what the exchange step of an iteration costs
         const int rc = rccl().AllReduce(d_buf, d_buf, count, kNcclFloat64, kNcclSum, c->nccl, c->ctx->stream);
         return rc == kNcclSuccess ? TC_OK : fail(c->ctx, TC_GPU, nccl_err(rc));
     }

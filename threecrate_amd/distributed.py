@@ -133,6 +133,18 @@ class Comm:
         return cls(ctx, h, 0, 1)
 
     @classmethod
+    def rccl_single(cls, ctx):
+        """a real one-rank RCCL communicator (tc_comm_unique_id + tc_comm_create): the code path of N ranks, exchange step
+        included, on one GPU"""
+        L = _lib.load()
+        ident = (C.c_uint8 * _lib.TC_COMM_ID_BYTES)()
+        if L.tc_comm_unique_id(ident) != _lib.TC_OK:
+            raise Unsupported("RCCL is not available to libthreecrate_hip (tc_comm_unique_id)")
+        h = C.c_void_p()
+        ctx._check(L.tc_comm_create(ctx._h, 1, 0, ident, C.byref(h)))
+        return cls(ctx, h, 0, 1)
+
+    @classmethod
     def from_group(cls, ctx, group=None, force_host=False):
         import torch
         import torch.distributed as dist
