@@ -55,15 +55,20 @@ def launch_ranks(n):
     return rc
 
 
-def emit(obj):
-    """the ONE JSON line, last on stdout: native libraries (RCCL's version banner) write to C stdio, which is flushed after
-    Python's own buffer at exit -- push their output out first, then the line"""
+def flush_native_stdio():
+    """native libraries (RCCL's version banner) write to C stdio, which is flushed after Python's own buffer at exit: push
+    their output out now"""
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
     sys.stdout.flush()
+
+
+def emit(obj):
+    """the ONE JSON line, last on stdout"""
+    flush_native_stdio()
     print(json.dumps(obj), flush=True)
 
 
@@ -250,6 +255,9 @@ def aux_modes(args):
         kern = {k: round(1e3 * ms / max(c, 1), 2) for k, (c, ms) in ctx.profile_read().items()
                 if k.startswith("icp_") or k.startswith("comm_")}
         ctx.profile_enable(0)
+        if world > 1:       # (every rank's native output before rank 0's line, see main())
+            flush_native_stdio()
+            dist.barrier()
         if rank == 0:
             err = float(np.linalg.norm(tc.isometry_to_matrix(r.transformation).astype(np.float64) - synth.isometry_matrix(T)))
             emit(({"metric": "sharded point-to-plane ICP iterations/sec (one cloud, source sharded spatially, 1 ncclAllReduce/iteration in the library)",
@@ -415,6 +423,10 @@ def main():
         tw = torch.tensor([wall, tn, ti], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, tn, ti = [float(v) for v in tw.tolist()]
+        # every rank's native output (the RCCL banner) goes out BEFORE rank 0 prints the line: the launcher merges the ranks'
+        # stdout, and a banner flushed at a rank's exit would land behind the JSON line
+        flush_native_stdio()
+        dist.barrier()
 
     if rank == 0:
         # what a plain device-to-device copy reaches on this box (report next to the 8 TB/s vendor peak)
