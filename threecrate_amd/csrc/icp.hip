@@ -1255,9 +1255,13 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
 }
 
 template <int MODE>
+// done_out: when set (the last iteration of a chunk of the host's enqueue schedule), the `done` flag is also written there --
+// a word of the context's pinned, device-visible host block, which the host reads after the chunk's event: no copy kernel on
+// the stream between two iterations (a 4-byte hipMemcpyAsync is a 4.7 us blit kernel; eight of them per 50-iteration call)
 __global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
-                                                           IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply) {
-    if (st->done) return;
+                                                           IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply,
+                                                           int32_t *__restrict__ done_out) {
+    if (st->done) { if (done_out && threadIdx.x == 0) *done_out = 1; return; }
     __shared__ double sm[kFinalizeThreads / 32][TC_ICP_SUMS_STRIDE];
 #ifdef TC_PHASE_STAMPS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -1269,6 +1273,7 @@ __global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const do
 #else
     finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm);
 #endif
+    if (done_out && threadIdx.x == 0) *done_out = st->done;      // (thread 0 wrote st->done itself)
 }
 
 // after the last iteration: not-converged epilogue (registration.rs:343-369 / :595-601)
@@ -1337,7 +1342,7 @@ static TileGeom plan_tiles(const GridGeom &g, size_t ns) {
 static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, const float4 *nrm, const float4 *src,
                              uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr_pos, uint32_t *rlist,
                              double *partials, bool do_sum, bool do_apply, bool do_reduce, const float4 *src_cov = nullptr,
-                             const float4 *vor = nullptr) {
+                             const float4 *vor = nullptr, int32_t *done_out = nullptr) {
     hipStream_t s = ctx->stream;
     const int dbg = debug_flags();
     double *refine_rows = partials + (size_t)l.nblocks * TC_ICP_SUMS_STRIDE;
@@ -1357,7 +1362,7 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
         ProfScope ps(ctx, "icp_finalize");
         const uint32_t rows = kRefineBlocks;      // the refine pass folded the main pass's rows into its own
         auto kern = mode == 0 ? icp_finalize_kernel<0> : icp_finalize_kernel<1>;
-        hipLaunchKernelGGL(kern, dim3(1), dim3(kFinalizeThreads), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0, (do_apply && !(dbg & 32)) ? 1 : 0);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kFinalizeThreads), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0, (do_apply && !(dbg & 32)) ? 1 : 0, do_apply ? done_out : nullptr);
     }
 }
 
@@ -1461,8 +1466,8 @@ tc_status icp_run_gicp(tc_context *ctx, const float *d_src, size_t ns, const flo
                         d_cov_tgt);
 }
 
-// Iterations are enqueued in chunks; the `done` flag of chunk c is polled (pinned copy + event) before chunk c + 2 is
-// enqueued, so the stream never drains while running.  Two chunks are always in flight and chunk c + 2 is only enqueued
+// Iterations are enqueued in chunks; the `done` flag of chunk c is polled (the chunk's last finalize launch writes it into the
+// pinned host block; event) before chunk c + 2 is enqueued, so the stream never drains while running.  Two chunks are always in flight and chunk c + 2 is only enqueued
 // when chunk c did not finish the job: a first chunk of 6 and a second of 2 make a registration that converges within 6
 // iterations -- scan-to-scan odometry -- pay 8 iterations of launches instead of 16 (that was 1/3 of a LiDAR frame's time).
 // The events live in the context (created once, reused by every call).
@@ -1480,6 +1485,8 @@ static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate
     size_t nchunks = 0;
     for (size_t covered = 0; covered < max_iters; ++nchunks) covered += chunk_len(nchunks);
     int32_t *flags = (int32_t *)((char *)ctx->pinned + 1024);
+    int32_t *d_flags = nullptr;                                    // the same words as the device sees them
+    TC_HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d_flags, flags, 0));
     const size_t max_flags = 200;                                  // pinned bytes 1024 .. 2048 hold them (the bbox partials follow)
     size_t it = 0;
     for (size_t c = 0; c < nchunks; ++c) {
@@ -1487,11 +1494,11 @@ static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate
             TC_HIP_TRY(ctx, hipEventSynchronize(ctx->chunk_events[(c - 2) & 3]));
             if (flags[c - 2]) break;
         }
-        for (size_t k = 0; k < chunk_len(c) && it < max_iters; ++k, ++it)
-            if (tc_status s = enqueue_iteration()) return s;
-        if (c < max_flags) {
-            flags[c] = 0;
-            TC_HIP_TRY(ctx, hipMemcpyAsync(&flags[c], &dstate->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (c < max_flags) flags[c] = 0;
+        for (size_t k = 0; k < chunk_len(c) && it < max_iters; ++k, ++it) {
+            // the chunk's last finalize launch writes the `done` flag straight into the pinned block
+            const bool last = k + 1 == chunk_len(c) || it + 1 == max_iters;
+            if (tc_status s = enqueue_iteration((last && c < max_flags) ? d_flags + c : nullptr)) return s;
         }
         while (ctx->chunk_events.size() < 4) {
             hipEvent_t ev;
@@ -1533,10 +1540,10 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     const float4 *vor = su.tix->vor_valid ? (const float4 *)su.tix->vor.p : nullptr;
     if (debug_flags() & 1024)
         if (tc_status s = ensure(ctx, ctx->dbg_times, 10 * (size_t)kMaxPartialBlocks * sizeof(unsigned long long))) return s;
-    if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
+    if (tc_status s = run_chunked(ctx, max_iters, dstate, [&](int32_t *done_out) -> tc_status {
             if (enq++ == vor_after() && !vor)
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
-            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor);
+            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor, done_out);
             return TC_OK;
         })) return s;
     if (mode == 0) {
@@ -1640,12 +1647,12 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     // bounds that already exist (a cloud handle whose normals were estimated here, or that has been a target before) serve from
     // the first iteration on; otherwise they are computed once the registration has run for a while
     const float4 *vor = su.tix->vor_valid ? (const float4 *)su.tix->vor.p : nullptr;
-    if (tc_status s = run_chunked(ctx, max_iters, dstate, [&]() -> tc_status {
+    if (tc_status s = run_chunked(ctx, max_iters, dstate, [&](int32_t *done_out) -> tc_status {
             if (enq++ == vor_after() && !vor)
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
             launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, true, false, true, nullptr, vor);
             if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;
-            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, false, true, false);
+            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, false, true, false, nullptr, nullptr, done_out);
             return TC_OK;
         })) return s;
     if (mode == 0) {        // registration.rs:343-361: the post-loop mse of a run that did not converge, summed over the ranks
