@@ -70,12 +70,14 @@ def reference_normal_of_cov(cov9):
     return q[:, m].astype(np.float64)
 
 
-def reference_solver_spread(nb_pts, trials=48, seed=0):
+def reference_solver_spread(nb_pts, trials=None, seed=0):
     """1 - |cos| spread of the reference's normal over rounding-level variants of ONE neighbourhood's covariance: the f32
     covariance in the order given (normals.rs:164-177), in permuted orders (tied neighbours have no defined order), and with
     entries moved by an ulp."""
     rng = np.random.default_rng(seed)
     P = np.asarray(nb_pts, np.float32)
+    if trials is None:          # (the bad summation orders can be a few per cent of all orders: sample small neighbourhoods densely)
+        trials = 240 if len(P) <= 12 else 96
     def cov_of(Q):
         n = np.float32(len(Q))
         cen = np.zeros(3, np.float32)
