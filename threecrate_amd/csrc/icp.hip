@@ -1466,11 +1466,6 @@ tc_status icp_run_gicp(tc_context *ctx, const float *d_src, size_t ns, const flo
                         d_cov_tgt);
 }
 
-// Iterations are enqueued in chunks; the `done` flag of chunk c is polled (the chunk's last finalize launch writes it into the
-// pinned host block; event) before chunk c + 2 is enqueued, so the stream never drains while running.  Two chunks are always in flight and chunk c + 2 is only enqueued
-// when chunk c did not finish the job: a first chunk of 6 and a second of 2 make a registration that converges within 6
-// iterations -- scan-to-scan odometry -- pay 8 iterations of launches instead of 16 (that was 1/3 of a LiDAR frame's time).
-// The events live in the context (created once, reused by every call).
 // A run that did not converge has executed exactly max_iters iterations (registration.rs:278 / :533): the device counts them
 static tc_status check_iteration_count(tc_context *ctx, const IcpState *hs, size_t max_iters) {
     if (hs->status == TC_OK && !hs->converged && hs->iterations != max_iters)
@@ -1478,6 +1473,11 @@ static tc_status check_iteration_count(tc_context *ctx, const IcpState *hs, size
     return TC_OK;
 }
 
+// Iterations are enqueued in chunks; the `done` flag of chunk c is polled (the chunk's last finalize launch writes it into the
+// pinned host block; event) before chunk c + 2 is enqueued, so the stream never drains while running.  Two chunks are always in flight and chunk c + 2 is only enqueued
+// when chunk c did not finish the job: a first chunk of 6 and a second of 2 make a registration that converges within 6
+// iterations -- scan-to-scan odometry -- pay 8 iterations of launches instead of 16 (that was 1/3 of a LiDAR frame's time).
+// The events live in the context (created once, reused by every call).
 template <typename F>
 static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate, F &&enqueue_iteration) {
     hipStream_t st = ctx->stream;
