@@ -133,3 +133,23 @@ def test_solvers_on_the_registration_systems(bench_cloud):
                        [2 * (x * y + z * wq), 1 - 2 * (x * x + z * z), 2 * (y * z - x * wq)],
                        [2 * (x * z - y * wq), 2 * (y * z + x * wq), 1 - 2 * (x * x + y * y)]])
         assert np.abs(Rq - R).max() < 4e-6
+
+
+def test_oracle_threads_follow_the_cpu_quota():
+    """oracle.effective_cpus(): the OpenMP regions of the oracle run on the CPUs this process may actually use (scheduler affinity
+    capped by the cgroup CPU quota), not on every CPU the box shows; tco_set_max_threads caps what `threads=0` means."""
+    import os
+    from oracle import oracle as O
+    n = O.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert O.num_threads() <= n
+    L = O.lib()
+    try:
+        L.tco_set_max_threads(1)
+        assert O.num_threads() == 1
+        pts = np.random.default_rng(0).random((2000, 3)).astype(np.float32)
+        one = O.estimate_normals(pts, 8)
+        L.tco_set_max_threads(n)
+        assert np.array_equal(one, O.estimate_normals(pts, 8))        # the thread count never changes a result
+    finally:
+        L.tco_set_max_threads(n)
