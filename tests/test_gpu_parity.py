@@ -452,6 +452,7 @@ def test_frame_stream_matches_per_frame_calls(ctx):
     for i in range(1, 5):
         cur = ctx.voxel_grid_filter(frames[i], 0.25)
         cur_h = tc.Cloud(ctx, cur)
+        cur_h.estimate_normals(16, out=False)        # (the stream indexes a frame once, before it registers it: same order here)
         r = cur_h.icp_point_to_plane(prev_h, None, 30, 2.0, 1e-6)
         assert res[i - 1].n_points == len(cur) and res[i - 1].n_points_in == len(frames[i])
         assert res[i - 1].iterations == r.iterations and res[i - 1].converged == r.converged
@@ -459,7 +460,6 @@ def test_frame_stream_matches_per_frame_calls(ctx):
         nrm = ctx.estimate_normals(prev, 16)
         p = ctx.icp_point_to_plane_detailed(cur, prev, nrm, None, 30, 2.0, 1e-6, correspondences=False)
         assert frob(p.transformation, r.transformation, O.isometry_to_matrix) <= 1e-5 and abs(p.iterations - r.iterations) <= 1
-        cur_h.estimate_normals(16, out=False)
         prev_h.close()
         prev, prev_h = cur, cur_h
     prev_h.close()

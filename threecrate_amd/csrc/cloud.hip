@@ -92,8 +92,9 @@ tc_status cloud_icp(tc_cloud *src, tc_cloud *tgt, bool p2plane, const float init
     if (max_iters == 0) return fail(ctx, TC_INVALID_DATA, "Max iterations must be positive");
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (tc_status s = prepare_target(tgt, p2plane)) return s;
+    // (a source handle that has been indexed -- for its own normals -- is walked in that order: no second sort of the source)
     return icp_run(ctx, p2plane, (const float *)src->xyz.p, src->n, (const float *)tgt->xyz.p, tgt->n, nullptr, 0, init, max_iters, max_dist,
-                   conv_thr, res, true, 0, &tgt->ix);
+                   conv_thr, res, true, 0, &tgt->ix, (src->indexed && src != tgt) ? &src->ix : nullptr);
 }
 
 // the target side of a registration against a handle: index (built once), cell-sorted normals

@@ -1399,11 +1399,12 @@ struct IcpSetup {
     GridView tv;
     TileGeom tg;
     DeviceIndex *tix = nullptr;      // the target's index: ctx->tgt_index, or a cloud handle's
+    const float4 *src = nullptr;     // the source records in the order the loop walks them
 };
 
 static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                            const float *d_nrm, size_t nstride, const float init[7], float max_dist, float conv_thr,
-                           IcpSetup &out, int kiss = 0, DeviceIndex *tgt_prebuilt = nullptr) {
+                           IcpSetup &out, int kiss = 0, DeviceIndex *tgt_prebuilt = nullptr, const DeviceIndex *src_presorted = nullptr) {
     // the search addresses target records by 32-bit byte offsets (16 B each)
     if (nt >= (1ull << 28)) return fail(ctx, TC_UNSUPPORTED, "ICP target clouds are limited to 2^28 - 1 points");
     out.tix = tgt_prebuilt ? tgt_prebuilt : &ctx->tgt_index;
@@ -1423,10 +1424,17 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     hs->kiss = kiss;
     hs->status = TC_OK;
     TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->state.p, hs, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
-    // order the source by the (tile-major) target cell of its initially transformed position
+    // order the source by the (tile-major) target cell of its initially transformed position -- or take the order a source
+    // HANDLE already has from its own index (cell-sorted in its own grid: spatially coherent as well; a frame of a stream is
+    // indexed once, for its normals and as the next registration's target, and not a second time as this one's source)
     out.tg = plan_tiles((*out.tix).geom, ns);
-    if (ns > 0)       // (a rank of a sharded run may own no source points)
-        if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &(*out.tix).geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
+    if (src_presorted && src_presorted->geom.n == ns) {
+        out.src = (const float4 *)src_presorted->pts.p;
+    } else {
+        if (ns > 0)       // (a rank of a sharded run may own no source points)
+            if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &(*out.tix).geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
+        out.src = (const float4 *)ctx->src_index.pts.p;
+    }
     out.l = plan_launch(ns);
     if (tc_status s = ensure(ctx, ctx->partials, ((size_t)(kMaxPartialBlocks + kRefineBlocks) * TC_ICP_SUMS_STRIDE + 2) * sizeof(double))) return s;
     // corr | corr_pos | refine counts (one per wave of a main block) | refine entries (32 bytes each, chunk / 4 per wave)
@@ -1449,13 +1457,13 @@ __global__ void __launch_bounds__(256) gather_cov_kernel(const float4 *__restric
 static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                               const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
                               float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, const float *d_cov_src,
-                              const float *d_cov_tgt, DeviceIndex *tgt_prebuilt = nullptr);
+                              const float *d_cov_tgt, DeviceIndex *tgt_prebuilt = nullptr, const DeviceIndex *src_presorted = nullptr);
 
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
-                  float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, DeviceIndex *tgt_prebuilt) {
+                  float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, DeviceIndex *tgt_prebuilt, const DeviceIndex *src_presorted) {
     return icp_run_mode(ctx, p2plane ? 1 : 0, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_iters, max_dist, conv_thr, res, corr_on_device,
-                        kiss, nullptr, nullptr, tgt_prebuilt);
+                        kiss, nullptr, nullptr, tgt_prebuilt, src_presorted);
 }
 
 // gicp.rs:157-305 once the covariances exist (d_cov_*: 8 floats per point, original order)
@@ -1513,15 +1521,16 @@ static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate
 static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                               const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
                               float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss, const float *d_cov_src,
-                              const float *d_cov_tgt, DeviceIndex *tgt_prebuilt) {
+                              const float *d_cov_tgt, DeviceIndex *tgt_prebuilt, const DeviceIndex *src_presorted) {
     const bool p2plane = mode == 1;
     IcpSetup su;
-    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, kiss, tgt_prebuilt)) return s;
+    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, kiss, tgt_prebuilt,
+                                mode == 2 ? nullptr : src_presorted)) return s;
     hipStream_t st = ctx->stream;
     IcpState *dstate = (IcpState *)ctx->state.p;
     uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns;
     double *partials = (double *)ctx->partials.p;
-    const float4 *src = (const float4 *)ctx->src_index.pts.p;
+    const float4 *src = su.src;
     const float4 *src_cov = nullptr;
     if (mode == 2) {
         if (tc_status s = ensure(ctx, (*su.tix).normals, nt * 2 * sizeof(float4))) return s;
@@ -1641,7 +1650,7 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     // corr (ns) | corr_pos (nl) | refine counts + entries -- inside the buffer icp_setup sized for the whole source
     uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns, *rlist = corr + 2 * ns;
     double *partials = (double *)ctx->partials.p;
-    const float4 *src = (const float4 *)ctx->src_index.pts.p + lo;
+    const float4 *src = su.src + lo;
     const float4 *nrm = (const float4 *)(*su.tix).normals.p;
     size_t enq = 0;
     // bounds that already exist (a cloud handle whose normals were estimated here, or that has been a target before) serve from

@@ -111,19 +111,20 @@ void worker_main(tc_frame_stream *s) {
         // the cell-sorted normals are what the NEXT frame registers against (the handle-free calls would index it twice).
         tc_cloud *cur_h = nullptr;
         if (st == TC_OK) st = tc_cloud_upload_device(ctx, s->d_frame[cur], n_cur, &cur_h);
+        if (st == TC_OK) {
+            // its normals first (the next registration needs them): the index built for them also orders this frame as the
+            // SOURCE of the registration below
+            tc_normal_config nc;
+            tc_normal_config_default(&nc);
+            nc.k_neighbors = c.k_neighbors;
+            st = tc_cloud_estimate_normals_device(cur_h, &nc, nullptr);
+        }
         if (st == TC_OK && have_prev) {
             tc_icp_result ir{};
             const float ident[7] = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
             st = tc_cloud_icp_point_to_plane(cur_h, s->prev_h, ident, c.max_iterations, c.max_correspondence_distance, c.convergence_threshold, &ir);
             std::memcpy(r.transformation, ir.transformation, sizeof(r.transformation));
             r.mse = ir.mse; r.iterations = ir.iterations; r.converged = ir.converged;
-        }
-        if (st == TC_OK) {
-            // this frame becomes the previous one: its normals are needed by the next registration
-            tc_normal_config nc;
-            tc_normal_config_default(&nc);
-            nc.k_neighbors = c.k_neighbors;
-            st = tc_cloud_estimate_normals_device(cur_h, &nc, nullptr);
         }
         if (st == TC_OK) {
             tc_cloud_destroy(s->prev_h);              // (its blocks go back to the context's pool: no allocation per frame)

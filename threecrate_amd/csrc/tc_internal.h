@@ -241,11 +241,12 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
                           size_t nt, const float *d_nrm, size_t nstride, const float init[7], size_t max_iters, float max_dist,
                           float conv_thr, tc_icp_result *res, DeviceIndex *tgt_prebuilt = nullptr);
 // tgt_prebuilt: an index of the target built by the caller (a cloud handle; with its cell-sorted normals when p2plane), else
-// the target is indexed into ctx->tgt_index
+// the target is indexed into ctx->tgt_index; src_presorted: an index of the SOURCE the caller already has (a cloud handle that
+// was indexed for its own normals): its cell-sorted records are walked as they are instead of sorting the source again
 tc_status icp_run(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                   const float *d_nrm, size_t nstride, const float init[7], size_t max_iters,
                   float max_dist, float conv_thr, tc_icp_result *res, bool corr_on_device, int kiss = 0,
-                  DeviceIndex *tgt_prebuilt = nullptr);
+                  DeviceIndex *tgt_prebuilt = nullptr, const DeviceIndex *src_presorted = nullptr);
 tc_status icp_run_gicp(tc_context *ctx, const float *d_src, size_t ns, const float *d_tgt, size_t nt, const float *d_cov_src,
                        const float *d_cov_tgt, const float init[7], size_t max_iters, float max_dist, float conv_thr,
                        tc_icp_result *res, bool corr_on_device);
