@@ -125,6 +125,7 @@ extern "C" {
     pub fn tc_read_kitti_bin(path: *const c_char, out_xyz: *mut f32, capacity_points: usize, n_points: *mut usize) -> c_int;
     // ---- stream ordering, communicator, one registration over several GPUs ----
     pub fn tc_context_wait_stream(ctx: *mut tc_context, other_hip_stream: *mut c_void) -> c_int;
+    pub fn tc_stream_wait_context(ctx: *mut tc_context, other_hip_stream: *mut c_void) -> c_int;
     pub fn tc_comm_unique_id(id: *mut u8) -> c_int;
     pub fn tc_comm_create(ctx: *mut tc_context, nranks: c_int, rank: c_int, id: *const u8, out: *mut *mut tc_comm) -> c_int;
     pub fn tc_comm_adopt(ctx: *mut tc_context, nccl_comm: *mut c_void, nranks: c_int, rank: c_int, out: *mut *mut tc_comm) -> c_int;

@@ -110,6 +110,10 @@ tc_status   tc_context_create_on_stream(int device, void *hip_stream, tc_context
  * it records an event on `other_stream` and makes the context's stream wait for it (no host wait).  Every entry point
  * returns with its outputs complete (the context's stream has been synchronised), so nothing is needed on the way out. */
 tc_status   tc_context_wait_stream(tc_context *ctx, void *other_hip_stream);
+/* The other direction: whatever is enqueued on `other_hip_stream` after this call waits for the work the context's stream holds now.
+ * For a producer that is about to overwrite or free a device buffer it has just handed to a stream-ordered entry point
+ * (tc_cloud_upload_device copies on the context's stream): no host wait. */
+tc_status   tc_stream_wait_context(tc_context *ctx, void *other_hip_stream);
 void        tc_context_destroy(tc_context *ctx);
 const char *tc_last_error_message(const tc_context *ctx);
 tc_status   tc_synchronize(tc_context *ctx);

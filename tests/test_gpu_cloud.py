@@ -102,3 +102,27 @@ def test_one_index_build_per_cloud(ctx):
     assert plain["cell_hist"][0] == 3 and plain["gather_normals"][0] == 1
     assert handle["cell_hist"][0] == 2 and handle.get("gather_normals", (0, 0))[0] == 0      # target once, source once
     t.close(); s.close()
+
+
+def test_a_handle_is_a_snapshot_of_its_tensor(ctx):
+    """tc_cloud_upload_device copies on the context's stream; torch's stream is made to wait for that copy
+    (tc_stream_wait_context), not the host: a tensor overwritten or freed right after the handle was made must not reach it."""
+    import torch
+    pts = synth.uniform_cloud(400_000, seed=5)
+    rh = tc.Cloud(ctx, pts)                         # (host upload: synchronous) -- the same handle path as below, bit for bit
+    ref = rh.estimate_normals(10)
+    rh.close()
+    for _ in range(12):        # (without the wait 2 of 20 such handles see the overwritten tensor: tools/dev/snapshot_teeth.py)
+        x = torch.from_numpy(pts).cuda()
+        h = tc.Cloud(ctx, x)
+        x.zero_()                                   # torch's next op on the buffer the copy reads
+        big = torch.empty_like(x).normal_()         # ... and allocator traffic
+        del x, big
+        got = h.estimate_normals(10)
+        h.close()
+        assert np.array_equal(got.cpu().numpy(), ref)
+        h2 = tc.Cloud(ctx, torch.from_numpy(pts).cuda() * 1.0)       # a temporary: freed as soon as the constructor returns
+        y = torch.full((400_000, 3), 7.0, device="cuda")             # likely reuses the temporary's block
+        got2 = h2.estimate_normals(10)
+        h2.close()
+        assert np.array_equal(got2.cpu().numpy(), ref) and float(y[0, 0]) == 7.0

@@ -171,6 +171,14 @@ class GpuContext:
         if self.stream is None or self.stream != cur:
             self._check(self._L.tc_context_wait_stream(self._h, C.c_void_p(cur)))
 
+    def _release(self, device):
+        """the reverse of _order: torch's current stream waits for what the context's stream holds now (a buffer torch owns
+        was handed to a stream-ordered entry point and may be overwritten or freed by torch next)"""
+        import torch
+        cur = torch.cuda.current_stream(device).cuda_stream
+        if self.stream is None or self.stream != cur:
+            self._check(self._L.tc_stream_wait_context(self._h, C.c_void_p(cur)))
+
     @staticmethod
     def _max_dist(d):
         """Option<f32> -> the ABI's encoding (< 0 = None).  A negative Some(d) must not alias None (see _reject_all):
@@ -519,7 +527,9 @@ class Cloud:
             x = points.detach().to(torch.float32).contiguous().reshape(-1, 3)
             ctx._order(x.device)
             ctx._check(self._L.tc_cloud_upload_device(ctx._h, x.data_ptr(), x.shape[0], C.byref(h)))
-            ctx._check(self._L.tc_synchronize(ctx._h))          # `x` may be a temporary: the copy must have landed
+            # `x` may be a temporary, or be overwritten by the caller's next torch op: torch's stream waits for the copy (an
+            # event, no host wait -- the constructor used to synchronise: 0.1 ms per 1 M-point pair)
+            ctx._release(x.device)
             self._torch_device = x.device
         else:
             x = _as_host(points)

@@ -215,6 +215,19 @@ tc_status tc_context_wait_stream(tc_context *ctx, void *other_hip_stream) {
     return TC_OK;
 }
 
+// the other direction: work enqueued on `other` AFTER this call waits for everything the context's stream holds now (a caller that
+// is about to overwrite or free a buffer it just handed to tc_cloud_upload_device: no host wait)
+tc_status tc_stream_wait_context(tc_context *ctx, void *other_hip_stream) {
+    if (!ctx) return TC_INVALID_DATA;
+    hipStream_t other = (hipStream_t)other_hip_stream;
+    if (other == ctx->stream) return TC_OK;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->release_event) TC_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->release_event, hipEventDisableTiming));
+    TC_HIP_TRY(ctx, hipEventRecord(ctx->release_event, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamWaitEvent(other, ctx->release_event, 0));
+    return TC_OK;
+}
+
 void tc_context_destroy(tc_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -225,6 +238,7 @@ void tc_context_destroy(tc_context *ctx) {
     for (auto &pb : ctx->pool) (void)hipFree(pb.p);
     for (auto e : ctx->chunk_events) (void)hipEventDestroy(e);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
+    if (ctx->release_event) (void)hipEventDestroy(ctx->release_event);
     for (auto &t : ctx->timers) for (auto &p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -142,6 +142,7 @@ struct tc_context {
     std::vector<tc::DevBuf> pool;
     size_t pool_bytes = 0;
     hipEvent_t order_event = nullptr;       // tc_context_wait_stream
+    hipEvent_t release_event = nullptr;     // tc_stream_wait_context
     std::vector<hipEvent_t> chunk_events;   // hipEventDisableTiming events of the ICP loop's chunk polling, reused across calls
 
     // persistent (grow-only) device buffers, reused across calls
