@@ -570,7 +570,8 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     // in three batches (9 central rows, then 2 x 8 outer rows judged against the list's last entry), parked in LDS and walked
     // flattened, lanes whose ring-2 block is not enough left to a second launch of this kernel: 648 us + 264 us for the second
     // launch (0.2 % of the points, but a lone wave's 18 k dependent instructions ARE its duration): VALU instructions -17 %, SALU
-    // +117 % (exec-mask bookkeeping of the divergent loops): the per-candidate insertion is the cost, not the number of steps.)
+    // +117 % (exec-mask bookkeeping of the divergent loops): the per-candidate insertion is the cost, not the number of steps;
+    // the list pass as ring 1 unpruned + ring-2 shell judged against the list's last entry: 590 vs 497 us.)
     scan_pruned<EXT>(gv, q, cx, cy, cz, -1, R, tau, [&](uint32_t j, const float4 &c) {
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
         bool take = v < tau;
