@@ -504,7 +504,43 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     } while (0)
     // ring R0: the whole block (no bound known yet)
     TC_NSTAMP(0);
-    scan_block(gv, cx, cy, cz, R, visit1);
+    {
+        // the block's rows centre-out (dz = 0, -1, +1, -2, +2; inside, dy likewise): the list is full after the central rows and every
+        // later row is judged (skipped, or trimmed in x in closed form) against a real limit -- 460 -> 433 us at 1 M points against
+        // the plain block scan (the same scan in z-major order: 460; ring 1 unpruned + pruned ring-2 shell: 479)
+        const float need0 = RADIUS ? fmaxf(r2, 0.0f) : 0.0f;
+        float live0 = INFINITY;
+        const int W = 2 * R + 1;
+        for (int iz = 0; iz < W; ++iz) {
+            const int mz = (iz + 1) >> 1, z = cz + ((iz & 1) ? -mz : mz);
+            if (z < 0 || z >= g.gz) continue;
+            const float gzv = axis_gap_n<EXT>(q.z, g.minz, g.h, z, g.gz - 1);
+            for (int iy = 0; iy < W; ++iy) {
+                const int my = (iy + 1) >> 1, y = cy + ((iy & 1) ? -my : my);
+                if (y < 0 || y >= g.gy) continue;
+                const float gyv = axis_gap_n<EXT>(q.y, g.miny, g.h, y, g.gy - 1);
+                const float rg = gyv * gyv + gzv * gzv;
+                if (rg > live0) continue;
+                int xa = max(cx - R, 0), xb = min(cx + R, g.gx - 1);
+                const float r = sqrtf(fmaxf(live0 - rg, 0.0f)) + 4e-3f * g.h;
+                const float fa = fminf(fmaxf((q.x - r - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
+                const float fb = fmaxf(fminf((q.x + r - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
+                xa = max(xa, (int)fa);
+                xb = min(xb, (int)fb);
+                if (xa > xb) continue;
+                const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
+                const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
+                for (uint32_t j = s; j < e; j += 4) {
+                    const float4 c0 = gv.pts[j], c1 = gv.pts[j + 1], c2 = gv.pts[j + 2], c3 = gv.pts[j + 3];
+                    visit1(j, c0);
+                    if (j + 1 < e) visit1(j + 1, c1);
+                    if (j + 2 < e) visit1(j + 2, c2);
+                    if (j + 3 < e) visit1(j + 3, c3);
+                }
+                live0 = fmaxf(d[L - 1], need0);
+            }
+        }
+    }
     { float sink_ = d[L - 1]; asm volatile("" :: "v"(sink_)); }
     TC_NSTAMP(1);
     for (;;) {
