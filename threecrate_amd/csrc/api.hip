@@ -102,9 +102,12 @@ float normals_cell_factor(size_t k, bool large) {
     // multiplier scanned on the 1 M-point uniform cloud (k = 16, whole call): 0.8 -> 0.95 ms, 0.9 -> 0.83, 0.95 -> 0.79,
     // 1.0 -> 0.75, 1.1 -> 0.75, 1.2 -> 0.79, 1.3 -> 0.84 (the in-place ring continuation made the overflow tail cheap);
     // again at 7 waves per SIMD: 0.9 -> 0.70, 0.95 -> 0.67, 1.0 -> 0.655, 1.03 -> 0.65, 1.1 -> 0.71
+    // after the centre-out pruned list pass (round 2; kernel only, TC_NORMALS_CELL_MULT): 0.8 -> 537 us, 0.9 -> 479, 1.0 -> 445,
+    // 1.03 -> 444, 1.1 -> 440, 1.2 -> 442, 1.3 -> 465: flat between 1.0 and 1.2
     // Applied to clouds of >= 2^18 points (those whose edge is also adapted to the measured occupancy); smaller clouds keep
     // 0.95: they are not adapted, and on surface-like frames (24 k-point voxel-filtered LiDAR) the larger edge costs 5 %.
-    return (float)((large ? 1.03 : 0.95) * c / 2.0);
+    static const double mult = [] { const char *e = getenv("TC_NORMALS_CELL_MULT"); return e ? atof(e) : 0.0; }();   // (tuning experiments)
+    return (float)((mult > 0.0 ? mult : (large ? 1.03 : 0.95)) * c / 2.0);
 }
 
 // points per occupied cell wanted on a SURFACE: the disc of radius ~1.9 h (ring 2) must hold the same
