@@ -507,7 +507,8 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     {
         // the block's rows centre-out (dz = 0, -1, +1, -2, +2; inside, dy likewise): the list is full after the central rows and every
         // later row is judged (skipped, or trimmed in x in closed form) against a real limit -- 460 -> 433 us at 1 M points against
-        // the plain block scan (the same scan in z-major order: 460; ring 1 unpruned + pruned ring-2 shell: 479)
+        // the plain block scan (the same scan in z-major order: 460; ring 1 unpruned + pruned ring-2 shell: 479; the next row's
+        // cell_start pair requested one row ahead, i.e. the row logic inside a per-lane loop: 516)
         const float need0 = RADIUS ? fmaxf(r2, 0.0f) : 0.0f;
         float live0 = INFINITY;
         const int W = 2 * R + 1;
