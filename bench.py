@@ -146,6 +146,20 @@ def cpu_baseline(n_points, tgt, src, gpu_normals=None):
         parity = {"normals_max_1_minus_abs_cos": float(1.0 - c.min()), "normals_frac_within_1e-4": float((c >= 1.0 - 1e-4).mean()),
                   "normals_bit_identical_frac": float((gpu_normals[:, 3:6] == nrm[:, 3:6]).all(1).mean()),
                   "positions_identical": bool(np.array_equal(gpu_normals[:, :3], nrm[:, :3]))}
+        # every normal beyond the budget, with what explains it (tests/h1.py, the checker's H1 report: an exact f32 tie at the
+        # neighbourhood boundary -- the neighbour SET is then implementation defined, nearest_neighbor.rs:202-219 -- or a
+        # degenerate smallest eigen-pair, or a covariance at which the reference's own eigen-solver is discontinuous)
+        try:
+            from tests import h1
+            try:
+                rep = h1.normals_report(tgt, K_NORMALS, gpu_normals, nrm)
+                parity["normals_offenders"] = rep["offenders"]
+                parity["normals_offenders_all_explained"] = True
+            except AssertionError as e:
+                parity["normals_offenders_all_explained"] = False
+                parity["normals_offenders_error"] = str(e)[:400]
+        except ImportError:
+            pass
     return {
         "parity": parity, "oracle_normals": nrm,
         "value": ICP_ITERS / job, "unit": "ICP it/s (whole job: normals + 50 it)", "cores": threads, "kind": "port",

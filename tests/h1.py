@@ -124,3 +124,57 @@ def reference_order_noise(run, src, seeds=(1, 2, 3)):
         m = O.isometry_to_matrix(run(np.ascontiguousarray(src[perm])).transformation).astype(np.float64)
         worst = max(worst, float(np.linalg.norm(m - base)))
     return worst
+
+
+def parting_report(grun, orun, src, tgt, nrm_t, iters, tol=1e-5):
+    """Two runs of the same point-to-plane registration (threshold 0: exactly max_iterations each) that end apart: replay both
+    with max_iterations = 1, 2, 4, ... and bisect to the FIRST iteration count k at which correspondences or transforms part.
+    Explained iff up to k - 1 the transforms agree within `tol` and, at k, every source point matched differently is matched to
+    the nearest target under ITS side's own transform after k - 1 updates (same f32 distance formula as both searches): the
+    sides' transforms differ by the rounding of their sums (sequential f32 vs fixed-tree f64), near ties flip, and from there
+    on the two runs are different -- equally valid -- trajectories.  grun / orun: max_iterations -> result."""
+    def parted(g, o):
+        same = len(g.correspondences) == len(o.correspondences) and np.array_equal(g.correspondences, o.correspondences)
+        fro = float(np.linalg.norm(O.isometry_to_matrix(g.transformation).astype(np.float64) - O.isometry_to_matrix(o.transformation).astype(np.float64)))
+        return (not same) or fro > tol, same, fro
+    runs = {}
+    def both(k):
+        if k not in runs: runs[k] = (grun(k), orun(k))
+        return runs[k]
+    ladder = [k for k in (1, 2, 4, 8, 16, 32) if k < iters] + [iters]
+    lo, hi = 0, None
+    for k in ladder:
+        if parted(*both(k))[0]: hi = k; break
+        lo = k
+    if hi is None:
+        return {"explained": True, "first_parting_iteration": None, "note": "the replays agree at every sampled iteration count"}
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if parted(*both(mid))[0]: hi = mid
+        else: lo = mid
+    g, o = both(hi)
+    _, same, fro = parted(g, o)
+    out = {"first_parting_iteration": hi, "frobenius_at_parting": fro, "same_pairs_at_parting": bool(same)}
+    if lo >= 1:
+        pg, po = both(lo)
+        Tg, To = pg.transformation, po.transformation
+        out["frobenius_one_iteration_before"] = parted(pg, po)[2]
+    else:
+        Tg = To = O.IDENTITY
+    if same:
+        # same pairs, transforms apart by more than tol after ONE more solve: the 6x6 system's conditioning times the sums' rounding
+        out["explained"] = False
+        out["note"] = "same pairs but transforms part: not a near-tie flip"
+        return out
+    gm = np.full(len(src), -1, np.int64); om = np.full(len(src), -1, np.int64)
+    gm[g.correspondences[:, 0]] = g.correspondences[:, 1]; om[o.correspondences[:, 0]] = o.correspondences[:, 1]
+    d = np.nonzero((gm != om) & (gm >= 0) & (om >= 0))[0]
+    tg_, to_ = O.isometry_apply(Tg, src[d]), O.isometry_apply(To, src[d])
+    # each side took ITS nearest: under the GPU's transform the GPU's target is not farther than the oracle's, and vice versa
+    wrong_g = int((d2_f32(tgt[gm[d]], tg_) > d2_f32(tgt[om[d]], tg_)).sum())
+    wrong_o = int((d2_f32(tgt[om[d]], to_) > d2_f32(tgt[gm[d]], to_)).sum())
+    rel = np.abs(d2_f32(tgt[gm[d]], tg_).astype(np.float64) - d2_f32(tgt[om[d]], tg_).astype(np.float64)) / np.maximum(d2_f32(tgt[gm[d]], tg_).astype(np.float64), 1e-300)
+    out.update({"pairs_differing": int(len(d)), "gpu_pairs_not_its_nearest": wrong_g, "oracle_pairs_not_its_nearest": wrong_o,
+                "max_relative_d2_gap_of_the_flipped_pairs": float(rel.max()) if len(d) else 0.0,
+                "explained": wrong_g == 0 and wrong_o == 0 and out.get("frobenius_one_iteration_before", 0.0) <= tol})
+    return out

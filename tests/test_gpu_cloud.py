@@ -126,3 +126,43 @@ def test_a_handle_is_a_snapshot_of_its_tensor(ctx):
         got2 = h2.estimate_normals(10)
         h2.close()
         assert np.array_equal(got2.cpu().numpy(), ref) and float(y[0, 0]) == 7.0
+
+
+@pytest.mark.parametrize("n,k", [(100000, 10), (100000, 96), (400000, 8)])
+def test_normals_kept_in_the_handle_survive_an_index_rebuild(ctx, n, k):
+    """estimate_normals(k, out=False) leaves the normals ONLY in the order of the normals grid; for k far from
+    16 the registration's cell edge differs by more than the sharing window (cloud.hip: shared_factor), so the first ICP against
+    the handle rebuilds the index.  The normals have to be carried over (un-sorted into input order, re-gathered) -- they used to
+    be read through a null pointer."""
+    src, tgt, T = synth.registration_pair(n, seed=11, noise_sigma=1e-4)
+    t, s = tc.Cloud(ctx, tgt), tc.Cloud(ctx, src)
+    assert t.estimate_normals(k, out=False) is None
+    a = s.icp_point_to_plane(t, None, 8, None, 0.0, correspondences=True)
+    nrm = ctx.estimate_normals(tgt, k)
+    b = ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, 8, None, 0.0)
+    assert a.iterations == 8 and _frob(a.transformation, b.transformation) <= 1e-6
+    assert np.array_equal(a.correspondences, b.correspondences)
+    # ... and they are the handle's normals in input order from then on
+    t.close(); s.close()
+
+
+def test_frame_stream_with_the_reference_default_k(ctx):
+    """The same path through tc_frame_stream_*: k_neighbors = 10 (the reference's default, normals.rs:28-37) on LiDAR-sized frames
+    puts the normals grid outside the sharing window, so every frame's handle is rebuilt when it becomes the target."""
+    ego = synth.yaw_isometry((-1.0, 0.0, 0.0), -np.deg2rad(0.5))
+    frames = [synth.kitti_shaped_cloud(seed=21)]
+    for i in range(3):
+        frames.append(synth.apply_isometry(ego, synth.kitti_shaped_cloud(seed=22 + i)))
+    fs = tc.FrameStream(ctx, max_points=130000, voxel_size=0.25, k_neighbors=10, max_iterations=30,
+                        max_correspondence_distance=2.0, convergence_threshold=1e-6)
+    for fr in frames:
+        fs.send(fr)
+    res, m = fs.finish()
+    assert len(res) == 3 and all(r.status == 0 for r in res)
+    prev = ctx.voxel_grid_filter(frames[0], 0.25)
+    for i in range(1, 4):
+        cur = ctx.voxel_grid_filter(frames[i], 0.25)
+        nrm = ctx.estimate_normals(prev, 10)
+        p = ctx.icp_point_to_plane_detailed(cur, prev, nrm, None, 30, 2.0, 1e-6, correspondences=False)
+        assert _frob(p.transformation, res[i - 1].transformation) <= 1e-5 and abs(p.iterations - res[i - 1].iterations) <= 1
+        prev = cur

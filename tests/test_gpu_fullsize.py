@@ -63,17 +63,37 @@ def test_config1_one_million_points_against_the_oracle(ctx):
     _save("h1_config1_tsmall.json", rep)
 
 
+_NOISY = {}
+
+
+def _noisy_pair():
+    """the pair bench.py times (seed 1, harness transform, sigma = 1e-4 noise on both scans) + the oracle's normals of its target"""
+    if not _NOISY:
+        src, tgt, T = synth.registration_pair(1_000_000, seed=1, transform=synth.harness_transform(), noise_sigma=1e-4)
+        _NOISY.update(src=src, tgt=tgt, T=T, ref=O.estimate_normals(tgt, 16))
+    return _NOISY["src"], _NOISY["tgt"], _NOISY["T"], _NOISY["ref"]
+
+
 def test_config1_the_timed_noisy_pair_normals_h1(ctx):
     """The cloud bench.py times (harness transform, sigma = 1e-4 noise on both scans): all 10^6 normals against the oracle,
-    every offender listed and explained, plus ONE point-to-plane iteration under the same transform: correspondences equal
-    up to exact ties."""
+    every offender listed and explained -- through the plain entry point AND through the tc_cloud handle bench.py times (the
+    handle builds ONE grid for normals and registration: another cell edge, so another visiting order of exact ties) -- plus
+    ONE point-to-plane iteration under the same transform: correspondences equal up to exact ties."""
     n, k = 1_000_000, 16
-    src, tgt, T = synth.registration_pair(n, seed=1, transform=synth.harness_transform(), noise_sigma=1e-4)
+    src, tgt, T, ref = _noisy_pair()
     dt, ds = torch.from_numpy(tgt).cuda(), torch.from_numpy(src).cuda()
     g = ctx.estimate_normals(dt, k).cpu().numpy()
-    ref = O.estimate_normals(tgt, k)
     rep = h1.normals_report(tgt, k, g, ref)
     assert rep["n_beyond"] <= 20
+    # the interface of the timed step: tc.Cloud(ctx, tgt).estimate_normals(16) (bench.py step())
+    hc = tc.Cloud(ctx, dt)
+    gh = hc.estimate_normals(k).cpu().numpy()
+    hc.close()
+    assert np.array_equal(gh[:, :3], tgt)
+    rep_h = h1.normals_report(tgt, k, gh, ref)                    # raises on an unexplained offender
+    assert rep_h["n_beyond"] <= 20
+    rep["handle_path"] = rep_h
+    rep["handle_vs_plain_normals_identical"] = int((gh[:, 3:] == g[:, 3:]).all(1).sum())
     dn = torch.from_numpy(np.ascontiguousarray(ref[:, 3:])).cuda()
     init = synth.yaw_isometry((0.049, -0.0195, 0.0102), 0.0199)           # near the answer: one iteration, same transform on both sides
     a = ctx.icp_point_to_plane_detailed(ds, dt, dn, init, 1, None, 0.0)
@@ -82,6 +102,39 @@ def test_config1_the_timed_noisy_pair_normals_h1(ctx):
     rep["icp_one_iteration_frobenius"] = _frob(a.transformation, b.transformation)
     assert rep["icp_one_iteration_frobenius"] <= 1e-5
     _save("h1_config1_noisy.json", rep)
+
+
+def test_config1_the_timed_noisy_pair_fifty_iterations_against_the_oracle(ctx):
+    """the registration bench.py times -- 50 iterations, threshold 0, FROM THE IDENTITY, on the noisy pair --
+    against the oracle's run of the same call (same normals on both sides: the oracle's).  Budget: 1e-5 Frobenius, equal
+    correspondences.  If the runs part, both are replayed (max_iterations = 1, 2, 4, ... then bisected) and the first parting
+    iteration must be decided by rounding: every differing pair is the nearest target under ITS side's own transform of the
+    iteration before (tests/h1.py parting_report)."""
+    src, tgt, T, ref = _noisy_pair()
+    dt, ds = torch.from_numpy(tgt).cuda(), torch.from_numpy(src).cuda()
+    nrm = np.ascontiguousarray(ref[:, 3:])
+    dn = torch.from_numpy(nrm).cuda()
+    grun = lambda it: ctx.icp_point_to_plane_detailed(ds, dt, dn, None, it, None, 0.0)
+    orun = lambda it: O.icp_point_to_plane_detailed(src, tgt, nrm, None, it, None, 0.0)
+    a, b = grun(50), orun(50)
+    assert a.iterations == b.iterations == 50 and not a.converged and not b.converged
+    fro = _frob(a.transformation, b.transformation)
+    ndiff = int((a.correspondences != b.correspondences).any(axis=1).sum()) if len(a.correspondences) == len(b.correspondences) else -1
+    rep = {"iterations": 50, "frobenius_vs_oracle": fro, "correspondences_differing": ndiff, "n_correspondences": [len(a.correspondences), len(b.correspondences)],
+           "mse": [a.mse, b.mse],
+           "frobenius_vs_truth": [float(np.linalg.norm(O.isometry_to_matrix(r.transformation).astype(np.float64) - synth.isometry_matrix(T))) for r in (a, b)]}
+    if fro > 1e-5 or ndiff != 0:
+        rep["parting"] = h1.parting_report(grun, orun, src, tgt, nrm, 50)
+        # what the reference's own summation order makes of this input: the same f32 terms added in f64
+        e = O.icp_point_to_plane_detailed(src, tgt, nrm, None, 50, None, 0.0, exact_sums=True)
+        rep["frobenius_vs_exact_sums"] = _frob(a.transformation, e.transformation)
+        rep["reference_accumulation_error"] = _frob(b.transformation, e.transformation)
+    _save("h1_config1_noisy_50it.json", rep)
+    if fro > 1e-5:
+        assert rep["parting"]["explained"], rep
+        assert rep["frobenius_vs_exact_sums"] <= 1e-5 or fro <= rep["reference_accumulation_error"] + 1e-5, rep
+    if ndiff != 0:
+        assert rep["parting"]["explained"], rep
 
 
 def test_config2_one_million_point_depth_map_pair(ctx):

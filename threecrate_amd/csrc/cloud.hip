@@ -39,10 +39,34 @@ float shared_factor(float want) {
     return (want > 0.8f * icp && want < 1.25f * icp) ? icp : want;
 }
 
+// normals6[orig(p)] = {position, cell-sorted normal of p}: the input-order copy of normals that so far only exist in the
+// order of the index about to be replaced
+__global__ void __launch_bounds__(256) cloud_unsort_normals_kernel(const float4 *__restrict__ pts, const float4 *__restrict__ sorted_nrm,
+                                                                  const float *__restrict__ xyz, uint32_t n, float *__restrict__ out6) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t orig = __float_as_uint(pts[p].w);
+    const float4 nr = sorted_nrm[p];
+    float *o = out6 + 6 * (size_t)orig;
+    o[0] = xyz[3 * (size_t)orig]; o[1] = xyz[3 * (size_t)orig + 1]; o[2] = xyz[3 * (size_t)orig + 2];
+    o[3] = nr.x; o[4] = nr.y; o[5] = nr.z;
+}
+
 tc_status ensure_index(tc_cloud *c, float want_factor, float target_ppo, float min_h) {
     tc_context *ctx = c->ctx;
     const float f = shared_factor(want_factor);
     if (c->indexed && c->factor > 0.8f * f && c->factor < 1.25f * f && min_h <= c->ix.geom.h) return TC_OK;
+    if (c->has_normals && !c->has_normals6 && c->indexed && c->n) {
+        // The handle's normals live only in the order of the index that is about to be rebuilt (estimated without an output
+        // array: tc_cloud_estimate_normals(c, cfg, NULL), the frame stream): keep them in input order first, or the next
+        // registration against this handle would gather from an array that was never written.
+        if (tc_status s = ensure(ctx, c->normals6, c->n * 6 * sizeof(float))) return s;
+        hipLaunchKernelGGL(cloud_unsort_normals_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float4 *)c->ix.pts.p, (const float4 *)c->ix.normals.p, (const float *)c->xyz.p, (uint32_t)c->n,
+                           (float *)c->normals6.p);
+        TC_HIP_TRY(ctx, hipGetLastError());
+        c->has_normals6 = true;
+    }
     c->has_normals = false;
     if (tc_status s = build_index(ctx, c->ix, (const float *)c->xyz.p, c->n, f, nullptr, nullptr, nullptr, min_h, target_ppo)) return s;
     c->indexed = true;
@@ -102,6 +126,7 @@ tc_status prepare_target(tc_cloud *tgt, bool p2plane) {
     tc_context *ctx = tgt->ctx;
     if (tc_status s = ensure_index(tgt, icp_cell_factor(), 2.5f, 0.0f)) return s;
     if (p2plane && !tgt->has_normals) {          // the index was rebuilt since the normals were made: re-sort them
+        if (!tgt->has_normals6) return fail(ctx, TC_INVALID_DATA, "the target handle has no normals in input order to re-sort after its index was rebuilt");
         if (tc_status s = gather_normals(ctx, tgt->ix, (const float *)tgt->normals6.p + 3, 6)) return s;
         tgt->has_normals = true;
     }
