@@ -49,9 +49,26 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll: the first rank that exits non-zero ends the job (its peers may be waiting for it in a collective: they are
+    # terminated, not waited for); fresh children only, the parent never touches a GPU and never re-execs
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(r))
+        if live and rc == 0:
+            time.sleep(0.05)
+    for p in live:
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
     return rc
 
 
@@ -186,6 +203,8 @@ def dry_run(args):
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("TC_BENCH_DRY_FAIL_RANK") == str(rank):      # tests/test_bench_launch.py: a rank that dies before its peers' collective
+        sys.exit(3)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dist.barrier()

@@ -45,3 +45,18 @@ def test_parent_never_imports_torch_before_spawning():
     body = src[src.index("def main():"):]
     spawn = body.index("launch_ranks(args.gpus)")
     assert "import torch" not in body[:spawn]
+
+
+def test_a_dead_rank_ends_the_job():
+    """launch_ranks waited on every child in turn -- one dead rank left its peers (blocked in a collective) and the
+    launcher hanging.  The launcher polls: the first non-zero exit terminates the rest and is the job's exit code."""
+    import time
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["TC_BENCH_DRY_FAIL_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=e, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3 and time.time() - t0 < 60
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]       # no JSON line from a failed job

@@ -110,6 +110,12 @@ def _free_port():
     return p
 
 
+def _big_cell_source(ds):
+    rng = np.random.default_rng(5)
+    clu = (np.array([0.5, 0.5, 0.5]) + rng.normal(0.0, 1e-5, (80000, 3))).astype(np.float32)
+    return torch.cat([torch.from_numpy(clu).cuda(), ds[:20000]])
+
+
 def _rank_main(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -134,6 +140,10 @@ def _rank_main(rank, world, port, q):
         mine = ds[:0] if rank == 0 else ds[(rank - 1) * per: rank * per]
         a = D.sharded_icp_point_to_plane(ctx, mine, dt, nrm, None, 8, None, 0.0, comm=comm, source_is_local_slice=True)
         out["local_empty"] = (a.transformation, a.mse, a.iterations)
+        # a source cell far beyond the deterministic re-rank's reach (80 k points inside one target cell): the ranks' shard
+        # boundaries fall INSIDE it, so they must agree on the order of its records (build_index(strict_order))
+        a = D.sharded_icp_point_to_plane(ctx, _big_cell_source(ds), dt, nrm, None, 4, None, 0.0, comm=comm, correspondences=True)
+        out["bigcell"] = (a.transformation, a.mse, a.iterations, a.converged, a.correspondences)
         comm.close()
         ctx.close()
     finally:
@@ -155,7 +165,7 @@ def test_ranks_sharing_the_gpu_drive_the_c_entry_points(ctx, world):
         p.join(timeout=120)
         assert p.exitcode == 0
     r0 = outs[0]
-    assert set(r0) == {"normals", "p2plane", "p2plane_conv", "p2p", "local_empty"}, "rank 0 failed: " + str(list(r0))
+    assert set(r0) == {"normals", "p2plane", "p2plane_conv", "p2p", "local_empty", "bigcell"}, "rank 0 failed: " + str(list(r0))
     # every rank ends with bit-identical state
     for r in range(1, world):
         for key in r0:
@@ -179,6 +189,9 @@ def test_ranks_sharing_the_gpu_drive_the_c_entry_points(ctx, world):
     T, mse, it, conv, corr = r0["p2p"]
     assert (it, conv) == (6, False) and _frob(T, b.transformation) <= 1e-5 and abs(mse - b.mse) <= 1e-5 * b.mse
     assert np.array_equal(corr, b.correspondences)
+    b = ctx.icp_point_to_plane_detailed(_big_cell_source(ds), dt, nrm, None, 4, None, 0.0)
+    T, mse, it, conv, corr = r0["bigcell"]
+    assert it == 4 and len(corr) == 100000 and np.array_equal(corr, b.correspondences) and _frob(T, b.transformation) <= 1e-5
     b = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, 8, None, 0.0)
     T, mse, it = r0["local_empty"]
     # ranks 1.. own everything between them: with two ranks that is ONE shard = the fused loop's sums bit for bit

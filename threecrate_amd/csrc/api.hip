@@ -134,7 +134,8 @@ tc_status normals_on_index(tc_context *ctx, DeviceIndex &ix, bool build, float c
         // radius mode: ring 2 must cover the radius ball, so the cell edge is at least radius / 2
         const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
         const float f = cell_factor_override > 0.0f ? cell_factor_override : normals_cell_factor(cfg->k_neighbors, n >= kAdaptMinPoints);
-        if (tc_status s = build_index(ctx, ix, d_xyz, n, f, nullptr, nullptr, nullptr, min_h, normals_target_ppo(cfg->k_neighbors))) return s;
+        // a SLICE of the cell-sorted order is some rank's share of it: every rank has to build the same order (strict_order)
+        if (tc_status s = build_index(ctx, ix, d_xyz, n, f, nullptr, nullptr, nullptr, min_h, normals_target_ppo(cfg->k_neighbors), slice_out)) return s;
     }
     float vp[3];
     if (cfg->has_viewpoint) {

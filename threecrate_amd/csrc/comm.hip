@@ -112,6 +112,24 @@ tc_status comm_allgather(tc_comm *c, void *d_buf, size_t bytes_per_rank) {
     return host_collective(c, TC_COLL_ALLGATHER_U8, d_buf, bytes_per_rank, bytes_per_rank * (size_t)c->nranks);
 }
 
+tc_status comm_agree(tc_comm *c, tc_status local) {
+    if (!c || c->nranks <= 1) return local;
+    tc_context *ctx = c->ctx;
+    if (!c->agree_word && hipMalloc(&c->agree_word, 64) != hipSuccess) c->agree_word = nullptr;
+    // (no device word: this rank cannot take part -- it still has to tell: the peers' all-reduce would wait for it.  Nothing
+    // sane is left to do but to fail loudly; a 64-byte allocation failing means the device is gone.)
+    if (!c->agree_word) return fail(ctx, TC_GPU, "communicator: cannot allocate the agreement word");
+    uint32_t *h = (uint32_t *)((char *)ctx->pinned + 2048 + 8192 + 128);
+    *h = local == TC_OK ? 0u : 1u;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(c->agree_word, h, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (tc_status s = comm_allreduce_u32(c, (uint32_t *)c->agree_word, 1)) return s;
+    TC_HIP_TRY(ctx, hipMemcpyAsync(h, c->agree_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (local != TC_OK) return local;
+    if (*h != 0u) return fail(ctx, TC_GPU, "sharded call: the set-up failed on " + std::to_string(*h) + " peer rank(s); no rank entered the loop");
+    return TC_OK;
+}
+
 }  // namespace tc
 
 extern "C" {
@@ -182,6 +200,7 @@ void tc_comm_destroy(tc_comm *c) {
         (void)hipStreamSynchronize(c->ctx->stream);
         (void)rccl().CommDestroy(c->nccl);
     }
+    if (c->agree_word) (void)hipFree(c->agree_word);
     delete c;
 }
 

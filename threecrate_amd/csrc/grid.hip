@@ -11,6 +11,7 @@
 // HBM traffic per point: 12 B read (AoS xyz) + 4 B cell id + 16 B sorted record + 4 B slot
 // (SURVEY 8d "index build" figure: 32 B/pt).
 #include "tc_internal.h"
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -133,7 +134,16 @@ __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict_
     cell_of[i] = c;
     // the returned count is this point's arrival rank inside its cell: the scatter pass then needs
     // no second round of atomics
-    arrival[i] = atomicAdd(&hist[c], 1u);
+    const uint32_t a = atomicAdd(&hist[c], 1u);
+    arrival[i] = a;
+    // a cell too populous for the quadratic re-rank (rank_gather_kernel): the word behind the histogram says so
+    // (build_index(strict_order): callers whose RANKS must agree on the order re-sort then)
+    if (a == kRankQuadraticMax) hist[nkeys + 1] = 1u;
+}
+
+__global__ void __launch_bounds__(256) iota_kernel(uint32_t *__restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
 }
 
 constexpr int kScanItems = 8;
@@ -245,7 +255,7 @@ __global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restric
                                                          const uint32_t *__restrict__ cell_of,
                                                          const uint32_t *__restrict__ cell_start,
                                                          const uint32_t *__restrict__ slot,
-                                                         float4 *__restrict__ pts) {
+                                                         float4 *__restrict__ pts, int slot_is_ordered) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     uint32_t i = slot[p];
@@ -256,7 +266,9 @@ __global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restric
     // edge) still rank in ~0.3 ms; beyond that the atomic arrival order is kept -- the only place where two runs may differ
     // (DESIGN.md section 3), on inputs whose every neighbour search is quadratic anyway.
     uint32_t rank;
-    if (e - s <= 65536u) {
+    if (slot_is_ordered) {            // `slot` comes from a stable sort by cell: already in ascending original index
+        rank = p - s;
+    } else if (e - s <= kRankQuadraticMax) {
         rank = 0;
         for (uint32_t j = s; j < e; ++j) rank += (slot[j] < i) ? 1u : 0u;
     } else {
@@ -403,7 +415,7 @@ tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3],
 
 tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n, float cell_factor,
                       const GridGeom *reuse_geom, const IcpState *d_state_transform, const TileGeom *tile_major,
-                      float min_cell_edge, float target_ppo) {
+                      float min_cell_edge, float target_ppo, bool strict_order) {
     if (n == 0 || n >= 0xFFFFFFF0ull) return fail(ctx, TC_INVALID_DATA, "build_index: bad point count");
     ix.vor_valid = false;
     hipStream_t st = ctx->stream;
@@ -438,6 +450,8 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     // (~15 us of launch bubble), which a 24 k-point LiDAR frame pipeline feels (-14 % frames/s) and a
     // 1 M-point cloud does not (-0.5 %), while the gain scales with the cloud (TUM-shaped 1 M: 2-3x).
     const bool adapt = target_ppo > 0.0f && !reuse_geom && !tile_major && n >= kAdaptMinPoints && !(dbg & 512);
+    uint32_t nkeys_final = 0;
+    const uint32_t *cs_final = nullptr;
     for (int attempt = 0;; ++attempt) {
         const GridGeom g = ix.geom;
         TileGeom tg{};
@@ -455,11 +469,12 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         if (tc_status s = ensure(ctx, ix.slot, n * sizeof(uint32_t))) return s;
         if (tc_status s = ensure(ctx, ix.arrival, n * sizeof(uint32_t))) return s;
         // nkeys cells + the bucket of the non-finite points behind them
-        if (tc_status s = ensure(ctx, ix.fill, ((size_t)nkeys + 1) * sizeof(uint32_t))) return s;
+        if (tc_status s = ensure(ctx, ix.fill, ((size_t)nkeys + 2) * sizeof(uint32_t))) return s;       // (+ the oversized-cell flag)
         if (tc_status s = ensure(ctx, ix.cell_start, (kCellStartFront + (size_t)nkeys + 2 + kCellStartPad) * sizeof(uint32_t))) return s;
         uint32_t *const cs = (uint32_t *)ix.cell_start.p + kCellStartFront;       // zeros in front (the ICP window of cell 0 starts at -1)
+        nkeys_final = nkeys; cs_final = cs;
 
-        TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st));
+        TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, ((size_t)nkeys + 2) * sizeof(uint32_t), st));
         // records past the end: huge finite coordinates -> d2 = +inf, never a match (kernels may read, never select them)
         {
             ProfScope ps(ctx, "cell_hist");
@@ -485,7 +500,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         {
             ProfScope ps(ctx, "cell_rank_gather");
             hipLaunchKernelGGL(rank_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, nkeys, (const uint32_t *)ix.cell_of.p,
-                               (const uint32_t *)cs, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p);
+                               (const uint32_t *)cs, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p, 0);
         }
         TC_HIP_TRY(ctx, hipGetLastError());
         if (!check) break;
@@ -502,6 +517,32 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         set_cell_edge(ng, h, n, 32.0);      // measured on a 1 M-point depth-map surface: 16 -> 32 cells per point -8 % normals, -10 % ICP; 64: no further gain
         if (!(ng.h < 0.95f * g.h)) break;                     // budget or minimum edge reached
         ix.geom = ng;
+    }
+    if (strict_order) {
+        // Ranks that split the cell-sorted order between them (TC_SHARD_SPATIAL, sharded normals) need the SAME order on every
+        // rank, also inside a cell of more than kRankQuadraticMax points, where rank_gather_kernel keeps the atomic arrival order:
+        // one host round trip for the flag, and -- only then -- a stable LSD radix sort of (cell, original index) replaces the
+        // order (rocPRIM, the library primitive the voxel filter's sort path already uses), records gathered again.
+        uint32_t *h_big = (uint32_t *)((char *)ctx->pinned + 2048 + 8192 + 64);
+        TC_HIP_TRY(ctx, hipMemcpyAsync(h_big, (const uint32_t *)ix.fill.p + nkeys_final + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (*h_big) {
+            if (tc_status s = ensure(ctx, ctx->overflow, n * sizeof(uint32_t))) return s;
+            uint32_t *iota = (uint32_t *)ix.arrival.p, *keys_out = (uint32_t *)ctx->overflow.p;
+            hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, st, iota, n32);
+            unsigned bits = 1;
+            while (bits < 32 && (1ull << bits) <= (unsigned long long)nkeys_final) ++bits;
+            size_t temp_bytes = 0;
+            TC_HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, (const uint32_t *)ix.cell_of.p, keys_out, (const uint32_t *)iota,
+                                                      (uint32_t *)ix.slot.p, n, 0u, bits, st));
+            if (tc_status s = ensure(ctx, ix.blocksum, temp_bytes)) return s;
+            TC_HIP_TRY(ctx, rocprim::radix_sort_pairs(ix.blocksum.p, temp_bytes, (const uint32_t *)ix.cell_of.p, keys_out, (const uint32_t *)iota,
+                                                      (uint32_t *)ix.slot.p, n, 0u, bits, st));
+            ProfScope ps(ctx, "cell_rank_gather_strict");
+            hipLaunchKernelGGL(rank_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, nkeys_final, (const uint32_t *)ix.cell_of.p,
+                               (const uint32_t *)cs_final, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p, 1);
+            TC_HIP_TRY(ctx, hipGetLastError());
+        }
     }
     return TC_OK;
 }

@@ -1409,7 +1409,8 @@ struct IcpSetup {
 
 static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                            const float *d_nrm, size_t nstride, const float init[7], float max_dist, float conv_thr,
-                           IcpSetup &out, int kiss = 0, DeviceIndex *tgt_prebuilt = nullptr, const DeviceIndex *src_presorted = nullptr) {
+                           IcpSetup &out, int kiss = 0, DeviceIndex *tgt_prebuilt = nullptr, const DeviceIndex *src_presorted = nullptr,
+                           bool strict_source_order = false) {
     // the search addresses target records by 32-bit byte offsets (16 B each)
     if (nt >= (1ull << 28) || ns >= (1ull << 28)) return fail(ctx, TC_UNSUPPORTED, "ICP clouds are limited to 2^28 - 1 points");
     out.tix = tgt_prebuilt ? tgt_prebuilt : &ctx->tgt_index;
@@ -1437,7 +1438,8 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
         out.src = (const float4 *)src_presorted->pts.p;
     } else {
         if (ns > 0)       // (a rank of a sharded run may own no source points)
-            if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &(*out.tix).geom, (const IcpState *)ctx->state.p, &out.tg)) return s;
+            if (tc_status s = build_index(ctx, ctx->src_index, d_src, ns, 0.0f, &(*out.tix).geom, (const IcpState *)ctx->state.p, &out.tg, 0.0f, 0.0f,
+                                          strict_source_order)) return s;
         out.src = (const float4 *)ctx->src_index.pts.p;
     }
     out.l = plan_launch(ns);
@@ -1644,7 +1646,15 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     const int mode = p2plane ? 1 : 0;
     const int W = comm ? comm->nranks : 1, rank = comm ? comm->rank : 0;
     IcpSetup su;
-    if (tc_status s = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, 0, tgt_prebuilt)) return s;
+    // (TC_SHARD_SPATIAL over several ranks: every rank sorts the replicated source and takes a range of positions -- the ranks must
+    // agree on the order, also inside a cell too populous for the deterministic re-rank: build_index(strict_order))
+    tc_status setup_rc = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, 0, tgt_prebuilt, nullptr,
+                                   shard_mode == TC_SHARD_SPATIAL && W > 1);
+    // Everything that can fail on ONE rank happens before the first collective, and the ranks agree on it: the inscribed-ball
+    // bounds' buffer (the loop computes them at iteration 6) is allocated here, so that no fallible host path sits between two
+    // all-reduces -- a rank returning early from inside the loop would leave its peers waiting in ncclAllReduce for ever.
+    if (setup_rc == TC_OK && !su.tix->vor_valid) setup_rc = ensure(ctx, su.tix->vor, (size_t)su.tix->geom.n * sizeof(float4));
+    if (tc_status s = comm_agree(comm, setup_rc)) return s;
     hipStream_t st = ctx->stream;
     IcpState *dstate = (IcpState *)ctx->state.p;
     // this rank's range of the tile-major sorted source: a spatially compact shard (TC_SHARD_SPATIAL), or everything it was given

@@ -70,6 +70,7 @@ constexpr int kIcpBlock = 256;
 // span (4-wide steps) and 16-byte windows of cell_start without clamping
 constexpr size_t kPtsPad = 4, kCellStartPad = 4;
 constexpr size_t kCellStartFront = 4;            // zero entries in front of the prefix sums (16-byte aligned start)
+constexpr uint32_t kRankQuadraticMax = 65536u;  // cells up to this population are re-ranked by original index in O(m^2) (rank_gather_kernel)
 constexpr int kMaxPartialBlocks = 1024;         // plan_launch: one round of 4 blocks per CU
 // clouds from this size on get the occupancy-adapted cell edge (one host round trip + possibly a rebuild)
 constexpr uint32_t kAdaptMinPoints = 1u << 18;   // 2^17: a 230 k-point depth frame gets slower (normals 0.67 -> 0.71 ms, 10 ICP iterations 1.5 -> 2.8 ms)
@@ -169,6 +170,7 @@ struct tc_comm {
     bool own_nccl = false;
     tc_host_collective_fn host_fn = nullptr;
     void *host_user = nullptr;
+    void *agree_word = nullptr;         // one device u32: comm_agree
 };
 
 namespace tc {
@@ -196,7 +198,7 @@ struct ProfScope {
 // grid.hip
 tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n,
                       float cell_factor, const GridGeom *reuse_geom, const IcpState *d_state_transform,
-                      const TileGeom *tile_major = nullptr, float min_cell_edge = 0.0f, float target_ppo = 0.0f);
+                      const TileGeom *tile_major = nullptr, float min_cell_edge = 0.0f, float target_ppo = 0.0f, bool strict_order = false);
 TileGeom make_tiles(const GridGeom &g, int tx, int ty, int tz);
 tc_status gather_normals(tc_context *ctx, DeviceIndex &ix, const float *d_normals, size_t stride);
 GridView view_of(const DeviceIndex &ix);
@@ -236,6 +238,10 @@ int debug_flags();
 tc_status comm_allreduce_f64(tc_comm *comm, double *d_buf, size_t count);
 tc_status comm_allreduce_u32(tc_comm *comm, uint32_t *d_buf, size_t count);
 tc_status comm_allgather(tc_comm *comm, void *d_buf, size_t bytes_per_rank);     // in place: rank r's part at r * bytes_per_rank
+// Every rank calls it with the status of its own fallible set-up (allocations, index builds) BEFORE the first collective of a
+// loop: one all-reduce of a flag; a rank that failed returns its own status, every other rank TC_GPU "a peer failed" -- nobody is
+// left waiting in a collective its peer never enters.  One rank: returns `local`.
+tc_status comm_agree(tc_comm *comm, tc_status local);
 
 // icp.hip
 tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p2plane, const float *d_src, size_t ns, const float *d_tgt,
