@@ -26,6 +26,9 @@ def test_gpus_2_starts_two_ranks():
     out = _run(["--gpus", "2"])
     assert out["n_gpus"] == 2 and out["dry_run"] is True
     assert out["pid"] != out["ppid"]          # the rank is a child of the launcher, not the launcher itself
+    # the line carries what every rank did and what the process group connected (the GPU modes print the same fields)
+    assert out["collective"]["world_size_seen_by_process_group"] == 2 and [r["rank"] for r in out["ranks"]] == [0, 1]
+    assert len({r["pid"] for r in out["ranks"]}) == 2
 
 
 def test_gpus_1_runs_in_process():
