@@ -625,10 +625,17 @@ def main():
                                           "steps after the timed region; `value` is the tc_cloud-handle interface unless --plain-calls"}
             # host path: pageable numpy in, numpy out (what a drop-in caller holding Vec<Point3f> sees; PCIe inclusive)
             th_n, nrm_host = timed(lambda: ctx.estimate_normals(tgt_h, K_NORMALS), 1, 3)
-            th_i, _ = timed(lambda: ctx.icp_point_to_plane_detailed(src_h, tgt_h, nrm_host, None, ICP_ITERS, None, 0.0, correspondences=True), 1, 3)
+            # what the C ABI hands back is the dense per-source target index (tc_icp_result::corr_target, caller-allocated host
+            # memory); turning it into Vec<(usize, usize)> is the binding's loop -- the Python mirror's numpy version of that
+            # loop (astype / nonzero / stack: 2-3 ms per million points) is reported next to it, not inside it
+            th_i, _ = timed(lambda: ctx.icp_point_to_plane_detailed(src_h, tgt_h, nrm_host, None, ICP_ITERS, None, 0.0, correspondences="device"), 1, 3)
+            th_p, _ = timed(lambda: ctx.icp_point_to_plane_detailed(src_h, tgt_h, nrm_host, None, ICP_ITERS, None, 0.0, correspondences=True), 0, 3)
             out["host_path"] = {"normals_ms": 1e3 * th_n, "icp_50it_ms": 1e3 * th_i, "it_per_s_whole_job": ICP_ITERS / (th_n + th_i),
-                                "note": "pageable numpy buffers in and out through tc_estimate_normals / tc_icp_point_to_plane_detailed, "
-                                        "correspondence pairs materialised; median of 3; never part of `value`"}
+                                "icp_50it_ms_with_pairs_materialised_in_python": 1e3 * th_p,
+                                "bytes_h2d": int(12 * n + 12 * n + 12 * n + 24 * n), "bytes_d2h": int(24 * n + 4 * n),
+                                "note": "pageable numpy buffers in and out through tc_estimate_normals / tc_icp_point_to_plane_detailed "
+                                        "(target first on the context's stream, source + normals on a copy stream under the target's index "
+                                        "build), dense correspondence array returned; median of 3; never part of `value`"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(n, tgt_h, src_h, nrm_last.cpu().numpy())
             out["parity"] = cb.pop("parity")

@@ -95,6 +95,26 @@ static void free_buf(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.
 
 // NormalEstimationConfig -> cell edge factor: ring R0 = 2 must cover the (k+1)-NN sphere for all
 // but ~1e-3 of the queries of a locally uniform cloud (Poisson tail), the rest take the overflow pass.
+tc_status upload_async(tc_context *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx->copy_stream) TC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->upload_event) TC_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->upload_event, hipEventDisableTiming));
+    // the destination may still be read by work the context's stream holds from an earlier call: entry points return
+    // synchronised, so nothing is in flight here
+    TC_HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    return TC_OK;
+}
+tc_status uploads_issued(tc_context *ctx) {
+    TC_HIP_TRY(ctx, hipEventRecord(ctx->upload_event, ctx->copy_stream));
+    ctx->upload_pending = true;
+    return TC_OK;
+}
+tc_status wait_uploads(tc_context *ctx) {
+    if (!ctx->upload_pending) return TC_OK;
+    ctx->upload_pending = false;
+    TC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->upload_event, 0));
+    return TC_OK;
+}
+
 float normals_cell_factor(size_t k, bool large) {
     const double K1 = (double)k + 1.0;
     const double lam = K1 + 3.1 * std::sqrt(K1) + 2.0;
@@ -236,6 +256,8 @@ void tc_context_destroy(tc_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->upload_event) (void)hipEventDestroy(ctx->upload_event);
     free_index(ctx->tgt_index); free_index(ctx->src_index); free_index(ctx->vox_index);
     free_buf(ctx->in_a); free_buf(ctx->in_b); free_buf(ctx->in_c); free_buf(ctx->out_a); free_buf(ctx->bbox);
     free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->gicp_src_cov); free_buf(ctx->overflow); free_buf(ctx->dbg_times);
@@ -348,10 +370,15 @@ tc_status tc_icp_detailed(tc_context *ctx, const float *source, size_t n_source,
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (tc_status s = ensure(ctx, ctx->in_a, n_source * 3 * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, ctx->in_b, n_target * 3 * sizeof(float))) return s;
-    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, source, n_source * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // the target first, on the context's stream: its index build starts as soon as it has landed; the source follows on the copy
+    // stream, under the build (icp_setup waits for it before it orders the source)
     TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_b.p, target, n_target * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    return icp_run(ctx, false, (const float *)ctx->in_a.p, n_source, (const float *)ctx->in_b.p, n_target, nullptr, 0, init,
-                   max_iters, max_dist, conv_thr, result, false);
+    if (tc_status s = upload_async(ctx, ctx->in_a.p, source, n_source * 3 * sizeof(float))) return s;
+    if (tc_status s = uploads_issued(ctx)) return s;
+    const tc_status rc = icp_run(ctx, false, (const float *)ctx->in_a.p, n_source, (const float *)ctx->in_b.p, n_target, nullptr, 0, init,
+                                 max_iters, max_dist, conv_thr, result, false);
+    if (ctx->upload_pending) { ctx->upload_pending = false; (void)hipStreamSynchronize(ctx->copy_stream); }     // (an early error return)
+    return rc;
 }
 
 tc_status tc_icp_point_to_point(tc_context *ctx, const float *source, size_t n_source, const float *target, size_t n_target,
@@ -404,11 +431,16 @@ tc_status tc_icp_point_to_plane_detailed(tc_context *ctx, const float *source, s
     if (tc_status s = ensure(ctx, ctx->in_a, n_source * 3 * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, ctx->in_b, n_target * 3 * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, ctx->in_c, nbytes)) return s;
-    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, source, n_source * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // the target first, on the context's stream: its index build starts as soon as it has landed; normals and source follow on
+    // the copy stream, under the build (icp_setup waits for them before it gathers the normals)
     TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_b.p, target, n_target * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_c.p, normals, nbytes, hipMemcpyHostToDevice, ctx->stream));
-    return icp_run(ctx, true, (const float *)ctx->in_a.p, n_source, (const float *)ctx->in_b.p, n_target,
-                   (const float *)ctx->in_c.p, stride, init, max_iters, max_dist, conv_thr, result, false);
+    if (tc_status s = upload_async(ctx, ctx->in_c.p, normals, nbytes)) return s;
+    if (tc_status s = upload_async(ctx, ctx->in_a.p, source, n_source * 3 * sizeof(float))) return s;
+    if (tc_status s = uploads_issued(ctx)) return s;
+    const tc_status rc = icp_run(ctx, true, (const float *)ctx->in_a.p, n_source, (const float *)ctx->in_b.p, n_target,
+                                 (const float *)ctx->in_c.p, stride, init, max_iters, max_dist, conv_thr, result, false);
+    if (ctx->upload_pending) { ctx->upload_pending = false; (void)hipStreamSynchronize(ctx->copy_stream); }     // (an early error return)
+    return rc;
 }
 
 // ---- one registration / one cloud over the ranks of a communicator ----------------------------------

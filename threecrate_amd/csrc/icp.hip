@@ -1416,9 +1416,11 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     out.tix = tgt_prebuilt ? tgt_prebuilt : &ctx->tgt_index;
     if (!tgt_prebuilt) {
         if (tc_status s = build_index(ctx, ctx->tgt_index, d_tgt, nt, icp_cell_factor(), nullptr, nullptr, nullptr, 0.0f, 2.5f)) return s;
+        if (tc_status s = wait_uploads(ctx)) return s;          // a host entry point's source / normals, uploaded under the build
         if (p2plane)
             if (tc_status s = gather_normals(ctx, ctx->tgt_index, d_nrm, nstride)) return s;
     }
+    if (tc_status s = wait_uploads(ctx)) return s;
     if (tc_status s = ensure(ctx, ctx->state, sizeof(IcpState))) return s;
     IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
     std::memset(hs, 0, sizeof(IcpState));

@@ -145,6 +145,11 @@ struct tc_context {
     hipEvent_t order_event = nullptr;       // tc_context_wait_stream
     hipEvent_t release_event = nullptr;     // tc_stream_wait_context
     std::vector<hipEvent_t> chunk_events;   // hipEventDisableTiming events of the ICP loop's chunk polling, reused across calls
+    // host entry points: the caller's source (+ normals) are uploaded on a second stream while the context's stream indexes the
+    // target; upload_pending = the context's stream has to wait for upload_event before it touches them (icp_setup does)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t upload_event = nullptr;
+    bool upload_pending = false;
 
     // persistent (grow-only) device buffers, reused across calls
     tc::DeviceIndex tgt_index;      // target / normals cloud
@@ -185,6 +190,11 @@ tc_status fail(tc_context *ctx, tc_status st, const std::string &msg);
     } while (0)
 
 tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes);
+// host -> device on the context's copy stream (created on first use), followed by tc::uploads_issued(): the context's stream
+// waits for everything issued so far the next time tc::wait_uploads is called
+tc_status upload_async(tc_context *ctx, void *d_dst, const void *h_src, size_t bytes);
+tc_status uploads_issued(tc_context *ctx);
+tc_status wait_uploads(tc_context *ctx);
 // hand a block back to the context's pool (the caller has made sure no work in flight uses it)
 void recycle(tc_context *ctx, DevBuf &b);
 
