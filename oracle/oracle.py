@@ -237,11 +237,16 @@ def _icp_common(fn, src, tgt, extra_pre, init, max_iters, tail, threads):
     return IcpResult(r, len(s), cs, ct)
 
 
-def icp_detailed(src, tgt, init, max_iters, max_correspondence_distance=None, convergence_threshold=1e-6, threads=0):
-    """registration.rs:258-370"""
+def icp_detailed(src, tgt, init, max_iters, max_correspondence_distance=None, convergence_threshold=1e-6, threads=0, exact_sums=False):
+    """registration.rs:258-370.  exact_sums (diagnostic): the Kabsch sums' f32 terms are added in f64 instead of the reference's
+    sequential f32 (tc_oracle.c, tco_set_exact_sums)."""
     md = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance)
-    return _icp_common(lib().tco_icp_point_to_point, src, tgt, (), init, max_iters,
-                       (C.c_float(md), C.c_float(convergence_threshold)), threads)
+    lib().tco_set_exact_sums(1 if exact_sums else 0)
+    try:
+        return _icp_common(lib().tco_icp_point_to_point, src, tgt, (), init, max_iters,
+                           (C.c_float(md), C.c_float(convergence_threshold)), threads)
+    finally:
+        lib().tco_set_exact_sums(0)
 
 
 def icp_point_to_point(src, tgt, init, max_iterations, convergence_threshold=1e-6, max_correspondence_distance=None, threads=0):
@@ -294,7 +299,8 @@ def gicp_covariances(points, k=20, threads=0):
     return out.reshape(-1, 3, 3)
 
 
-def kiss_icp(src, tgt, init=None, voxel_size=1.0, max_range=100.0, min_range=0.5, max_iterations=50, threads=0, voxel_order_seed=0):
+def kiss_icp(src, tgt, init=None, voxel_size=1.0, max_range=100.0, min_range=0.5, max_iterations=50, threads=0, voxel_order_seed=0,
+             exact_sums=False):
     """kiss_icp.rs:183-300 (KissIcpConfig defaults :40-49); correspondences index the voxel-downsampled source.
     Returns (IcpResult, number of downsampled source points)."""
     s, t = _f32(src, 3), _f32(tgt, 3)
@@ -306,11 +312,13 @@ def kiss_icp(src, tgt, init=None, voxel_size=1.0, max_range=100.0, min_range=0.5
     i7 = _f32(IDENTITY if init is None else init).reshape(7)
     nd = C.c_size_t(0)
     lib().tco_set_voxel_order_seed(int(voxel_order_seed))      # the reference's HashMap order is unspecified: see tc_oracle.c
+    lib().tco_set_exact_sums(1 if exact_sums else 0)            # diagnostic: the svd_transform sums' f32 terms added in f64
     try:
         rc = lib().tco_kiss_icp(_p(s), len(s), _p(t), len(t), _p(i7), voxel_size, max_range, min_range, max_iterations,
                                 C.byref(r), C.byref(nd), threads)
     finally:
         lib().tco_set_voxel_order_seed(0)
+        lib().tco_set_exact_sums(0)
     if rc:
         raise OracleError(rc)
     return IcpResult(r, len(s), cs, ct), int(nd.value)

@@ -1453,15 +1453,27 @@ static int kiss_svd_transform(const float *vs, const float *vq, size_t n, float 
     if (n < 3) return TCO_ALGORITHM;
     float nf = (float)n;
     float cs[3] = { 0, 0, 0 }, cq[3] = { 0, 0, 0 };
+    float h[3][3] = { {0, 0, 0}, {0, 0, 0}, {0, 0, 0} };
+    if (g_exact_sums) {          /* diagnostic (tco_set_exact_sums): the same f32 terms, added in f64 */
+        double dcs[3] = { 0, 0, 0 }, dcq[3] = { 0, 0, 0 }, dh[3][3] = { {0, 0, 0}, {0, 0, 0}, {0, 0, 0} };
+        for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) { dcs[c] += (double)vs[3 * i + c]; dcq[c] += (double)vq[3 * i + c]; }
+        for (int c = 0; c < 3; ++c) { cs[c] = (float)dcs[c] / nf; cq[c] = (float)dcq[c] / nf; }
+        for (size_t i = 0; i < n; ++i) {
+            float p[3] = { vs[3 * i] - cs[0], vs[3 * i + 1] - cs[1], vs[3 * i + 2] - cs[2] };
+            float q[3] = { vq[3 * i] - cq[0], vq[3 * i + 1] - cq[1], vq[3 * i + 2] - cq[2] };
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) dh[r][c] += (double)(p[r] * q[c]);
+        }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) h[r][c] = (float)dh[r][c];
+    } else {
     for (size_t i = 0; i < n; ++i) { cs[0] = cs[0] + vs[3 * i]; cs[1] = cs[1] + vs[3 * i + 1]; cs[2] = cs[2] + vs[3 * i + 2]; }
     cs[0] /= nf; cs[1] /= nf; cs[2] /= nf;
     for (size_t i = 0; i < n; ++i) { cq[0] = cq[0] + vq[3 * i]; cq[1] = cq[1] + vq[3 * i + 1]; cq[2] = cq[2] + vq[3 * i + 2]; }
     cq[0] /= nf; cq[1] /= nf; cq[2] /= nf;
-    float h[3][3] = { {0, 0, 0}, {0, 0, 0}, {0, 0, 0} };
     for (size_t i = 0; i < n; ++i) {
         float p[3] = { vs[3 * i] - cs[0], vs[3 * i + 1] - cs[1], vs[3 * i + 2] - cs[2] };
         float q[3] = { vq[3 * i] - cq[0], vq[3 * i + 1] - cq[1], vq[3 * i + 2] - cq[2] };
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) h[r][c] += p[r] * q[c];
+    }
     }
     float hn = 0.0f;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) hn += h[r][c] * h[r][c];

@@ -809,7 +809,20 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     // d[0] is the query itself (0), d[1] the squared distance to its nearest OTHER record (0 for an exact duplicate: never kept)
     if (prm.vor_out) prm.vor_out[p] = make_float4(q.x, q.y, q.z, 0.25f * 0.9999f * d[1]);
     float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
-    if (RADIUS && use_radius) {
+    // Radius mode with a radius set that fits the list (the query + at most L - 1 others): the set is exactly the list's first
+    // cnt_r + 1 entries, so it goes through the k-NN epilogue with k + 1 := cnt_r + 1 -- neighbours in ascending distance, the
+    // query last, f32 centroid / covariance in the reference's order (normals.rs:141-146, :164-177), nalgebra's eigen solve:
+    // bit-comparable like the k-NN path.  A larger set keeps the order-free f64 moments + closed form below.
+    const bool radius_fit = RADIUS && use_radius && cnt_r + 1u <= (uint32_t)L;
+    uint32_t K1e = K1;
+    if (radius_fit) {
+        K1e = cnt_r + 1u;
+        float tr = d[0];
+#pragma unroll
+        for (int t = 1; t < L; ++t) tr = ((uint32_t)t == cnt_r) ? d[t] : tr;
+        tau = tr;
+    }
+    if (RADIUS && use_radius && !radius_fit) {
         const double nn = (double)cnt_r + 1.0;                     // + the query itself (normals.rs:338-340)
         const double mx = s1x / nn, my = s1y / nn, mz = s1z / nn;
         double ex, ey, ez;
@@ -824,7 +837,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     uint32_t n_lt = 0;
 #pragma unroll
     for (int t = 0; t < L; ++t) n_lt += (d[t] < tau) ? 1u : 0u;
-    const uint32_t quota = K1 - min(n_lt, K1);
+    const uint32_t quota = K1e - min(n_lt, K1e);
     uint32_t ties = 0;
     cnt = 0;
     // rescan only the cells within sqrt(tau) of the query (same visiting order as phase 1).  (Measured instead: the plain,
@@ -840,7 +853,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
         bool take = v < tau;
         if (!take && v == tau && ties < quota) { take = true; ++ties; }
-        if (take && cnt < K1) { ldsA[cnt * BLOCK] = j; ++cnt; }
+        if (take && cnt < K1e) { ldsA[cnt * BLOCK] = j; ++cnt; }
     });
     TC_NSTAMP(3);
     // rank -> ascending-distance order (ties keep scan order)
