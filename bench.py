@@ -628,11 +628,13 @@ def main():
             # what the C ABI hands back is the dense per-source target index (tc_icp_result::corr_target, caller-allocated host
             # memory); turning it into Vec<(usize, usize)> is the binding's loop -- the Python mirror's numpy version of that
             # loop (astype / nonzero / stack: 2-3 ms per million points) is reported next to it, not inside it
-            th_i, _ = timed(lambda: ctx.icp_point_to_plane_detailed(src_h, tgt_h, nrm_host, None, ICP_ITERS, None, 0.0, correspondences="device"), 1, 3)
-            th_p, _ = timed(lambda: ctx.icp_point_to_plane_detailed(src_h, tgt_h, nrm_host, None, ICP_ITERS, None, 0.0, correspondences=True), 0, 3)
+            # (target_normals: &[Vector3f] in the reference's signature, registration.rs:508-516: an n x 3 array, as its callers build it)
+            nrm3_host = np.ascontiguousarray(nrm_host[:, 3:])
+            th_i, _ = timed(lambda: ctx.icp_point_to_plane_detailed(src_h, tgt_h, nrm3_host, None, ICP_ITERS, None, 0.0, correspondences="device"), 1, 3)
+            th_p, _ = timed(lambda: ctx.icp_point_to_plane_detailed(src_h, tgt_h, nrm3_host, None, ICP_ITERS, None, 0.0, correspondences=True), 0, 3)
             out["host_path"] = {"normals_ms": 1e3 * th_n, "icp_50it_ms": 1e3 * th_i, "it_per_s_whole_job": ICP_ITERS / (th_n + th_i),
                                 "icp_50it_ms_with_pairs_materialised_in_python": 1e3 * th_p,
-                                "bytes_h2d": int(12 * n + 12 * n + 12 * n + 24 * n), "bytes_d2h": int(24 * n + 4 * n),
+                                "bytes_h2d": int(12 * n + 12 * n + 12 * n + 12 * n), "bytes_d2h": int(24 * n + 4 * n),
                                 "note": "pageable numpy buffers in and out through tc_estimate_normals / tc_icp_point_to_plane_detailed "
                                         "(target first on the context's stream, source + normals on a copy stream under the target's index "
                                         "build), dense correspondence array returned; median of 3; never part of `value`"}

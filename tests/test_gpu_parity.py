@@ -237,10 +237,10 @@ def test_normals_radius_mode_matches_oracle(ctx, radius):
 
 
 def test_normals_radius_sets_that_fit_the_list_are_bit_comparable(ctx):
-    """VERDICT r2 missing #6: a radius set of at most L - 1 members (L = the register list of the launch: 17 for k <= 16) is
-    summed in the reference's f32 ascending-distance order (normals.rs:141-146, :164-177) and solved by its eigen algorithm,
-    like the k-NN path: bit-identical to the oracle up to exact distance ties.  12 000 uniform points, radius 0.07: 11-16
-    members for most points (k-NN fallback below 10, f64 moments above 16)."""
+    """VERDICT r2 missing #6: a radius set of at most L - 1 members (L = the register list of the launch, sized for the expected
+    set: 33 here) is summed in the reference's f32 ascending-distance order (normals.rs:141-146, :164-177) and solved by its
+    eigen algorithm, like the k-NN path: bit-identical to the oracle up to exact distance ties.  12 000 uniform points, radius
+    0.07: 17 members on average (k-NN fallback below 10, f64 moments above 32)."""
     pts = synth.uniform_cloud(12000, seed=7)
     r = 0.07
     cfg = tc.NormalEstimationConfig(k_neighbors=10, radius=r, consistent_orientation=True)
@@ -249,8 +249,8 @@ def test_normals_radius_sets_that_fit_the_list_are_bit_comparable(ctx):
     # members of every radius set (brute force on the f32 formula the searches use)
     idx, dist, cnt = O.knn_batch(pts, pts, 40)
     members = (dist.astype(np.float32) ** 2 <= np.float32(r) * np.float32(r)).sum(1) - 1       # rough count (sqrt round trip): +-1 at the boundary
-    fits = (members >= 11) & (members <= 14)            # safely inside "radius set used" and "fits a 17-entry list"
-    assert fits.sum() > 2000
+    fits = (members >= 11) & (members <= 30)            # safely inside "radius set used" and "fits the 33-entry list"
+    assert fits.sum() > 9000
     same = (gpu[:, 3:] == ref[:, 3:]).all(1)
     assert same[fits].mean() >= 0.999, same[fits].mean()
     c = cos_abs(gpu[:, 3:], ref[:, 3:])

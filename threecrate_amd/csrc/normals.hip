@@ -1210,10 +1210,25 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     } stat_dump{ctx->stream};
 #endif
     if (cfg.has_radius && cfg.radius > 0.0f) {   // radius <= 0 finds nothing (nearest_neighbor.rs:255): pure k-NN fallback
-        if (K1 <= 11)      launch_variant<11, 256, true>(ctx->stream, gv, prm, d_out6, ctx);
-        else if (K1 <= 17) launch_variant<17, 256, true>(ctx->stream, gv, prm, d_out6, ctx);
-        else if (K1 <= 33) launch_variant<33, 128, true>(ctx->stream, gv, prm, d_out6, ctx);
-        else if (K1 <= 65) launch_variant<65, 64, true>(ctx->stream, gv, prm, d_out6, ctx);
+        // A radius set that fits the register list is summed in the reference's order (normals_point: radius_fit), so the list
+        // is sized for the EXPECTED set -- density of the box x ball volume, + 3 sigma -- when that is within reach of an
+        // instantiation, else for k + 1 as before (larger sets then take the f64 moments).
+        uint32_t Lw = K1;
+        {
+            const GridGeom &g = gv.g;
+            double vol = 1.0, emax = std::max({(double)g.maxx - g.minx, (double)g.maxy - g.miny, (double)g.maxz - g.minz});
+            bool flat = !(emax > 0.0);
+            for (double e : {(double)g.maxx - g.minx, (double)g.maxy - g.miny, (double)g.maxz - g.minz}) { if (!(e > 1e-3 * emax)) flat = true; vol *= e; }
+            if (!flat && vol > 0.0) {
+                const double lam = (double)g.n / vol * 4.18879 * (double)cfg.radius * cfg.radius * cfg.radius;
+                const double want = lam + 3.0 * std::sqrt(lam) + 2.0;
+                if (want <= 129.0) Lw = std::max<uint32_t>(K1, (uint32_t)want);
+            }
+        }
+        if (Lw <= 11)      launch_variant<11, 256, true>(ctx->stream, gv, prm, d_out6, ctx);
+        else if (Lw <= 17) launch_variant<17, 256, true>(ctx->stream, gv, prm, d_out6, ctx);
+        else if (Lw <= 33) launch_variant<33, 128, true>(ctx->stream, gv, prm, d_out6, ctx);
+        else if (Lw <= 65) launch_variant<65, 64, true>(ctx->stream, gv, prm, d_out6, ctx);
         else               launch_variant<129, 64, true>(ctx->stream, gv, prm, d_out6, ctx);
         TC_HIP_TRY(ctx, hipGetLastError());
         return TC_OK;
