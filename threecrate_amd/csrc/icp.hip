@@ -731,15 +731,96 @@ __device__ __forceinline__ unsigned long long refine_shell(const GridView &tgt, 
     return group_min_u64(lk);
 }
 
+// Ball scan (round 3): once a query holds a candidate, everything that can beat it lies in the ball of that distance -- and the ball
+// clipped to the grid is enumerated DIRECTLY, row by row ((y, z) pairs dealt to the group's lanes, the x window of a row in closed
+// form like the normals' pruned scans) instead of shell by shell around the query's cell.  Shells cost O(R^3) cell tests for a
+// match R cells away; a query D cells OUTSIDE the target's box has its match in a thin cap of the box (depth ~1 cell, lateral
+// radius sqrt(2 D) cells): the rows of the cap, O(D), not the (2 sqrt(2 D))^3 cells of the shells that reach it.  A lane's limit is
+// its own best so far, refreshed from the group every few batches: always >= the final distance, so no cell of the final ball is
+// skipped.  Exact like the shells (same distance expression, same (distance, position) key).
+__device__ __forceinline__ unsigned long long refine_ball_scan(const GridView &tgt, const __amdgpu_buffer_rsrc_t &cs_rsrc,
+                                                               const __amdgpu_buffer_rsrc_t &pt_rsrc, int lg, float x, float y, float z,
+                                                               unsigned long long bestkey, float cap2) {
+    const GridGeom &g = tgt.g;
+    float lim = fminf(__uint_as_float((uint32_t)(bestkey >> 32)), cap2);
+    // rows the ball can reach (clamped coordinates: with a clamped box the boundary rows also hold the points beyond it).  A query
+    // OUTSIDE the box along some axis is at least that far from every record (all of them lie inside an exact box), which leaves
+    // the other axes only the rest of the budget: the cap of the box the ball cuts off, not the ball's whole bounding square.
+    const float ox = g.clamped ? 0.0f : fmaxf(fmaxf(g.minx - x, x - g.maxx), 0.0f) * 0.9999f;
+    const float oy = g.clamped ? 0.0f : fmaxf(fmaxf(g.miny - y, y - g.maxy), 0.0f) * 0.9999f;
+    const float oz = g.clamped ? 0.0f : fmaxf(fmaxf(g.minz - z, z - g.maxz), 0.0f) * 0.9999f;
+    const float ry = sqrtf(fmaxf(lim - ox * ox - oz * oz, 0.0f)) * 1.0001f + 4e-3f * g.h;
+    const float rz = sqrtf(fmaxf(lim - ox * ox - oy * oy, 0.0f)) * 1.0001f + 4e-3f * g.h;
+    const int y0 = cell_coord(fminf(fmaxf(y - ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy), y1 = cell_coord(fminf(fmaxf(y + ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy);
+    const int z0 = cell_coord(fminf(fmaxf(z - rz, g.minz), g.maxz), g.minz, g.inv_h, g.gz), z1 = cell_coord(fminf(fmaxf(z + rz, g.minz), g.maxz), g.minz, g.inv_h, g.gz);
+    const int ny = y1 - y0 + 1;
+    const uint32_t nrows = (uint32_t)ny * (uint32_t)(z1 - z0 + 1);
+    unsigned long long lk = bestkey;
+    uint32_t batch = 0;
+    for (uint32_t r0i = (uint32_t)lg; r0i < nrows; r0i += kRG * kRB, ++batch) {
+        uint32_t s0[kRB], e0[kRB];
+#pragma unroll
+        for (int t = 0; t < kRB; ++t) {
+            const uint32_t ri = r0i + (uint32_t)t * kRG;
+            const int zz = z0 + (int)(min(ri, nrows - 1) / (uint32_t)ny), yy = y0 + (int)(min(ri, nrows - 1) % (uint32_t)ny);
+            const float gy = axis_gap(y, g.miny, g.h, yy, g.gy - 1, g.clamped), gz = axis_gap(z, g.minz, g.h, zz, g.gz - 1, g.clamped);
+            const float rg = gy * gy + gz * gz;
+            bool in = ri < nrows && !(rg + ox * ox > lim);
+            int xa = 0, xb = 0;
+            if (in) {
+                const float rx = __builtin_amdgcn_sqrtf(fmaxf(lim - rg, 0.0f)) * 1.0001f + 4e-3f * g.h;
+                const float fa = fminf(fmaxf((x - rx - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
+                const float fb = fmaxf(fminf((x + rx - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
+                xa = (int)fa; xb = (int)fb;
+                in = xa <= xb;
+            }
+            const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
+            uint32_t s = 0, e = 0;
+            if (in) {
+                s = __builtin_amdgcn_raw_buffer_load_b32(cs_rsrc, (row + (uint32_t)xa) << 2, 0, 0);
+                e = __builtin_amdgcn_raw_buffer_load_b32(cs_rsrc, (row + (uint32_t)xb + 1u) << 2, 0, 0);
+            }
+            s0[t] = s; e0[t] = e;
+        }
+#pragma unroll
+        for (int t = 0; t < kRB; ++t) {
+            for (uint32_t jj = s0[t]; jj < e0[t]; jj += 4) {
+                const uint32_t o = jj << 4;
+                const f32x3 p0 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o, 0, 0));
+                const f32x3 p1 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u, 0, 0));
+                const f32x3 p2 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 32u, 0, 0));
+                const f32x3 p3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 48u, 0, 0));
+                // (reads past the span hit real points of the next cells or the +inf padding: harmless extra candidates)
+                const unsigned long long k0 = ((unsigned long long)__float_as_uint(d2_nc(p0.x, p0.y, p0.z, x, y, z)) << 32) | jj;
+                const unsigned long long k1 = ((unsigned long long)__float_as_uint(d2_nc(p1.x, p1.y, p1.z, x, y, z)) << 32) | (jj + 1);
+                const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2_nc(p2.x, p2.y, p2.z, x, y, z)) << 32) | (jj + 2);
+                const unsigned long long k3 = ((unsigned long long)__float_as_uint(d2_nc(p3.x, p3.y, p3.z, x, y, z)) << 32) | (jj + 3);
+                const unsigned long long ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
+                const unsigned long long kc = ka < kb ? ka : kb;
+                lk = kc < lk ? kc : lk;
+            }
+        }
+        lim = fminf(lim, __uint_as_float((uint32_t)(lk >> 32)));
+        if ((batch & 3u) == 3u) {       // what the other lanes of the group have found tightens this lane's limit
+            float gl = lim;
+#pragma unroll
+            for (int o = kRG / 2; o > 0; o >>= 1) gl = fminf(gl, __shfl_xor(gl, o));
+            lim = gl;
+        }
+    }
+    return group_min_u64(lk);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src,
     IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
     const double *__restrict__ main_rows, uint32_t n_main_rows, uint32_t seg_stride, double *__restrict__ partial_rows,
-    const float4 *__restrict__ src_cov) {
+    const float4 *__restrict__ src_cov, int dbg) {
     constexpr bool P2PLANE = MODE == 1;
     constexpr int NACC = MODE == 0 ? TC_ICP_SUMS_P2P : TC_ICP_SUMS_P2PLANE;
     if (st->done) return;
+    const bool dbg_shells = (dbg & 8192) != 0;          // TC_DEBUG & 8192: shells only, as before round 3 (A/B)
     __shared__ float lacc[kRefineThreads / kRG][TC_ICP_SUMS_STRIDE];
     // every refine block also folds its share of the main pass's per-block rows (written by the
     // previous launch) into its own row, in a fixed order: icp_finalize then reads kRefineBlocks rows
@@ -858,6 +939,12 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
             if (covers || !any_touched) break;
             if (bestkey != ~0ull && bd <= bound * bound + out2) break;
             if (max_dist >= 0.0f && bound > max_dist) break;   // everything unscanned would be rejected
+            // a candidate in hand and the ring rule not met: the rest of its ball, directly (see refine_ball_scan); without a
+            // candidate -- an empty neighbourhood -- the shells keep growing until one turns up
+            if (bestkey != ~0ull && !(dbg_shells)) {
+                bestkey = refine_ball_scan(tgt, cs_rsrc, pt_rsrc, lg, x, y, z, bestkey, max_dist >= 0.0f ? max_dist * max_dist * 1.0001f : INFINITY);
+                break;
+            }
         }
         if (lg == 0) {
             const float best = __uint_as_float((uint32_t)(bestkey >> 32));
@@ -1361,7 +1448,7 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
         ProfScope ps(ctx, "icp_refine");
         auto kern = mode == 1 ? icp_refine_kernel<1> : mode == 2 ? icp_refine_kernel<2> : icp_refine_kernel<0>;
         hipLaunchKernelGGL(kern, dim3(kRefineBlocks), dim3(kRefineThreads), 0, s, tv, nrm, src, st, corr_pos, rlist, partials, l.nblocks, l.chunk / (kIcpBlock / 64),
-                           refine_rows, src_cov);
+                           refine_rows, src_cov, dbg);
     }
     if (do_sum || do_apply) {
         ProfScope ps(ctx, "icp_finalize");
