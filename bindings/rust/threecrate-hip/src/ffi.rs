@@ -81,6 +81,7 @@ extern "C" {
     pub fn tc_device_count() -> c_int;
     pub fn tc_context_create(device: c_int, out: *mut *mut tc_context) -> c_int;
     pub fn tc_context_create_on_stream(device: c_int, hip_stream: *mut c_void, out: *mut *mut tc_context) -> c_int;
+    pub fn tc_context_trim(ctx: *mut tc_context) -> c_int;
     pub fn tc_context_destroy(ctx: *mut tc_context);
     pub fn tc_last_error_message(ctx: *const tc_context) -> *const c_char;
     pub fn tc_normal_config_default(cfg: *mut tc_normal_config);

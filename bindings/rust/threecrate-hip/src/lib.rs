@@ -81,11 +81,26 @@ fn result_from(r: &ffi::tc_icp_result, corr: &[u32], n_valid: usize) -> ICPResul
 }
 
 /// `Option<f32>` -> the ABI's encoding (< 0 = None).  A negative `Some(d)` must not alias `None`: the reference rejects every
-/// pair then (`distance > d` always holds, registration.rs:100-101) and fails with "Insufficient correspondences".
-fn encode_max_dist(d: Option<f32>) -> Result<f32> {
+/// pair then (`distance > d` always holds, registration.rs:100-101) and fails with "Insufficient correspondences" -- AFTER its
+/// own validation (registration.rs:266-276 / :517-531: empty clouds, the normals' length, max_iterations == 0 are InvalidData
+/// first), which therefore runs here in the same order before the Algorithm error is returned.
+fn encode_max_dist(d: Option<f32>, ns: usize, nt: usize, max_iters: usize, normals_len: Option<usize>) -> Result<f32> {
     match d {
         None => Ok(-1.0),
-        Some(v) if v < 0.0 => Err(Error::Algorithm("Insufficient correspondences found".to_string())),
+        Some(v) if v < 0.0 => {
+            if ns == 0 || nt == 0 {
+                return Err(Error::InvalidData("Source or target point cloud is empty".to_string()));
+            }
+            if let Some(nn) = normals_len {
+                if nn != nt {
+                    return Err(Error::InvalidData("target_normals length must equal the number of target points".to_string()));
+                }
+            }
+            if max_iters == 0 {
+                return Err(Error::InvalidData("Max iterations must be positive".to_string()));
+            }
+            Err(Error::Algorithm("Insufficient correspondences found".to_string()))
+        }
         Some(v) => Ok(v),
     }
 }
@@ -138,7 +153,7 @@ pub fn icp_detailed(ctx: &HipContext, source: &PointCloud<Point3f>, target: &Poi
     let i7 = iso_to7(&init);
     ctx.check(unsafe {
         ffi::tc_icp_detailed(ctx.0, xyz(source), ns, xyz(target), target.points.len(), i7.as_ptr(), max_iters,
-                             encode_max_dist(max_correspondence_distance)?, convergence_threshold, &mut r)
+                             encode_max_dist(max_correspondence_distance, ns, target.points.len(), max_iters, None)?, convergence_threshold, &mut r)
     })?;
     Ok(result_from(&r, &corr, ns))
 }
@@ -161,7 +176,7 @@ pub fn icp_point_to_point(ctx: &HipContext, source: &PointCloud<Point3f>, target
     let i7 = iso_to7(&init);
     ctx.check(unsafe {
         ffi::tc_icp_point_to_point(ctx.0, xyz(source), ns, xyz(target), target.points.len(), i7.as_ptr(), max_iterations,
-                                   convergence_threshold, encode_max_dist(max_correspondence_distance)?, &mut r)
+                                   convergence_threshold, encode_max_dist(max_correspondence_distance, ns, target.points.len(), max_iterations, None)?, &mut r)
     })?;
     Ok(result_from(&r, &corr, ns))
 }
@@ -177,7 +192,8 @@ pub fn icp_point_to_plane_detailed(ctx: &HipContext, source: &PointCloud<Point3f
     ctx.check(unsafe {
         ffi::tc_icp_point_to_plane_detailed(ctx.0, xyz(source), ns, xyz(target), target.points.len(),
                                             target_normals.as_ptr() as *const f32, target_normals.len(), 3, i7.as_ptr(), max_iters,
-                                            encode_max_dist(max_correspondence_distance)?, convergence_threshold, &mut r)
+                                            encode_max_dist(max_correspondence_distance, ns, target.points.len(), max_iters, Some(target_normals.len()))?,
+                                            convergence_threshold, &mut r)
     })?;
     Ok(result_from(&r, &corr, ns))
 }
@@ -348,7 +364,8 @@ impl<'a> HipCloud<'a> {
         r.corr_target = std::ptr::null_mut();            // (device memory when wanted: see the header)
         let i7 = iso_to7(&init);
         self.ctx.check(unsafe {
-            ffi::tc_cloud_icp_point_to_plane(self.raw, target.raw, i7.as_ptr(), max_iters, encode_max_dist(max_correspondence_distance)?,
+            ffi::tc_cloud_icp_point_to_plane(self.raw, target.raw, i7.as_ptr(), max_iters,
+                                             encode_max_dist(max_correspondence_distance, self.len(), target.len(), max_iters, None)?,
                                              convergence_threshold, &mut r)
         })?;
         Ok(result_from(&r, &[], 0))
@@ -394,7 +411,8 @@ impl<'a> HipComm<'a> {
         let i7 = iso_to7(&init);
         self.ctx.check(ffi::tc_sharded_icp_point_to_plane_device(self.ctx.0, self.raw, ffi::TC_SHARD_SPATIAL, d_source, n_source, d_target,
                                                                   n_target, d_target_normals, n_target, normal_stride, i7.as_ptr(), max_iters,
-                                                                  encode_max_dist(max_correspondence_distance)?, convergence_threshold, &mut r))?;
+                                                                  encode_max_dist(max_correspondence_distance, n_source, n_target, max_iters, None)?,
+                                                                  convergence_threshold, &mut r))?;
         Ok(result_from(&r, &[], 0))
     }
 }

@@ -114,6 +114,10 @@ tc_status   tc_context_wait_stream(tc_context *ctx, void *other_hip_stream);
  * For a producer that is about to overwrite or free a device buffer it has just handed to a stream-ordered entry point
  * (tc_cloud_upload_device copies on the context's stream): no host wait. */
 tc_status   tc_stream_wait_context(tc_context *ctx, void *other_hip_stream);
+/* Device memory given back by destroyed handles (tc_cloud, tc_search_index) is parked in the context and reused by the next
+ * handle of a similar size (a handle per frame costs no hipMalloc); the parked amount is capped at a few handles' worth.
+ * tc_context_trim releases all of it to the device -- for a caller about to hand the GPU to another allocator. */
+tc_status   tc_context_trim(tc_context *ctx);
 void        tc_context_destroy(tc_context *ctx);
 const char *tc_last_error_message(const tc_context *ctx);
 tc_status   tc_synchronize(tc_context *ctx);

@@ -83,7 +83,7 @@ class KernelStatC(C.Structure):
 # every symbol include/threecrate_hip.h declares (tests/test_abi_symbols.py checks the header against this)
 EXPORTS = [
     "tc_abi_version", "tc_device_count", "tc_context_create", "tc_context_create_on_stream", "tc_context_wait_stream", "tc_stream_wait_context",
-    "tc_context_destroy", "tc_last_error_message", "tc_synchronize", "tc_normal_config_default",
+    "tc_context_trim", "tc_context_destroy", "tc_last_error_message", "tc_synchronize", "tc_normal_config_default",
     "tc_estimate_normals", "tc_estimate_normals_device", "tc_estimate_normals_slice_device", "tc_normals_unsort_device", "tc_icp_detailed", "tc_icp_detailed_device",
     "tc_icp_point_to_point", "tc_icp", "tc_icp_point_to_plane_detailed",
     "tc_icp_point_to_plane_detailed_device", "tc_batch_icp", "tc_icp_shard_create", "tc_icp_shard_sums",
@@ -143,6 +143,8 @@ def load():
     L.tc_context_create_on_stream.argtypes = [i, vp, ctxpp]
     L.tc_context_wait_stream.argtypes = [vp, vp]
     L.tc_stream_wait_context.argtypes = [vp, vp]
+    L.tc_context_trim.argtypes = [vp]
+    L.tc_context_trim.restype = C.c_int
     L.tc_context_destroy.argtypes = [vp]
     L.tc_context_destroy.restype = None
     L.tc_last_error_message.argtypes = [vp]

@@ -146,6 +146,11 @@ class GpuContext:
         self.device = device
         self.stream = stream          # raw hipStream_t the context enqueues on (None: its own stream)
 
+    def trim(self):
+        """tc_context_trim: release the device memory parked by destroyed handles (the context keeps a few handles' worth for
+        reuse) -- before handing the GPU to another allocator"""
+        self._check(self._L.tc_context_trim(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.tc_context_destroy(self._h)

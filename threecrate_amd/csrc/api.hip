@@ -21,11 +21,17 @@ tc_status fail(tc_context *ctx, tc_status st, const std::string &msg) {
     return st;
 }
 
-constexpr size_t kPoolMaxBytes = (size_t)32 << 30, kPoolMaxBlocks = 96;
+// The pool parks what destroyed handles give back so that a handle per frame costs no hipMalloc.  Its cap follows the blocks it has
+// seen -- a few handles' worth (a handle holds about a dozen buffers of at most `pool_largest` bytes) -- instead of a flat 32 GB:
+// memory parked here is invisible to every other allocator of the process (torch's caching allocator, RCCL, a second context),
+// which would run out of memory next to it.  tc_context_trim releases it on demand.
+constexpr size_t kPoolMaxBytes = (size_t)32 << 30, kPoolMinBytes = (size_t)256 << 20, kPoolMaxBlocks = 96;
 
 void recycle(tc_context *ctx, DevBuf &b) {
     if (!b.p) return;
-    if (ctx->pool.size() >= kPoolMaxBlocks || ctx->pool_bytes + b.cap > kPoolMaxBytes) {
+    ctx->pool_largest = std::max(ctx->pool_largest, b.cap);
+    const size_t cap_bytes = std::min(kPoolMaxBytes, std::max(kPoolMinBytes, 48 * ctx->pool_largest));
+    if (ctx->pool.size() >= kPoolMaxBlocks || ctx->pool_bytes + b.cap > cap_bytes) {
         (void)hipFree(b.p);
     } else {
         ctx->pool.push_back(b);
@@ -260,7 +266,7 @@ void tc_context_destroy(tc_context *ctx) {
     if (ctx->upload_event) (void)hipEventDestroy(ctx->upload_event);
     free_index(ctx->tgt_index); free_index(ctx->src_index); free_index(ctx->vox_index);
     free_buf(ctx->in_a); free_buf(ctx->in_b); free_buf(ctx->in_c); free_buf(ctx->out_a); free_buf(ctx->bbox);
-    free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->gicp_src_cov); free_buf(ctx->overflow); free_buf(ctx->dbg_times);
+    free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->gicp_src_cov); free_buf(ctx->overflow); free_buf(ctx->normals_hard); free_buf(ctx->dbg_times);
     for (auto &pb : ctx->pool) (void)hipFree(pb.p);
     for (auto e : ctx->chunk_events) (void)hipEventDestroy(e);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
@@ -270,6 +276,17 @@ void tc_context_destroy(tc_context *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+tc_status tc_context_trim(tc_context *ctx) {
+    if (!ctx) return TC_INVALID_DATA;
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &pb : ctx->pool) (void)hipFree(pb.p);
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+    ctx->pool_largest = 0;
+    return TC_OK;
 }
 
 const char *tc_last_error_message(const tc_context *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }

@@ -46,6 +46,8 @@ struct NormalParams {
     float4 *sorted_nrm;     // optional: the normal of cell-sorted position p -> sorted_nrm[p] (a cloud handle keeps them: the ICP target layout)
     float4 *vor_out;        // optional: {x, y, z, inscribed-ball bound} per position (icp.hip: the bound is a quarter of the squared
                             // distance to the nearest OTHER record = the second entry of the k-NN list, for free here)
+    uint32_t *hard_list;        // optional: positions whose search would outgrow kHardRing rings are appended here (hard_list[0] = count,
+                                // entries from [1]) and served by normals_coop_kernel, one wave per point
     uint32_t p_begin, p_end;    // cell-sorted positions handled by this launch (a multi-GPU shard: SURVEY 8e)
     int      slice_out;         // 1: record of position p goes to row p - p_begin (sorted order) instead of its original index
 #ifdef TC_PHASE_STAMPS
@@ -334,6 +336,8 @@ __device__ __forceinline__ void sym_eigen3_f32(float axx, float axy, float axz, 
     }
     e0 = d0 * amax; e1 = d1 * amax; e2 = d2 * amax;
 }
+
+constexpr int kHardRing = 6;        // a search that would go beyond this many rings is a hard point (normals_coop_kernel)
 
 // square root for pruning radii: the raw v_sqrt_f32 (1 ulp; the callers add the cell-assignment fuzz, thousands of ulps, as slack;
 // sqrtf's correctly rounded sequence costs ~10 instructions per row: 434 -> 421 us at 1 M points)
@@ -790,6 +794,12 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         const float need2 = RADIUS ? fmaxf(r2, 0.0f) : 0.0f;     // radius mode must also see the whole radius ball
         if (tau == INFINITY) R += max(1, R / 2);
         else R = max(R + 1, (int)fminf(ceilf(sqrtf(fmaxf(tau, need2)) * g.inv_h - mf + 0.01f), 1.0e9f));
+        // An isolated point (a far outlier: its neighbours are a hundred extents away; a point in an empty region) would walk
+        // thousands of rows -- the whole grid -- through ONE lane: handed to normals_coop_kernel instead, a wave per point.
+        if (!RADIUS && prm.hard_list != nullptr && R > kHardRing) {
+            prm.hard_list[1u + atomicAdd(&prm.hard_list[0], 1u)] = p;
+            return;
+        }
         // one call site for both cases (lanes of a wave differ): only the growing lanes refresh their limit
         // one call site (a second, plain one costs 20 registers and sends the list to scratch)
         const bool growing = tau == INFINITY || R > Rin + 1;
@@ -928,6 +938,206 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = nrm_x; o[4] = nrm_y; o[5] = nrm_z;
     }
     TC_NSTAMP(7);
+}
+
+// ---- cooperative k-NN + PCA: one wave per point (round 3) -------------------------------------------------------------------
+// For the points the lane-per-point kernel cannot serve: k_neighbors > 128 (its sorted list lives in registers: 129 entries at
+// most; the reference has no cap, normals.rs:17-26) and HARD points, whose neighbours are so far away that one lane would walk the
+// whole grid (normals_point hands them over through prm.hard_list).  The wave enumerates the ball of a radius r clipped to the
+// grid row by row (rows dealt to the lanes, closed-form x windows), appends (distance bits << 32 | position) of every record within
+// r to an LDS buffer, and adapts r until the buffer holds at least k + 1 and at most CAPB records -- then the buffer IS the ball,
+// a bitonic sort orders it by (distance, position): the first k + 1 keys are the reference's neighbour list, ties to the lowest
+// position like the register-list path.  Lane 0 runs the reference's f32 centroid / covariance / eigen sequence over the
+// neighbours' coordinates (parked in LDS by all lanes).  Same bits as normals_point on every point both can serve.
+constexpr int kCoopThreads = 256;
+template <int CAPB>
+__global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv, NormalParams prm, float *__restrict__ out6, const uint32_t *__restrict__ hard) {
+    __shared__ unsigned long long buf[CAPB];
+    __shared__ float nbx[CAPB / 2], nby[CAPB / 2], nbz[CAPB / 2];
+    __shared__ uint32_t cnt_s;
+    __shared__ int self_s, bin_s;
+    __shared__ uint32_t hist[256];          // squared distances of the current ball over (lo2, lim], 256 bins: where an overflowing ball is cut
+    const GridGeom &g = gv.g;
+    const int tid = threadIdx.x;
+    const uint32_t count = hard ? hard[0] : prm.p_end - prm.p_begin;
+    const uint32_t nfin = gv.cell_start[g.ncell];
+    for (uint32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const uint32_t p = hard ? hard[1u + idx] : prm.p_begin + idx;
+        const float4 q = gv.pts[p];
+        const uint32_t orig = __float_as_uint(q.w);
+        float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
+        float vor_w = 0.0f;
+        float px = q.x, py = q.y, pz = q.z;
+        if (p >= nfin) {            // a non-finite point: the default normal (see normals_point)
+            if (tid == 0) { px = prm.xyz[3 * (size_t)orig]; py = prm.xyz[3 * (size_t)orig + 1]; pz = prm.xyz[3 * (size_t)orig + 2]; }
+        } else {
+            const uint32_t K1 = min(prm.k + 1u, nfin);
+            // the radius that certainly holds the whole cloud: the distance to the farthest corner of its (grid) box -- a clamped box
+            // has records beyond it: there only the counts end the growth
+            const float fxm = fmaxf(fabsf(q.x - g.minx), fabsf(q.x - g.maxx)), fym = fmaxf(fabsf(q.y - g.miny), fabsf(q.y - g.maxy)),
+                        fzm = fmaxf(fabsf(q.z - g.minz), fabsf(q.z - g.maxz));
+            const float r_all = g.clamped ? 3.0e38f : sqrtf(fxm * fxm + fym * fym + fzm * fzm) * 1.001f;
+            // the first radius at which the box proper comes into reach of a point outside it; no record INSIDE an exact box is
+            // closer than the box (a clamped box has records beyond it, possibly nearer: they fall into the first histogram bin)
+            const float bxo = fmaxf(fmaxf(g.minx - q.x, q.x - g.maxx), 0.0f), byo = fmaxf(fmaxf(g.miny - q.y, q.y - g.maxy), 0.0f),
+                        bzo = fmaxf(fmaxf(g.minz - q.z, q.z - g.maxz), 0.0f);
+            const float d_box2 = (bxo * bxo + byo * byo + bzo * bzo) * 0.9999f;
+            const float r_box = sqrtf(d_box2) + 2.0f * g.h;
+            float r = 2.0f * g.h * cbrtf((float)K1 / 17.0f);
+            float lo2 = 0.0f;                           // a squared radius known to hold fewer than K1 records
+            uint32_t total = 0;
+            for (int guard = 0; guard < 200; ++guard) {
+                if (tid == 0) cnt_s = 0;
+                hist[tid] = 0;
+                __syncthreads();
+                const float lim = r * r;
+                const float hlo = fminf(fmaxf(lo2, d_box2), lim);          // the histogram's range: (hlo, lim]
+                const float hscale = 256.0f / fmaxf(lim - hlo, 1e-30f);
+                const float ry = r * 1.0001f + 4e-3f * g.h;
+                const int y0 = cell_coord(fminf(fmaxf(q.y - ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy), y1 = cell_coord(fminf(fmaxf(q.y + ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy);
+                const int z0 = cell_coord(fminf(fmaxf(q.z - ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz), z1 = cell_coord(fminf(fmaxf(q.z + ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz);
+                const int ny = y1 - y0 + 1;
+                const uint32_t nrows = (uint32_t)ny * (uint32_t)(z1 - z0 + 1);
+                auto take = [&](uint32_t j, const float4 &c) {
+                    const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+                    if (v <= lim) {
+                        const uint32_t slot = atomicAdd(&cnt_s, 1u);
+                        if (slot < (uint32_t)CAPB) buf[slot] = ((unsigned long long)__float_as_uint(v) << 32) | j;
+                        atomicAdd(&hist[min((uint32_t)(fmaxf(v - hlo, 0.0f) * hscale), 255u)], 1u);
+                    }
+                };
+                for (uint32_t ri = (uint32_t)tid; ri < nrows; ri += kCoopThreads) {
+                    const int zz = z0 + (int)(ri / (uint32_t)ny), yy = y0 + (int)(ri % (uint32_t)ny);
+                    const float gy = g.clamped ? axis_gap_n<true>(q.y, g.miny, g.h, yy, g.gy - 1) : axis_gap_n<false>(q.y, g.miny, g.h, yy, g.gy - 1);
+                    const float gz = g.clamped ? axis_gap_n<true>(q.z, g.minz, g.h, zz, g.gz - 1) : axis_gap_n<false>(q.z, g.minz, g.h, zz, g.gz - 1);
+                    const float rg = gy * gy + gz * gz;
+                    if (rg > lim) continue;
+                    const float rx = sqrtf(fmaxf(lim - rg, 0.0f)) * 1.0001f + 4e-3f * g.h;
+                    const int xa = (int)fminf(fmaxf((q.x - rx - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
+                    const int xb = (int)fmaxf(fminf((q.x + rx - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
+                    if (xa > xb) continue;
+                    const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
+                    const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
+                    for (uint32_t j = s; j < e; j += 4) {          // (reads past the span stay inside the padded array)
+                        const float4 c0 = gv.pts[j], c1 = gv.pts[j + 1], c2 = gv.pts[j + 2], c3 = gv.pts[j + 3];
+                        take(j, c0);
+                        if (j + 1 < e) take(j + 1, c1);
+                        if (j + 2 < e) take(j + 2, c2);
+                        if (j + 3 < e) take(j + 3, c3);
+                    }
+                }
+                __syncthreads();
+                total = cnt_s;
+                if (total > (uint32_t)CAPB) {
+                    // too many for the buffer: cut the ball at the histogram bin in which the count reaches K1 (everything binned at
+                    // or below it lies within the bin's upper edge: the new ball still holds >= K1 records, and ~1/256 of the excess)
+                    if (tid == 0) {
+                        uint32_t cum = 0; int b = 0;
+                        for (; b < 255; ++b) { cum += hist[b]; if (cum >= K1) break; }
+                        bin_s = b;
+                    }
+                    __syncthreads();
+                    const int mybin = bin_s;
+                    const float width = (lim - hlo) / 256.0f;
+                    const float new_lim = fminf((hlo + (float)(mybin + 1) * width) * 1.00001f + 1e-37f, lim);
+                    const float new_lo = fmaxf(hlo + (float)mybin * width * 0.99999f - 1e-37f, lo2);
+                    const bool stuck = !(new_lim < lim) && !(new_lo > lo2);
+                    __syncthreads();
+                    if (stuck) break;                                       // a plateau of ties wider than the buffer
+                    lo2 = (mybin > 0) ? new_lo : fmaxf(lo2, fminf(hlo, new_lim) * 0.99999f);
+                    r = sqrtf(new_lim) * 1.000001f;
+                    continue;
+                }
+                __syncthreads();
+                if (total >= K1 || total >= nfin || r >= r_all) break;
+                lo2 = lim * 0.99999f;                    // too few: grow towards the expected count (at most 2x per step), and at least to the box
+                float rn = r * fminf(2.0f, fmaxf(1.26f, cbrtf(1.5f * (float)K1 / (float)max(total, 1u))));
+                if (r < r_box) rn = fmaxf(rn, r_box);
+                r = fminf(rn, r_all);
+            }
+            // (total > CAPB here only for a tie plateau wider than the buffer: the launch code sizes CAPB >= 2 (k + 1), such a cloud
+            // holds thousands of points at exactly the same distance: not reachable with distinct points)
+            total = min(total, (uint32_t)CAPB);
+            // bitonic sort of the first n2 = 2^m >= total entries (padding: all ones)
+            uint32_t n2 = 2 * kCoopThreads;
+            while (n2 < total) n2 <<= 1;
+            for (uint32_t i = total + tid; i < n2; i += kCoopThreads) buf[i] = ~0ull;
+            if (tid == 0) self_s = -1;
+            __syncthreads();
+            for (uint32_t kk = 2; kk <= n2; kk <<= 1) {
+                for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+                    for (uint32_t t = (uint32_t)tid; t < (n2 >> 1); t += kCoopThreads) {
+                        const uint32_t i = 2 * t - (t & (jj - 1));          // the lower index of pair t at distance jj
+                        const uint32_t l = i + jj;
+                        const unsigned long long a = buf[i], b = buf[l];
+                        const bool up = (i & kk) == 0;
+                        if ((a > b) == up) { buf[i] = b; buf[l] = a; }
+                    }
+                    __syncthreads();
+                }
+            }
+            const uint32_t cnt = min(K1, total);        // the k + 1 nearest (fewer: the whole cloud)
+            // their coordinates, parked in LDS by all lanes
+            for (uint32_t r2 = (uint32_t)tid; r2 < cnt; r2 += kCoopThreads) {
+                const uint32_t j = (uint32_t)buf[r2];
+                const float4 c = gv.pts[j];
+                nbx[r2] = c.x; nby[r2] = c.y; nbz[r2] = c.z;
+                if (j == p) self_s = (int)r2;
+            }
+            __syncthreads();
+            const int self_r = self_s;
+            vor_w = 0.25f * 0.9999f * (cnt >= 2 ? __uint_as_float((uint32_t)(buf[1] >> 32)) : INFINITY);
+            if (tid == 0) {
+                // normals.rs:147-153: drop self from the k + 1 list (or the last entry when self is not in it); self appended last
+                const int drop_r = (self_r >= 0) ? self_r : (int)cnt - 1;
+                const uint32_t npts = cnt;
+                if (npts >= 3) {
+                    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+                    for (uint32_t r2 = 0; r2 < cnt; ++r2) {
+                        if ((int)r2 == drop_r) continue;
+                        sx += nbx[r2]; sy += nby[r2]; sz += nbz[r2];
+                    }
+                    sx += q.x; sy += q.y; sz += q.z;
+                    const float nf = (float)npts;
+                    const float mx = sx / nf, my = sy / nf, mz = sz / nf;
+                    float cxx = 0.0f, cxy = 0.0f, cxz = 0.0f, cyy = 0.0f, cyz = 0.0f, czz = 0.0f;
+                    for (uint32_t r2 = 0; r2 < cnt; ++r2) {
+                        if ((int)r2 == drop_r) continue;
+                        const float dx = nbx[r2] - mx, dy = nby[r2] - my, dz = nbz[r2] - mz;
+                        cxx += dx * dx; cxy += dx * dy; cxz += dx * dz; cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
+                    }
+                    {
+                        const float dx = q.x - mx, dy = q.y - my, dz = q.z - mz;
+                        cxx += dx * dx; cxy += dx * dy; cxz += dx * dz; cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
+                    }
+                    cxx /= nf; cxy /= nf; cxz /= nf; cyy /= nf; cyz /= nf; czz /= nf;
+                    float e0, e1, e2, x0, y0, z0, x1, y1, z1, x2, y2, z2;
+                    sym_eigen3_f32(cxx, cxy, cxz, cyy, cyz, czz, e0, e1, e2, x0, y0, z0, x1, y1, z1, x2, y2, z2);
+                    float vx = x0, vy = y0, vz = z0, emin = e0;
+                    if (e1 < emin) { emin = e1; vx = x1; vy = y1; vz = z1; }
+                    if (e2 < emin) { vx = x2; vy = y2; vz = z2; }
+                    const float mag = sqrtf(vx * vx + vy * vy + vz * vz);
+                    if (mag > 1e-6f) { nrm_x = vx / mag; nrm_y = vy / mag; nrm_z = vz / mag; }
+                }
+                if (prm.orient) {
+                    const float tx = prm.vx - q.x, ty = prm.vy - q.y, tz = prm.vz - q.z;
+                    const float tn = sqrtf(tx * tx + ty * ty + tz * tz);
+                    const float ux = tx / tn, uy = ty / tn, uz = tz / tn;
+                    const float dp = nrm_x * ux + nrm_y * uy + nrm_z * uz;
+                    if (dp < 0.0f) { nrm_x = -nrm_x; nrm_y = -nrm_y; nrm_z = -nrm_z; }
+                }
+            }
+        }
+        if (tid == 0) {
+            if (prm.sorted_nrm) prm.sorted_nrm[p] = make_float4(nrm_x, nrm_y, nrm_z, 0.0f);
+            if (prm.vor_out) prm.vor_out[p] = make_float4(q.x, q.y, q.z, vor_w);
+            if (out6) {
+                float *o = out6 + 6 * (size_t)(prm.slice_out ? p - prm.p_begin : orig);
+                o[0] = px; o[1] = py; o[2] = pz; o[3] = nrm_x; o[4] = nrm_y; o[5] = nrm_z;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // XCD-aware block remap: hardware deals blocks round-robin over the 8 XCDs, so give each XCD
@@ -1154,8 +1364,13 @@ tc_status launch_normals_unsort(tc_context *ctx, const DeviceIndex &ix, const fl
 
 tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_xyz, const tc_normal_config &cfg, const float vp[3],
                          float *d_out6, size_t p_begin, size_t p_end, bool slice_out, float4 *d_sorted_nrm, float4 *d_vor) {
-    if (cfg.k_neighbors + 1 > 129) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 128 is not supported by the HIP backend");
+    const bool radius_mode = cfg.has_radius && cfg.radius > 0.0f;
+    // k_neighbors > 128: the wave-per-point kernel (the k + 1 nearest in an LDS buffer instead of a register list), up to 2047
+    const bool big_k = cfg.k_neighbors + 1 > 129;
+    if (big_k && radius_mode) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 128 together with a radius is not supported by the HIP backend");
+    if (cfg.k_neighbors + 1 > 2048) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 2047 is not supported by the HIP backend");
     NormalParams prm;
+    prm.hard_list = nullptr;
     prm.k = (uint32_t)cfg.k_neighbors;
     prm.orient = cfg.consistent_orientation ? 1 : 0;
     prm.vx = vp[0]; prm.vy = vp[1]; prm.vz = vp[2];
@@ -1193,6 +1408,34 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
 #endif
     const GridView gv = view_of(ix);
     const uint32_t K1 = prm.k + 1;
+    if (big_k) {
+        const uint32_t npts = prm.p_end - prm.p_begin;
+        if (npts == 0) return TC_OK;
+        ProfScope ps(ctx, "normals_coop");
+        const dim3 grid(std::min<uint32_t>(npts, 1u << 16)), block(kCoopThreads);
+        if (K1 <= 256) hipLaunchKernelGGL(normals_coop_kernel<512>, grid, block, 0, ctx->stream, gv, prm, d_out6, (const uint32_t *)nullptr);
+        else hipLaunchKernelGGL(normals_coop_kernel<4096>, grid, block, 0, ctx->stream, gv, prm, d_out6, (const uint32_t *)nullptr);
+        TC_HIP_TRY(ctx, hipGetLastError());
+        return TC_OK;
+    }
+    // hard points (isolated: their search would walk the grid through one lane) are listed by the main launch and served by the
+    // wave-per-point kernel behind it (k-NN mode)
+    if (!radius_mode && prm.p_end > prm.p_begin) {
+        if (tc_status s = ensure(ctx, ctx->normals_hard, ((size_t)(prm.p_end - prm.p_begin) + 1) * sizeof(uint32_t))) return s;
+        prm.hard_list = (uint32_t *)ctx->normals_hard.p;
+        TC_HIP_TRY(ctx, hipMemsetAsync(prm.hard_list, 0, sizeof(uint32_t), ctx->stream));
+    }
+    struct HardPass {
+        tc_context *ctx; const GridView &gv; NormalParams &prm; float *out6;
+        ~HardPass() {
+            if (!prm.hard_list) return;
+            const uint32_t *hl = prm.hard_list;
+            NormalParams p2 = prm;
+            p2.hard_list = nullptr;
+            ProfScope ps(ctx, "normals_coop");
+            hipLaunchKernelGGL(normals_coop_kernel<512>, dim3(256), dim3(kCoopThreads), 0, ctx->stream, gv, p2, out6, hl);
+        }
+    } hard_pass{ctx, gv, prm, d_out6};
 #ifdef TC_NSTATS
     {
         unsigned long long z[16] = {0};

@@ -142,6 +142,7 @@ struct tc_context {
     // size: a handle per frame must not cost a hipMalloc / hipFree pair per buffer per frame (milliseconds)
     std::vector<tc::DevBuf> pool;
     size_t pool_bytes = 0;
+    size_t pool_largest = 0;                // largest block ever parked: the pool's cap is a multiple of it (api.hip: recycle)
     hipEvent_t order_event = nullptr;       // tc_context_wait_stream
     hipEvent_t release_event = nullptr;     // tc_stream_wait_context
     std::vector<hipEvent_t> chunk_events;   // hipEventDisableTiming events of the ICP loop's chunk polling, reused across calls
@@ -163,6 +164,7 @@ struct tc_context {
     tc::DevBuf gicp_src_cov;        // GICP: source covariances in the sorted source order (2 float4 per point)
     tc::DevBuf dbg_times;           // TC_DEBUG & 1024: per-block stamps of the main pass
     tc::DevBuf overflow;            // scratch (voxel filter: occupied-cell flags / output slots)
+    tc::DevBuf normals_hard;        // normals: count + positions of the points handed to the wave-per-point kernel
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
     size_t pinned_cap = 0;
