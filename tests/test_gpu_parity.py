@@ -754,20 +754,17 @@ def test_partially_overlapping_scans_and_far_sources_without_a_maximum_distance(
     tgt = synth.uniform_cloud(n, seed=21)
     src = synth.apply_isometry(synth.yaw_isometry((0.5, 0.02, -0.01), 0.02), tgt[::2]).astype(np.float32)     # 50 % overlap along x
     src[:3] = np.array([[100, 0.5, 0.5], [0.5, -100, 0.2], [0.3, 0.3, 100]], np.float32)                      # + three far points
-    t0 = time.perf_counter()
-    g = ctx.icp_detailed(src, tgt, None, 3, None, 0.0)
-    dt = time.perf_counter() - t0
-    r = O.icp_detailed(src, tgt, None, 3, None, 0.0)
-    assert g.iterations == r.iterations == 3
-    # every source point has a match (no cut-off) and it is the kd-tree's, up to exact ties
+    # ONE iteration from the identity: both sides search under the same transform -- every source point has a match (no cut-off)
+    # and it is the kd-tree's, up to exact ties
+    g = ctx.icp_detailed(src, tgt, None, 1, None, 0.0)
+    r = O.icp_detailed(src, tgt, None, 1, None, 0.0)
     assert len(g.correspondences) == len(src) == len(r.correspondences)
-    h1.correspondence_report(src, tgt, _last_transform_before(g, r, src, tgt), g.correspondences, r.correspondences)
-    assert dt < 2.0
-
-
-def _last_transform_before(g, r, src, tgt):
-    """the transform under which the LAST iteration's pairs were found: two iterations of the oracle (the runs agree to rounding)"""
-    return O.icp_detailed(src, tgt, None, 2, None, 0.0).transformation
+    h1.correspondence_report(src, tgt, O.IDENTITY, g.correspondences, r.correspondences)
+    # ... and several iterations at kd-tree-like cost
+    ctx.icp_detailed(src, tgt, None, 5, None, 0.0)
+    t0 = time.perf_counter()
+    g = ctx.icp_detailed(src, tgt, None, 5, None, 0.0, correspondences=False)
+    assert g.iterations == 5 and time.perf_counter() - t0 < 0.05
 
 
 def test_sharded_normals_slices_reassemble(ctx):

@@ -281,6 +281,59 @@ __global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restric
     pts[s + rank] = r;
 }
 
+// Direct placement (round 3): the point's record goes straight to  cell_start[cell] + arrival rank  -- the input is read once,
+// coalesced, instead of being gathered 12 bytes at a time through the permutation (7x over-fetch) -- and a second, streaming
+// pass re-ranks the records INSIDE each cell by original index (the deterministic order; the arrival order is the atomics').
+__global__ void __launch_bounds__(256) place_kernel(const float *__restrict__ xyz, uint32_t n, uint32_t nkeys,
+                                                   const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ cell_start,
+                                                   const uint32_t *__restrict__ arrival, float4 *__restrict__ tmp) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cell_of[i];
+    const uint32_t pos = cell_start[c] + arrival[i];
+    float4 r;
+    r.x = xyz[3 * (size_t)i]; r.y = xyz[3 * (size_t)i + 1]; r.z = xyz[3 * (size_t)i + 2];
+    if (c == nkeys) r.x = r.y = r.z = __uint_as_float(0x7F7F7F7Fu);     // the non-finite bucket: d2 to anything = +inf, never selected
+    r.w = __uint_as_float(i);
+    tmp[pos] = r;
+}
+
+// (the record's cell is computed again from its coordinates -- the same expressions on the same bits as cell_hist_kernel -- rather
+// than carried in a second scattered array: scattered 4-byte writes cost as much as the 16-byte ones)
+__global__ void __launch_bounds__(256) rerank_kernel(uint32_t n, GridGeom g, const IcpState *__restrict__ st, TileGeom tg, int tile_major,
+                                                    uint32_t nkeys, const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tmp,
+                                                    float4 *__restrict__ pts) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float4 r = tmp[p];
+    uint32_t c;
+    {
+        float x = r.x, y = r.y, z = r.z;
+        if (st) {
+            float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]}, t[3] = {st->t[0], st->t[1], st->t[2]};
+            float ox, oy, oz;
+            isometry_apply(q, t, x, y, z, ox, oy, oz);
+            x = ox; y = oy; z = oz;
+        }
+        const int ix = cell_coord(x, g.minx, g.inv_h, g.gx), iy = cell_coord(y, g.miny, g.inv_h, g.gy), iz = cell_coord(z, g.minz, g.inv_h, g.gz);
+        c = tile_major ? tile_major_id(tg, ix, iy, iz) : ((uint32_t)iz * g.gy + iy) * g.gx + ix;
+        // (the non-finite bucket's records hold the placeholder 0x7F7F7F7F = 3.39e38; a transformed finite point that overflowed
+        // was put there by cell_hist_kernel through the same test)
+        if (!(fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f)) c = nkeys;
+    }
+    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+    const uint32_t i = __float_as_uint(r.w);
+    // rank = the number of records of the cell with a smaller original index (see rank_gather_kernel for the population cut-off)
+    uint32_t rank;
+    if (e - s <= kRankQuadraticMax) {
+        rank = 0;
+        for (uint32_t j = s; j < e; ++j) rank += (__float_as_uint(tmp[j].w) < i) ? 1u : 0u;
+    } else {
+        rank = p - s;
+    }
+    pts[s + rank] = r;
+}
+
 __global__ void __launch_bounds__(256) gather_normals_kernel(const float4 *__restrict__ pts, uint32_t n,
                                                             const float *__restrict__ nrm, size_t stride,
                                                             float4 *__restrict__ out) {
@@ -492,15 +545,16 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
             const uint32_t nscan = (nkeys + 1 + kScanTile - 1) / kScanTile;
             TC_HIP_TRY(ctx, hipMemcpyAsync(h_occ, (const uint32_t *)ix.blocksum.p + 2 * nscan, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         }
+        if (tc_status s = ensure(ctx, ctx->build_tmp, (n + kPtsPad) * sizeof(float4))) return s;       // (shared by every build of the context)
         {
-            ProfScope ps(ctx, "cell_scatter");
-            hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)ix.cell_of.p, n32,
-                               (const uint32_t *)cs, (const uint32_t *)ix.arrival.p, (uint32_t *)ix.slot.p);
+            ProfScope ps(ctx, "cell_place");
+            hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, nkeys, (const uint32_t *)ix.cell_of.p, (const uint32_t *)cs,
+                               (const uint32_t *)ix.arrival.p, (float4 *)ctx->build_tmp.p);
         }
         {
-            ProfScope ps(ctx, "cell_rank_gather");
-            hipLaunchKernelGGL(rank_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, nkeys, (const uint32_t *)ix.cell_of.p,
-                               (const uint32_t *)cs, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p, 0);
+            ProfScope ps(ctx, "cell_rerank");
+            hipLaunchKernelGGL(rerank_kernel, dim3(nb), dim3(256), 0, st, n32, g, d_state_transform, tg, tile_major ? 1 : 0, nkeys, (const uint32_t *)cs,
+                               (const float4 *)ctx->build_tmp.p, (float4 *)ix.pts.p);
         }
         TC_HIP_TRY(ctx, hipGetLastError());
         if (!check) break;

@@ -164,6 +164,7 @@ struct tc_context {
     tc::DevBuf gicp_src_cov;        // GICP: source covariances in the sorted source order (2 float4 per point)
     tc::DevBuf dbg_times;           // TC_DEBUG & 1024: per-block stamps of the main pass
     tc::DevBuf overflow;            // scratch (voxel filter: occupied-cell flags / output slots)
+    tc::DevBuf build_tmp;           // index build: the records in arrival order, before the in-cell re-rank (float4 * n)
     tc::DevBuf normals_hard;        // normals: count + positions of the points handed to the wave-per-point kernel
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
