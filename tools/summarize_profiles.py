@@ -26,7 +26,7 @@ def short(name):
     for k in ["icp_correspond_reduce_kernel<1>", "icp_correspond_reduce_kernel<0>", "icp_correspond_reduce_kernel<2>",
               "icp_refine_kernel<1>", "icp_refine_kernel<0>", "icp_refine_kernel<2>", "icp_finalize_kernel", "knn_kernel", "vox_hist_kernel", "vox_scatter_kernel",
               "vox_rank_kernel", "vox_flag_kernel", "vox_centroid_kernel",
-              "normals_knn_pca_kernel", "normals_overflow_kernel", "cell_hist_kernel", "scatter_kernel",
+              "normals_knn_pca_kernel", "normals_coop_kernel", "normals_overflow_kernel", "cell_hist_kernel", "place_kernel", "rerank_kernel", "scatter_kernel",
               "rank_gather_kernel", "scan_apply_kernel", "scan_top_kernel", "scan_reduce_kernel", "bbox_kernel",
               "gather_normals_kernel", "icp_finish_kernel", "icp_write_corr_kernel", "icp_final_mse_kernel"]:
         if k.split("<")[0] in name and (("<" not in k) or (k[k.index("<"):] in name)):
