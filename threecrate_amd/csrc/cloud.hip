@@ -173,8 +173,11 @@ static tc_status cloud_normals(tc_cloud *c, const tc_normal_config *cfg, float *
     if (tc_status s = ensure_index(c, normals_cell_factor(cfg->k_neighbors, c->n >= kAdaptMinPoints), normals_target_ppo(cfg->k_neighbors), min_h)) return s;
     if (tc_status s = ensure(ctx, c->ix.normals, c->n * sizeof(float4))) return s;
     // the N x 6 records in input order (24-byte scattered stores) are only produced when somebody wants them
-    const bool want6 = out != nullptr || keep6;
-    float *d_out6 = nullptr;
+    // (a caller's DEVICE array is written directly: no copy of the 24-byte records through the handle's own array -- should the
+    // index ever be rebuilt, ensure_index recovers the input-order normals from the cell-sorted ones)
+    const bool direct = out != nullptr && !out_on_host && !keep6;
+    const bool want6 = (out != nullptr || keep6) && !direct;
+    float *d_out6 = direct ? out : nullptr;
     if (want6) {
         if (tc_status s = ensure(ctx, c->normals6, c->n * 6 * sizeof(float))) return s;
         d_out6 = (float *)c->normals6.p;
@@ -186,7 +189,7 @@ static tc_status cloud_normals(tc_cloud *c, const tc_normal_config *cfg, float *
                                        (float4 *)c->ix.normals.p, true)) return s;
     c->has_normals = true;
     c->has_normals6 = want6;
-    if (out) TC_HIP_TRY(ctx, hipMemcpyAsync(out, d_out6, c->n * 6 * sizeof(float), out_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+    if (out && !direct) TC_HIP_TRY(ctx, hipMemcpyAsync(out, d_out6, c->n * 6 * sizeof(float), out_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
 }

@@ -1660,10 +1660,10 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
     TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
     if (res->corr_target) {
+        // (a caller's device array is written directly, a host array through the context's buffer)
         hipLaunchKernelGGL(icp_write_corr_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, su.tv, src, (uint32_t)ns,
-                           corr_pos, corr);
-        TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, ns * sizeof(uint32_t),
-                                       corr_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+                           corr_pos, corr_on_device ? res->corr_target : corr);
+        if (!corr_on_device) TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     }
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
     TC_HIP_TRY(ctx, hipGetLastError());
