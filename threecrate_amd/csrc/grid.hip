@@ -4,10 +4,12 @@
 //   bbox_kernel      : per-block min/max partials, folded on the host (order independent)
 //   cell_hist_kernel : cell id per point + histogram
 //   scan_*           : exclusive prefix sum of the histogram -> cell_start
-//   scatter_kernel   : counting-sort scatter by the arrival rank the histogram atomics returned
-//                      (atomic arrival order, not yet deterministic)
-//   rank_gather_kernel : stable re-rank inside each cell by original index -> deterministic
+//   place_kernel     : the record goes straight to cell_start[cell] + the arrival rank the histogram atomics returned
+//                      (input read once, coalesced; atomic arrival order, not yet deterministic)
+//   rerank_kernel    : streaming re-rank inside each cell by original index -> deterministic
 //                      cell-sorted float4 {x, y, z, original-index bits}
+//   (strict_order builds -- ranks that split one order between them -- replace the order of a cloud with an oversized cell by a
+//    stable radix sort of (cell, original index) + rank_gather_kernel)
 // HBM traffic per point: 12 B read (AoS xyz) + 4 B cell id + 16 B sorted record + 4 B slot
 // (SURVEY 8d "index build" figure: 32 B/pt).
 #include "tc_internal.h"
@@ -242,15 +244,8 @@ __global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *
     }
 }
 
-__global__ void __launch_bounds__(256) scatter_kernel(const uint32_t *__restrict__ cell_of, uint32_t n,
-                                                     const uint32_t *__restrict__ cell_start,
-                                                     const uint32_t *__restrict__ arrival, uint32_t *__restrict__ slot) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    slot[cell_start[cell_of[i]] + arrival[i]] = i;
-}
-
-// stable re-rank inside the cell (ascending original index) + gather into the sorted record array
+// (strict-order path only) records gathered through `slot`, the original indices in final order (slot_is_ordered), or --
+// historically -- in arrival order with a stable re-rank inside the cell
 __global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restrict__ xyz, uint32_t n, uint32_t nkeys,
                                                          const uint32_t *__restrict__ cell_of,
                                                          const uint32_t *__restrict__ cell_start,
