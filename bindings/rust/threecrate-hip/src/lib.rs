@@ -295,7 +295,7 @@ impl<'a> HipKdTree<'a> {
 
 impl NearestNeighborSearch for HipKdTree<'_> {
     fn find_k_nearest(&self, query: &Point3f, k: usize) -> Vec<(usize, f32)> {
-        self.query(std::slice::from_ref(query), k.min(self.len()).min(129), -1.0).map(|mut v| v.remove(0)).unwrap_or_default()
+        self.query(std::slice::from_ref(query), k.min(self.len()).min(2048), -1.0).map(|mut v| v.remove(0)).unwrap_or_default()
     }
 
     /// every neighbour within `radius`, nearest first (nearest_neighbor.rs:254-298): count, then fill

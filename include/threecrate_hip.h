@@ -130,8 +130,10 @@ void        tc_normal_config_default(tc_normal_config *cfg);   /* normals.rs:28-
  * = cfg{k=10, radius, consistent, viewpoint None}; gpu_estimate_normals
  * (threecrate-gpu/src/normals.rs:443-461) has the same meaning.
  * xyz: n x 3 f32.  out: n x 6 f32 (NormalPoint3f).  n == 0 -> TC_OK before the k check.
- * Limits of this backend (the reference has none): k_neighbors <= 128 (the k + 1 nearest incl. the point itself live in a
- * 129-entry register list; the k-NN / radius exports below return up to 129 entries per query) -> TC_UNSUPPORTED beyond.
+ * Limits of this backend (the reference has none): k_neighbors <= 2047 (up to 128 the k + 1 nearest incl. the point itself live in
+ * a 129-entry register list, one lane per point; beyond that a block-per-point kernel serves every point; the k-NN / radius
+ * exports below return up to 2048 entries per query) -> TC_UNSUPPORTED beyond; k_neighbors > 128 together with a radius:
+ * TC_UNSUPPORTED.
  * Non-finite points (NaN / +-inf coordinates) are inert: never a neighbour, their own normal is the default (0, 0, 1). */
 tc_status tc_estimate_normals(tc_context *ctx, const float *xyz, size_t n,
                               const tc_normal_config *cfg, float *out_normal_points);
@@ -358,7 +360,7 @@ tc_status tc_multiscale_icp_point_to_point(tc_context *ctx, const float *source,
  * :25-40, defaults 50 iterations, max distance 1.0, threshold 1e-6, k = 20): per-point covariances from the k
  * nearest points (:52-86), per pair M = C_t + R C_s R^T, 6x6 Gauss-Newton system H dx = g, Cholesky then LU,
  * update Rz Ry Rx + t, mse = mean squared correspondence distance before the update.  Clouds smaller than
- * max(k, 4) points or with a bounding-box side < 1e-4 -> TC_INVALID_DATA; k > 129 -> TC_UNSUPPORTED. */
+ * max(k, 4) points or with a bounding-box side < 1e-4 -> TC_INVALID_DATA; k > 2048 -> TC_UNSUPPORTED. */
 typedef struct tc_gicp_config {
     size_t max_iterations;
     float  max_correspondence_distance;
@@ -394,7 +396,8 @@ tc_status tc_kiss_icp_device(tc_context *ctx, const float *d_source, size_t n_so
  * (threecrate-core/src/traits.rs:6-12, threecrate-algorithms/src/nearest_neighbor.rs:177-251;
  * gpu_find_k_nearest_batch threecrate-gpu/src/nearest_neighbor.rs:345-355; Python KdTree.knn
  * threecrate-python/src/lib.rs:735-745).  Row q of idx / dist (nq x k) holds count[q] = min(k, n)
- * neighbours in ascending distance = sqrt(d2); k == 0 or n == 0 -> count = 0.  k <= 129. */
+ * neighbours in ascending distance = sqrt(d2); k == 0 or n == 0 -> count = 0.  k <= 2048 (up to 129 in a lane-per-query
+ * kernel, beyond that a block per query). */
 tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *queries, size_t nq, size_t k,
                  uint32_t *idx, float *dist, uint32_t *count);
 tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, size_t k,
@@ -405,7 +408,7 @@ tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const f
  * nearest_neighbor.rs:254-298: every point with d2 <= radius^2, ascending distance) for many queries, capped at
  * k_max nearest per query like gpu_find_radius_neighbors (threecrate-gpu/src/nearest_neighbor.rs:357-367,
  * k_max = 32 there).  Row q of idx / dist (nq x k_max) holds count[q] entries; count[q] == k_max may be a
- * truncated neighbourhood.  radius <= 0 -> empty results.  k_max <= 129. */
+ * truncated neighbourhood.  radius <= 0 -> empty results.  k_max <= 2048. */
 tc_status tc_radius_search(tc_context *ctx, const float *cloud, size_t n, const float *queries, size_t nq, float radius, size_t k_max,
                            uint32_t *idx, float *dist, uint32_t *count);
 tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, float radius,
@@ -415,7 +418,7 @@ tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t 
  * KdTree::new(&points) once (threecrate-algorithms/src/nearest_neighbor.rs:37-58), then any number of
  * find_k_nearest / find_radius_neighbors calls (threecrate-core/src/traits.rs:6-12; Python `KdTree`
  * threecrate-python/src/lib.rs:707-776).  The handle owns a cell-sorted copy of the cloud and its grid in device
- * memory; the caller's buffer is not referenced after create.  k_hint sizes the cells (any k <= 129 is answered
+ * memory; the caller's buffer is not referenced after create.  k_hint sizes the cells (any k <= 2048 is answered
  * exactly whatever the hint).  An empty cloud gives an empty index (every count = 0), like the reference.
  * query: radius < 0 -> the k nearest; radius >= 0 -> the neighbours with distance <= radius among the k nearest
  * (count[q] == k means there may be more).  Rows of idx / dist (nq x k) ascending by distance = sqrt(d2).

@@ -692,7 +692,12 @@ def test_search_index_handle_matches_one_shot_calls(ctx):
     empty = tc.SearchIndex(ctx, np.zeros((0, 3), np.float32))
     assert len(empty) == 0 and empty.find_k_nearest_batch(q, 4)[2].sum() == 0
     with pytest.raises(tc.Unsupported):
-        ix.find_k_nearest_batch(q, 130)
+        ix.find_k_nearest_batch(q, 2049)
+    # beyond the register list's 129 entries: the block-per-query kernel (same answers: distances bit for bit against the kd-tree)
+    for kk in (130, 300):
+        i3, d3, c3 = ix.find_k_nearest_batch(q[:50], kk)
+        _, od3, oc3 = O.knn_batch(pts, q[:50], kk)
+        assert np.array_equal(c3, oc3) and np.array_equal(d3, od3)
     i100, d100, c100 = ix.find_k_nearest_batch(q, 100)            # the 129-entry instantiation
     _, od100, oc100 = O.knn_batch(pts, q, 100)
     assert np.array_equal(c100, oc100) and np.array_equal(d100, od100)

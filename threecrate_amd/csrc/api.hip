@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(256) gicp_cov_kernel(const float *__restrict__
 static tc_status gicp_covariances_device(tc_context *ctx, const float *d_xyz, size_t n, size_t k, DevBuf &idx, DevBuf &dist, DevBuf &cnt,
                                          float *d_cov8) {
     k = std::max<size_t>(k, 4);
-    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "GICP: k_correspondences > 129 is not supported by this backend");
+    if (k > 2048) return fail(ctx, TC_UNSUPPORTED, "GICP: k_correspondences > 2048 is not supported by this backend");
     if (tc_status s = ensure(ctx, idx, n * k * sizeof(uint32_t))) return s;
     if (tc_status s = ensure(ctx, dist, n * k * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, cnt, n * sizeof(uint32_t))) return s;
@@ -767,7 +767,7 @@ tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const f
         return TC_OK;
     }
     if (n >= 0xFFFFFFF0ull || nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
-    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP k-NN export");
+    if (k > 2048) return fail(ctx, TC_UNSUPPORTED, "k > 2048 is not supported by the HIP k-NN export");
     if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k > 1 ? k - 1 : 1, false) * 2.0f, nullptr, nullptr)) return s;
     if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k, d_idx, d_dist, d_count)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -786,7 +786,7 @@ tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t 
         return TC_OK;
     }
     if (n >= 0xFFFFFFF0ull || nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
-    if (k_max > 129) return fail(ctx, TC_UNSUPPORTED, "k_max > 129 is not supported by the HIP radius search");
+    if (k_max > 2048) return fail(ctx, TC_UNSUPPORTED, "k_max > 2048 is not supported by the HIP radius search");
     if (tc_status s = build_index(ctx, ctx->tgt_index, d_cloud, n, normals_cell_factor(k_max > 1 ? k_max - 1 : 1, false) * 2.0f, nullptr, nullptr)) return s;
     if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k_max, d_idx, d_dist, d_count, radius * radius)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -799,7 +799,7 @@ tc_status tc_radius_search(tc_context *ctx, const float *cloud, size_t n, const 
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!(radius > 0.0f) || n == 0 || k_max == 0) { std::memset(count, 0, nq * sizeof(uint32_t)); return TC_OK; }
-    if (k_max > 129) return fail(ctx, TC_UNSUPPORTED, "k_max > 129 is not supported by the HIP radius search");
+    if (k_max > 2048) return fail(ctx, TC_UNSUPPORTED, "k_max > 2048 is not supported by the HIP radius search");
     DevBuf dc, dq, di, dd, dn;
     auto cleanup = [&]() { for (DevBuf *b : {&dc, &dq, &di, &dd, &dn}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } };
     tc_status st = TC_OK;
@@ -823,7 +823,7 @@ tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *que
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (k == 0 || n == 0) { std::memset(count, 0, nq * sizeof(uint32_t)); return TC_OK; }
-    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP k-NN export");      // before any buffer is sized by k
+    if (k > 2048) return fail(ctx, TC_UNSUPPORTED, "k > 2048 is not supported by the HIP k-NN export");      // before any buffer is sized by k
     if (tc_status s = ensure(ctx, ctx->in_a, n * 3 * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, ctx->in_b, nq * 3 * sizeof(float))) return s;
     if (tc_status s = ensure(ctx, ctx->out_a, nq * k * 8 + nq * 4)) return s;
@@ -896,7 +896,7 @@ tc_status tc_search_index_query_device(tc_search_index *s, const float *d_querie
         TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return TC_OK;
     }
-    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP neighbour search");
+    if (k > 2048) return fail(ctx, TC_UNSUPPORTED, "k > 2048 is not supported by the HIP neighbour search");
     if (nq >= 0xFFFFFFF0ull) return fail(ctx, TC_UNSUPPORTED, "more than 2^32 points");
     if (tc_status rc = launch_knn(ctx, s->ix, d_queries, nq, k, d_idx, d_dist, d_count, by_radius ? radius * radius : INFINITY)) return rc;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -910,7 +910,7 @@ tc_status tc_search_index_query(tc_search_index *s, const float *queries, size_t
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (k == 0 || s->n == 0) { std::memset(count, 0, nq * sizeof(uint32_t)); return TC_OK; }
-    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP neighbour search");
+    if (k > 2048) return fail(ctx, TC_UNSUPPORTED, "k > 2048 is not supported by the HIP neighbour search");
     if (tc_status rc = ensure(ctx, s->q, nq * 3 * sizeof(float))) return rc;
     if (tc_status rc = ensure(ctx, s->out, nq * k * 8 + nq * 4)) return rc;
     uint32_t *d_idx = (uint32_t *)s->out.p;

@@ -950,13 +950,133 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
 // position like the register-list path.  Lane 0 runs the reference's f32 centroid / covariance / eigen sequence over the
 // neighbours' coordinates (parked in LDS by all lanes).  Same bits as normals_point on every point both can serve.
 constexpr int kCoopThreads = 256;
+
+// shared scratch of one block of the wave-per-point kernels
+template <int CAPB>
+struct CoopShared {
+    unsigned long long buf[CAPB];
+    uint32_t hist[256];         // squared distances of the current ball over (hlo, lim], 256 bins: where an overflowing ball is cut
+    uint32_t cnt;
+    int bin;
+};
+
+// The K1 nearest records of q (any point, inside or outside the grid), as keys (distance bits << 32 | position) sorted ascending in
+// sh.buf[0 .. return value): adaptive ball + LDS buffer + bitonic sort (see normals_coop_kernel).  Called by all threads of the block.
+template <int CAPB>
+__device__ __forceinline__ uint32_t coop_nearest(const GridView &gv, float qx, float qy, float qz, uint32_t K1, uint32_t nfin, CoopShared<CAPB> &sh) {
+    const GridGeom &g = gv.g;
+    const int tid = threadIdx.x;
+    // the radius that certainly holds the whole cloud: the distance to the farthest corner of its (grid) box -- a clamped box
+    // has records beyond it: there only the counts end the growth
+    const float fxm = fmaxf(fabsf(qx - g.minx), fabsf(qx - g.maxx)), fym = fmaxf(fabsf(qy - g.miny), fabsf(qy - g.maxy)),
+                fzm = fmaxf(fabsf(qz - g.minz), fabsf(qz - g.maxz));
+    const float r_all = g.clamped ? 3.0e38f : sqrtf(fxm * fxm + fym * fym + fzm * fzm) * 1.001f;
+    // the first radius at which the box proper comes into reach of a point outside it; no record INSIDE an exact box is
+    // closer than the box (a clamped box has records beyond it, possibly nearer: they fall into the first histogram bin)
+    const float bxo = fmaxf(fmaxf(g.minx - qx, qx - g.maxx), 0.0f), byo = fmaxf(fmaxf(g.miny - qy, qy - g.maxy), 0.0f),
+                bzo = fmaxf(fmaxf(g.minz - qz, qz - g.maxz), 0.0f);
+    const float d_box2 = (bxo * bxo + byo * byo + bzo * bzo) * 0.9999f;
+    const float r_box = sqrtf(d_box2) + 2.0f * g.h;
+    float r = 2.0f * g.h * cbrtf((float)K1 / 17.0f);
+    float lo2 = 0.0f;                           // a squared radius known to hold fewer than K1 records
+    uint32_t total = 0;
+    for (int guard = 0; guard < 200; ++guard) {
+        if (tid == 0) sh.cnt = 0;
+        sh.hist[tid] = 0;
+        __syncthreads();
+        const float lim = r * r;
+        const float hlo = fminf(fmaxf(lo2, d_box2), lim);          // the histogram's range: (hlo, lim]
+        const float hscale = 256.0f / fmaxf(lim - hlo, 1e-30f);
+        const float ry = r * 1.0001f + 4e-3f * g.h;
+        const int y0 = cell_coord(fminf(fmaxf(qy - ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy), y1 = cell_coord(fminf(fmaxf(qy + ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy);
+        const int z0 = cell_coord(fminf(fmaxf(qz - ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz), z1 = cell_coord(fminf(fmaxf(qz + ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz);
+        const int ny = y1 - y0 + 1;
+        const uint32_t nrows = (uint32_t)ny * (uint32_t)(z1 - z0 + 1);
+        auto take = [&](uint32_t j, const float4 &c) {
+            const float v = d2_nc(c.x, c.y, c.z, qx, qy, qz);
+            if (v <= lim) {
+                const uint32_t slot = atomicAdd(&sh.cnt, 1u);
+                if (slot < (uint32_t)CAPB) sh.buf[slot] = ((unsigned long long)__float_as_uint(v) << 32) | j;
+                atomicAdd(&sh.hist[min((uint32_t)(fmaxf(v - hlo, 0.0f) * hscale), 255u)], 1u);
+            }
+        };
+        for (uint32_t ri = (uint32_t)tid; ri < nrows; ri += kCoopThreads) {
+            const int zz = z0 + (int)(ri / (uint32_t)ny), yy = y0 + (int)(ri % (uint32_t)ny);
+            const float gy = g.clamped ? axis_gap_n<true>(qy, g.miny, g.h, yy, g.gy - 1) : axis_gap_n<false>(qy, g.miny, g.h, yy, g.gy - 1);
+            const float gz = g.clamped ? axis_gap_n<true>(qz, g.minz, g.h, zz, g.gz - 1) : axis_gap_n<false>(qz, g.minz, g.h, zz, g.gz - 1);
+            const float rg = gy * gy + gz * gz;
+            if (rg > lim) continue;
+            const float rx = sqrtf(fmaxf(lim - rg, 0.0f)) * 1.0001f + 4e-3f * g.h;
+            const int xa = (int)fminf(fmaxf((qx - rx - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
+            const int xb = (int)fmaxf(fminf((qx + rx - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
+            if (xa > xb) continue;
+            const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
+            const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
+            for (uint32_t j = s; j < e; j += 4) {          // (reads past the span stay inside the padded array)
+                const float4 c0 = gv.pts[j], c1 = gv.pts[j + 1], c2 = gv.pts[j + 2], c3 = gv.pts[j + 3];
+                take(j, c0);
+                if (j + 1 < e) take(j + 1, c1);
+                if (j + 2 < e) take(j + 2, c2);
+                if (j + 3 < e) take(j + 3, c3);
+            }
+        }
+        __syncthreads();
+        total = sh.cnt;
+        if (total > (uint32_t)CAPB) {
+            // too many for the buffer: cut the ball at the histogram bin in which the count reaches K1 (everything binned at
+            // or below it lies within the bin's upper edge: the new ball still holds >= K1 records, and ~1/256 of the excess)
+            if (tid == 0) {
+                uint32_t cum = 0; int b = 0;
+                for (; b < 255; ++b) { cum += sh.hist[b]; if (cum >= K1) break; }
+                sh.bin = b;
+            }
+            __syncthreads();
+            const int mybin = sh.bin;
+            const float width = (lim - hlo) / 256.0f;
+            const float new_lim = fminf((hlo + (float)(mybin + 1) * width) * 1.00001f + 1e-37f, lim);
+            const float new_lo = fmaxf(hlo + (float)mybin * width * 0.99999f - 1e-37f, lo2);
+            const bool stuck = !(new_lim < lim) && !(new_lo > lo2);
+            __syncthreads();
+            if (stuck) break;                                       // a plateau of ties wider than the buffer
+            lo2 = (mybin > 0) ? new_lo : fmaxf(lo2, fminf(hlo, new_lim) * 0.99999f);
+            r = sqrtf(new_lim) * 1.000001f;
+            continue;
+        }
+        __syncthreads();
+        if (total >= K1 || total >= nfin || r >= r_all) break;
+        lo2 = lim * 0.99999f;                    // too few: grow towards the expected count (at most 2x per step), and at least to the box
+        float rn = r * fminf(2.0f, fmaxf(1.26f, cbrtf(1.5f * (float)K1 / (float)max(total, 1u))));
+        if (r < r_box) rn = fmaxf(rn, r_box);
+        r = fminf(rn, r_all);
+    }
+    // (total > CAPB here only for a tie plateau wider than the buffer: the launch code sizes CAPB >= 2 K1, such a cloud holds
+    // thousands of points at exactly the same distance; which of them are used is then not reproducible)
+    total = min(total, (uint32_t)CAPB);
+    // bitonic sort of the first n2 = 2^m >= total entries (padding: all ones)
+    uint32_t n2 = 2 * kCoopThreads;
+    while (n2 < total) n2 <<= 1;
+    for (uint32_t i = total + tid; i < n2; i += kCoopThreads) sh.buf[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= n2; kk <<= 1) {
+        for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (uint32_t t = (uint32_t)tid; t < (n2 >> 1); t += kCoopThreads) {
+                const uint32_t i = 2 * t - (t & (jj - 1));          // the lower index of pair t at distance jj
+                const uint32_t l = i + jj;
+                const unsigned long long a = sh.buf[i], b = sh.buf[l];
+                const bool up = (i & kk) == 0;
+                if ((a > b) == up) { sh.buf[i] = b; sh.buf[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    return total;
+}
+
 template <int CAPB>
 __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv, NormalParams prm, float *__restrict__ out6, const uint32_t *__restrict__ hard) {
-    __shared__ unsigned long long buf[CAPB];
+    __shared__ CoopShared<CAPB> sh;
     __shared__ float nbx[CAPB / 2], nby[CAPB / 2], nbz[CAPB / 2];
-    __shared__ uint32_t cnt_s;
-    __shared__ int self_s, bin_s;
-    __shared__ uint32_t hist[256];          // squared distances of the current ball over (lo2, lim], 256 bins: where an overflowing ball is cut
+    __shared__ int self_s;
     const GridGeom &g = gv.g;
     const int tid = threadIdx.x;
     const uint32_t count = hard ? hard[0] : prm.p_end - prm.p_begin;
@@ -972,121 +1092,19 @@ __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv,
             if (tid == 0) { px = prm.xyz[3 * (size_t)orig]; py = prm.xyz[3 * (size_t)orig + 1]; pz = prm.xyz[3 * (size_t)orig + 2]; }
         } else {
             const uint32_t K1 = min(prm.k + 1u, nfin);
-            // the radius that certainly holds the whole cloud: the distance to the farthest corner of its (grid) box -- a clamped box
-            // has records beyond it: there only the counts end the growth
-            const float fxm = fmaxf(fabsf(q.x - g.minx), fabsf(q.x - g.maxx)), fym = fmaxf(fabsf(q.y - g.miny), fabsf(q.y - g.maxy)),
-                        fzm = fmaxf(fabsf(q.z - g.minz), fabsf(q.z - g.maxz));
-            const float r_all = g.clamped ? 3.0e38f : sqrtf(fxm * fxm + fym * fym + fzm * fzm) * 1.001f;
-            // the first radius at which the box proper comes into reach of a point outside it; no record INSIDE an exact box is
-            // closer than the box (a clamped box has records beyond it, possibly nearer: they fall into the first histogram bin)
-            const float bxo = fmaxf(fmaxf(g.minx - q.x, q.x - g.maxx), 0.0f), byo = fmaxf(fmaxf(g.miny - q.y, q.y - g.maxy), 0.0f),
-                        bzo = fmaxf(fmaxf(g.minz - q.z, q.z - g.maxz), 0.0f);
-            const float d_box2 = (bxo * bxo + byo * byo + bzo * bzo) * 0.9999f;
-            const float r_box = sqrtf(d_box2) + 2.0f * g.h;
-            float r = 2.0f * g.h * cbrtf((float)K1 / 17.0f);
-            float lo2 = 0.0f;                           // a squared radius known to hold fewer than K1 records
-            uint32_t total = 0;
-            for (int guard = 0; guard < 200; ++guard) {
-                if (tid == 0) cnt_s = 0;
-                hist[tid] = 0;
-                __syncthreads();
-                const float lim = r * r;
-                const float hlo = fminf(fmaxf(lo2, d_box2), lim);          // the histogram's range: (hlo, lim]
-                const float hscale = 256.0f / fmaxf(lim - hlo, 1e-30f);
-                const float ry = r * 1.0001f + 4e-3f * g.h;
-                const int y0 = cell_coord(fminf(fmaxf(q.y - ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy), y1 = cell_coord(fminf(fmaxf(q.y + ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy);
-                const int z0 = cell_coord(fminf(fmaxf(q.z - ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz), z1 = cell_coord(fminf(fmaxf(q.z + ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz);
-                const int ny = y1 - y0 + 1;
-                const uint32_t nrows = (uint32_t)ny * (uint32_t)(z1 - z0 + 1);
-                auto take = [&](uint32_t j, const float4 &c) {
-                    const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
-                    if (v <= lim) {
-                        const uint32_t slot = atomicAdd(&cnt_s, 1u);
-                        if (slot < (uint32_t)CAPB) buf[slot] = ((unsigned long long)__float_as_uint(v) << 32) | j;
-                        atomicAdd(&hist[min((uint32_t)(fmaxf(v - hlo, 0.0f) * hscale), 255u)], 1u);
-                    }
-                };
-                for (uint32_t ri = (uint32_t)tid; ri < nrows; ri += kCoopThreads) {
-                    const int zz = z0 + (int)(ri / (uint32_t)ny), yy = y0 + (int)(ri % (uint32_t)ny);
-                    const float gy = g.clamped ? axis_gap_n<true>(q.y, g.miny, g.h, yy, g.gy - 1) : axis_gap_n<false>(q.y, g.miny, g.h, yy, g.gy - 1);
-                    const float gz = g.clamped ? axis_gap_n<true>(q.z, g.minz, g.h, zz, g.gz - 1) : axis_gap_n<false>(q.z, g.minz, g.h, zz, g.gz - 1);
-                    const float rg = gy * gy + gz * gz;
-                    if (rg > lim) continue;
-                    const float rx = sqrtf(fmaxf(lim - rg, 0.0f)) * 1.0001f + 4e-3f * g.h;
-                    const int xa = (int)fminf(fmaxf((q.x - rx - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
-                    const int xb = (int)fmaxf(fminf((q.x + rx - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
-                    if (xa > xb) continue;
-                    const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
-                    const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
-                    for (uint32_t j = s; j < e; j += 4) {          // (reads past the span stay inside the padded array)
-                        const float4 c0 = gv.pts[j], c1 = gv.pts[j + 1], c2 = gv.pts[j + 2], c3 = gv.pts[j + 3];
-                        take(j, c0);
-                        if (j + 1 < e) take(j + 1, c1);
-                        if (j + 2 < e) take(j + 2, c2);
-                        if (j + 3 < e) take(j + 3, c3);
-                    }
-                }
-                __syncthreads();
-                total = cnt_s;
-                if (total > (uint32_t)CAPB) {
-                    // too many for the buffer: cut the ball at the histogram bin in which the count reaches K1 (everything binned at
-                    // or below it lies within the bin's upper edge: the new ball still holds >= K1 records, and ~1/256 of the excess)
-                    if (tid == 0) {
-                        uint32_t cum = 0; int b = 0;
-                        for (; b < 255; ++b) { cum += hist[b]; if (cum >= K1) break; }
-                        bin_s = b;
-                    }
-                    __syncthreads();
-                    const int mybin = bin_s;
-                    const float width = (lim - hlo) / 256.0f;
-                    const float new_lim = fminf((hlo + (float)(mybin + 1) * width) * 1.00001f + 1e-37f, lim);
-                    const float new_lo = fmaxf(hlo + (float)mybin * width * 0.99999f - 1e-37f, lo2);
-                    const bool stuck = !(new_lim < lim) && !(new_lo > lo2);
-                    __syncthreads();
-                    if (stuck) break;                                       // a plateau of ties wider than the buffer
-                    lo2 = (mybin > 0) ? new_lo : fmaxf(lo2, fminf(hlo, new_lim) * 0.99999f);
-                    r = sqrtf(new_lim) * 1.000001f;
-                    continue;
-                }
-                __syncthreads();
-                if (total >= K1 || total >= nfin || r >= r_all) break;
-                lo2 = lim * 0.99999f;                    // too few: grow towards the expected count (at most 2x per step), and at least to the box
-                float rn = r * fminf(2.0f, fmaxf(1.26f, cbrtf(1.5f * (float)K1 / (float)max(total, 1u))));
-                if (r < r_box) rn = fmaxf(rn, r_box);
-                r = fminf(rn, r_all);
-            }
-            // (total > CAPB here only for a tie plateau wider than the buffer: the launch code sizes CAPB >= 2 (k + 1), such a cloud
-            // holds thousands of points at exactly the same distance: not reachable with distinct points)
-            total = min(total, (uint32_t)CAPB);
-            // bitonic sort of the first n2 = 2^m >= total entries (padding: all ones)
-            uint32_t n2 = 2 * kCoopThreads;
-            while (n2 < total) n2 <<= 1;
-            for (uint32_t i = total + tid; i < n2; i += kCoopThreads) buf[i] = ~0ull;
             if (tid == 0) self_s = -1;
-            __syncthreads();
-            for (uint32_t kk = 2; kk <= n2; kk <<= 1) {
-                for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
-                    for (uint32_t t = (uint32_t)tid; t < (n2 >> 1); t += kCoopThreads) {
-                        const uint32_t i = 2 * t - (t & (jj - 1));          // the lower index of pair t at distance jj
-                        const uint32_t l = i + jj;
-                        const unsigned long long a = buf[i], b = buf[l];
-                        const bool up = (i & kk) == 0;
-                        if ((a > b) == up) { buf[i] = b; buf[l] = a; }
-                    }
-                    __syncthreads();
-                }
-            }
+            const uint32_t total = coop_nearest<CAPB>(gv, q.x, q.y, q.z, K1, nfin, sh);
             const uint32_t cnt = min(K1, total);        // the k + 1 nearest (fewer: the whole cloud)
             // their coordinates, parked in LDS by all lanes
             for (uint32_t r2 = (uint32_t)tid; r2 < cnt; r2 += kCoopThreads) {
-                const uint32_t j = (uint32_t)buf[r2];
+                const uint32_t j = (uint32_t)sh.buf[r2];
                 const float4 c = gv.pts[j];
                 nbx[r2] = c.x; nby[r2] = c.y; nbz[r2] = c.z;
                 if (j == p) self_s = (int)r2;
             }
             __syncthreads();
             const int self_r = self_s;
-            vor_w = 0.25f * 0.9999f * (cnt >= 2 ? __uint_as_float((uint32_t)(buf[1] >> 32)) : INFINITY);
+            vor_w = 0.25f * 0.9999f * (cnt >= 2 ? __uint_as_float((uint32_t)(sh.buf[1] >> 32)) : INFINITY);
             if (tid == 0) {
                 // normals.rs:147-153: drop self from the k + 1 list (or the last entry when self is not in it); self appended last
                 const int drop_r = (self_r >= 0) ? self_r : (int)cnt - 1;
@@ -1136,6 +1154,43 @@ __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv,
                 o[0] = px; o[1] = py; o[2] = pz; o[3] = nrm_x; o[4] = nrm_y; o[5] = nrm_z;
             }
         }
+        __syncthreads();
+    }
+}
+
+// NearestNeighborSearch::find_k_nearest beyond the register list's 129 entries (k up to 2048): a block per query, the same
+// selection; output like knn_kernel: (original index, sqrt(d2)) ascending, count = the entries within radius_sq
+template <int CAPB>
+__global__ void __launch_bounds__(kCoopThreads) knn_coop_kernel(GridView gv, const float *__restrict__ queries, uint32_t nq, uint32_t k,
+                                                                uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
+                                                                uint32_t *__restrict__ out_count, float radius_sq) {
+    __shared__ CoopShared<CAPB> sh;
+    __shared__ uint32_t within_s;
+    const GridGeom &g = gv.g;
+    const int tid = threadIdx.x;
+    const uint32_t nfin = gv.cell_start[g.ncell];
+    for (uint32_t t = blockIdx.x; t < nq; t += gridDim.x) {
+        const float qx = queries[3 * (size_t)t], qy = queries[3 * (size_t)t + 1], qz = queries[3 * (size_t)t + 2];
+        const uint32_t K1 = min(k, nfin);
+        // a NaN / infinite query has no finite distance to anything: no neighbours (see knn_kernel)
+        if (!(fabsf(qx) <= 3.0e38f && fabsf(qy) <= 3.0e38f && fabsf(qz) <= 3.0e38f) || K1 == 0) {
+            if (tid == 0) out_count[t] = 0;
+            continue;
+        }
+        if (tid == 0) within_s = 0;
+        const uint32_t total = coop_nearest<CAPB>(gv, qx, qy, qz, K1, nfin, sh);
+        const uint32_t cnt = min(K1, total);
+        uint32_t within = 0;
+        for (uint32_t r = (uint32_t)tid; r < cnt; r += kCoopThreads) {
+            const unsigned long long key = sh.buf[r];
+            const float v = __uint_as_float((uint32_t)(key >> 32));
+            out_idx[(size_t)t * k + r] = __float_as_uint(gv.pts[(uint32_t)key].w);
+            out_dist[(size_t)t * k + r] = sqrtf(v);                                   // nearest_neighbor.rs:249
+            within += (v <= radius_sq) ? 1u : 0u;
+        }
+        if (within) atomicAdd(&within_s, within);
+        __syncthreads();
+        if (tid == 0) out_count[t] = within_s;
         __syncthreads();
     }
 }
@@ -1322,10 +1377,17 @@ tc_status launch_radius_all(tc_context *ctx, const DeviceIndex &ix, const float 
 
 tc_status launch_knn(tc_context *ctx, const DeviceIndex &ix, const float *d_queries, size_t nq, size_t k,
                      uint32_t *d_idx, float *d_dist, uint32_t *d_count, float radius_sq) {
-    if (k > 129) return fail(ctx, TC_UNSUPPORTED, "k > 129 is not supported by the HIP k-NN export");
+    if (k > 2048) return fail(ctx, TC_UNSUPPORTED, "k > 2048 is not supported by the HIP k-NN export");
     const GridView gv = view_of(ix);
     ProfScope ps(ctx, "knn_batch");
     hipStream_t st = ctx->stream;
+    if (k > 129) {          // beyond the register list: a block per query (knn_coop_kernel)
+        const dim3 grid((unsigned)std::min<size_t>(nq, 1u << 16)), block(kCoopThreads);
+        if (k <= 256) hipLaunchKernelGGL(knn_coop_kernel<512>, grid, block, 0, st, gv, d_queries, (uint32_t)nq, (uint32_t)k, d_idx, d_dist, d_count, radius_sq);
+        else hipLaunchKernelGGL(knn_coop_kernel<4096>, grid, block, 0, st, gv, d_queries, (uint32_t)nq, (uint32_t)k, d_idx, d_dist, d_count, radius_sq);
+        TC_HIP_TRY(ctx, hipGetLastError());
+        return TC_OK;
+    }
 #define TC_KNN(LL, BB)                                                                                                          \
     do {                                                                                                                        \
         if (gv.g.clamped) hipLaunchKernelGGL((knn_kernel<LL, BB, true>), dim3((unsigned)((nq + BB - 1) / BB)), dim3(BB), 0, st, gv, \
