@@ -285,10 +285,14 @@ def icp_point_to_plane(src, tgt, tgt_normals, init, max_iters, threads=0):
 
 
 def gicp(src, tgt, init=None, max_iterations=50, max_correspondence_distance=1.0, convergence_threshold=1e-6,
-         k_correspondences=20, threads=0):
-    """gicp.rs:100-305 (GicpConfig defaults :31-40)"""
-    return _icp_common(lib().tco_gicp, src, tgt, (), init, max_iterations,
-                       (C.c_float(max_correspondence_distance), C.c_float(convergence_threshold), C.c_size_t(k_correspondences)), threads)
+         k_correspondences=20, threads=0, exact_sums=False):
+    """gicp.rs:100-305 (GicpConfig defaults :31-40).  exact_sums (diagnostic): the Gauss-Newton system's f32 terms added in f64."""
+    lib().tco_set_exact_sums(1 if exact_sums else 0)
+    try:
+        return _icp_common(lib().tco_gicp, src, tgt, (), init, max_iterations,
+                           (C.c_float(max_correspondence_distance), C.c_float(convergence_threshold), C.c_size_t(k_correspondences)), threads)
+    finally:
+        lib().tco_set_exact_sums(0)
 
 
 def gicp_covariances(points, k=20, threads=0):

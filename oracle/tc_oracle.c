@@ -1703,6 +1703,8 @@ int tco_gicp(const float *src, size_t ns, const float *tgt, size_t nt, const flo
         }
         float H[36]; float g[6];
         memset(H, 0, sizeof(H)); memset(g, 0, sizeof(g));
+        double dH[36], dg[6], dmse = 0.0;            /* diagnostic (tco_set_exact_sums): the same f32 terms, added in f64 */
+        memset(dH, 0, sizeof(dH)); memset(dg, 0, sizeof(dg));
         size_t n_corr = 0; float mse_sum = 0.0f;
         for (size_t j = 0; j < ns; ++j) {
             if (ti[j] == UINT64_MAX) continue;
@@ -1726,13 +1728,25 @@ int tco_gicp(const float *src, size_t ns, const float *tgt, size_t nt, const flo
                     H[6 * i + jj + 3] += hrt[3 * i + jj];
                     H[6 * (i + 3) + jj] += hrt[3 * jj + i];
                     H[6 * (i + 3) + jj + 3] += Mi[3 * i + jj];
+                    dH[6 * i + jj] += (double)hrr[3 * i + jj];
+                    dH[6 * i + jj + 3] += (double)hrt[3 * i + jj];
+                    dH[6 * (i + 3) + jj] += (double)hrt[3 * jj + i];
+                    dH[6 * (i + 3) + jj + 3] += (double)Mi[3 * i + jj];
                 }
                 g[i] += gr[i];
                 g[i + 3] += wr[i];
+                dg[i] += (double)gr[i];
+                dg[i + 3] += (double)wr[i];
             }
             pcs[n_corr] = j; pct[n_corr] = ti[j];
             n_corr += 1;
             mse_sum += td[j] * td[j];
+            dmse += (double)(td[j] * td[j]);
+        }
+        if (g_exact_sums) {
+            for (int e = 0; e < 36; ++e) H[e] = (float)dH[e];
+            for (int e = 0; e < 6; ++e) g[e] = (float)dg[e];
+            mse_sum = (float)dmse;
         }
         if (n_corr < 6) { rc = TCO_ALGORITHM; break; }                        /* :253-257 */
         float mse = mse_sum / (float)n_corr;

@@ -114,6 +114,25 @@ def correspondence_report(src, tgt, T, g_corr, r_corr):
     return int(len(diff))
 
 
+def transform_budget(g_T, run_ref, run_exact, tol, scale=1.0):
+    """The transform of a run against the oracle's: within `tol` x `scale` (north_star's 1e-5 Frobenius is stated for clouds of unit
+    extent; one ulp of a translation at coordinates of 50 is already 4e-6) -- or, SHOWN not assumed, the reference's sequential f32
+    sums are the noisy side: within the budget of the oracle run with the SAME f32 terms added in f64 (`exact_sums`), and no farther
+    from the reference than the reference is from those.  -> dict for a report; raises AssertionError otherwise."""
+    M = lambda T: O.isometry_to_matrix(np.asarray(T, np.float32)).astype(np.float64)
+    r = run_ref()
+    fro = float(np.linalg.norm(M(g_T) - M(r.transformation)))
+    out = {"frobenius_vs_oracle": fro}
+    if fro <= tol * scale:
+        return out
+    e = run_exact()
+    out["frobenius_vs_exact_sums"] = float(np.linalg.norm(M(g_T) - M(e.transformation)))
+    out["reference_accumulation_error"] = float(np.linalg.norm(M(r.transformation) - M(e.transformation)))
+    assert out["frobenius_vs_exact_sums"] <= tol * scale, out
+    assert fro <= out["reference_accumulation_error"] + tol * scale, out
+    return out
+
+
 def reference_order_noise(run, src, seeds=(1, 2, 3)):
     """max Frobenius distance between the oracle's transform on `src` and on the same points in a permuted order:
     what the reference's sequential f32 sums (registration.rs:154-172 / :409-428) make of the SAME input."""
