@@ -166,3 +166,25 @@ def test_frame_stream_with_the_reference_default_k(ctx):
         p = ctx.icp_point_to_plane_detailed(cur, prev, nrm, None, 30, 2.0, 1e-6, correspondences=False)
         assert _frob(p.transformation, res[i - 1].transformation) <= 1e-5 and abs(p.iterations - res[i - 1].iterations) <= 1
         prev = cur
+
+
+def test_context_trim_releases_the_parked_blocks(ctx):
+    """tc_context_trim: destroyed handles park their device blocks in the context (a handle per frame costs no
+    hipMalloc); trim hands them back -- the free device memory grows by what was parked, and the context keeps working."""
+    pts = synth.uniform_cloud(400_000, seed=3)
+    d = torch.from_numpy(pts).cuda()
+    ref = None
+    for _ in range(3):
+        h = tc.Cloud(ctx, d)
+        got = h.estimate_normals(16)
+        h.close()
+        ref = got if ref is None else ref
+        assert torch.equal(got, ref)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    ctx.trim()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 >= free0 + 8 * len(pts)          # at least the records / normals blocks of one handle came back
+    h = tc.Cloud(ctx, d)
+    assert torch.equal(h.estimate_normals(16), ref)
+    h.close()
