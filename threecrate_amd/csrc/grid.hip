@@ -174,46 +174,19 @@ __global__ void __launch_bounds__(kScanBlock) scan_reduce_kernel(const uint32_t 
     }
 }
 
-// single block: in-place exclusive scan of blocksum[0..nb)
-__global__ void __launch_bounds__(1024) scan_top_kernel(uint32_t *__restrict__ blocksum, uint32_t nb) {
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t carry_s, nz_s;
-    if (threadIdx.x == 0) { carry_s = 0; nz_s = 0; }
-    __syncthreads();
-    {   // total of the non-zero counts -> blocksum[2 * nb]
-        uint32_t nz = 0;
-        for (uint32_t i = threadIdx.x; i < nb; i += 1024) nz += blocksum[nb + i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nz += __shfl_xor(nz, o);
-        if ((threadIdx.x & 63) == 0 && nz) atomicAdd(&nz_s, nz);
-        __syncthreads();
-        if (threadIdx.x == 0) blocksum[2 * nb] = nz_s;
-    }
-    for (uint32_t base = 0; base < nb; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = (i < nb) ? blocksum[i] : 0;
-        uint32_t inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t t = __shfl_up(inc, o);
-            if ((threadIdx.x & 63) >= (unsigned)o) inc += t;
-        }
-        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
-        uint32_t carry = carry_s;
-        if (i < nb) blocksum[i] = carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
-        __syncthreads();
-    }
-}
-
+// (the exclusive scan of the block sums used to be a launch of its own, ~4.6 us of a 16 us scan: every apply block now adds up
+// the sums in front of it itself -- a few hundred values --, block 0 also the non-zero counts -> blocksum[2 * nb])
 __global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t n,
-                                                                const uint32_t *__restrict__ blocksum,
+                                                                uint32_t *__restrict__ blocksum,
                                                                 uint32_t *__restrict__ out /* n+1 */) {
     __shared__ uint32_t wtot[kScanBlock / 64];
+    __shared__ uint32_t wpre[kScanBlock / 64], wnz[kScanBlock / 64];
+    uint32_t pre = 0, nzt = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kScanBlock) pre += blocksum[i];
+    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < gridDim.x; i += kScanBlock) nzt += blocksum[gridDim.x + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o); nzt += __shfl_xor(nzt, o); }
+    if ((threadIdx.x & 63) == 0) { wpre[threadIdx.x >> 6] = pre; wnz[threadIdx.x >> 6] = nzt; }
     // thread owns kScanItems CONSECUTIVE items so the in-thread prefix is sequential
     uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     uint32_t v[kScanItems];
@@ -234,7 +207,14 @@ __global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *
     __syncthreads();
     uint32_t woff = 0;
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wtot[w];
-    uint32_t run = blocksum[blockIdx.x] + woff + inc - s;
+    uint32_t block_pre = 0;
+    for (int w = 0; w < kScanBlock / 64; ++w) block_pre += wpre[w];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kScanBlock / 64; ++w) t += wnz[w];
+        blocksum[2 * gridDim.x] = t;
+    }
+    uint32_t run = block_pre + woff + inc - s;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         uint32_t i = base + k;
@@ -402,8 +382,7 @@ tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, 
     const uint32_t nscan = (n + kScanTile - 1) / kScanTile;
     if (tc_status s = ensure(ctx, blocksum, ((size_t)2 * nscan + 1) * sizeof(uint32_t))) return s;   // sums | non-zero counts | their total
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, (uint32_t *)blocksum.p, nscan);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (const uint32_t *)blocksum.p, d_out);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p, d_out);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
 }
