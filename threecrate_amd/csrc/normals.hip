@@ -47,7 +47,7 @@ struct NormalParams {
     float4 *vor_out;        // optional: {x, y, z, inscribed-ball bound} per position (icp.hip: the bound is a quarter of the squared
                             // distance to the nearest OTHER record = the second entry of the k-NN list, for free here)
     uint32_t *hard_list;        // optional: positions whose search would outgrow kHardRing rings are appended here (hard_list[0] = count,
-                                // entries from [1]) and served by normals_coop_kernel, one wave per point
+                                // [1] = the serving kernel's exit ticket, entries from [2]) and served by normals_coop_kernel, a block per point
     uint32_t p_begin, p_end;    // cell-sorted positions handled by this launch (a multi-GPU shard: SURVEY 8e)
     int      slice_out;         // 1: record of position p goes to row p - p_begin (sorted order) instead of its original index
 #ifdef TC_PHASE_STAMPS
@@ -797,7 +797,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         // An isolated point (a far outlier: its neighbours are a hundred extents away; a point in an empty region) would walk
         // thousands of rows -- the whole grid -- through ONE lane: handed to normals_coop_kernel instead, a wave per point.
         if (!RADIUS && prm.hard_list != nullptr && R > kHardRing) {
-            prm.hard_list[1u + atomicAdd(&prm.hard_list[0], 1u)] = p;
+            prm.hard_list[2u + atomicAdd(&prm.hard_list[0], 1u)] = p;
             return;
         }
         // one call site for both cases (lanes of a wave differ): only the growing lanes refresh their limit
@@ -1073,7 +1073,7 @@ __device__ __forceinline__ uint32_t coop_nearest(const GridView &gv, float qx, f
 }
 
 template <int CAPB>
-__global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv, NormalParams prm, float *__restrict__ out6, const uint32_t *__restrict__ hard) {
+__global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv, NormalParams prm, float *__restrict__ out6, uint32_t *__restrict__ hard) {
     __shared__ CoopShared<CAPB> sh;
     __shared__ float nbx[CAPB / 2], nby[CAPB / 2], nbz[CAPB / 2];
     __shared__ int self_s;
@@ -1082,7 +1082,7 @@ __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv,
     const uint32_t count = hard ? hard[0] : prm.p_end - prm.p_begin;
     const uint32_t nfin = gv.cell_start[g.ncell];
     for (uint32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const uint32_t p = hard ? hard[1u + idx] : prm.p_begin + idx;
+        const uint32_t p = hard ? hard[2u + idx] : prm.p_begin + idx;
         const float4 q = gv.pts[p];
         const uint32_t orig = __float_as_uint(q.w);
         float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
@@ -1156,6 +1156,9 @@ __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv,
         }
         __syncthreads();
     }
+    // the list is left empty for the next normals launch by the LAST block to leave (every block has read the count by then): no
+    // memset launch per call
+    if (hard && tid == 0 && atomicAdd(&hard[1], 1u) == gridDim.x - 1u) { hard[0] = 0u; hard[1] = 0u; }
 }
 
 // NearestNeighborSearch::find_k_nearest beyond the register list's 129 entries (k up to 2048): a block per query, the same
@@ -1475,23 +1478,25 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
         if (npts == 0) return TC_OK;
         ProfScope ps(ctx, "normals_coop");
         const dim3 grid(std::min<uint32_t>(npts, 1u << 16)), block(kCoopThreads);
-        if (K1 <= 256) hipLaunchKernelGGL(normals_coop_kernel<512>, grid, block, 0, ctx->stream, gv, prm, d_out6, (const uint32_t *)nullptr);
-        else hipLaunchKernelGGL(normals_coop_kernel<4096>, grid, block, 0, ctx->stream, gv, prm, d_out6, (const uint32_t *)nullptr);
+        if (K1 <= 256) hipLaunchKernelGGL(normals_coop_kernel<512>, grid, block, 0, ctx->stream, gv, prm, d_out6, (uint32_t *)nullptr);
+        else hipLaunchKernelGGL(normals_coop_kernel<4096>, grid, block, 0, ctx->stream, gv, prm, d_out6, (uint32_t *)nullptr);
         TC_HIP_TRY(ctx, hipGetLastError());
         return TC_OK;
     }
     // hard points (isolated: their search would walk the grid through one lane) are listed by the main launch and served by the
     // wave-per-point kernel behind it (k-NN mode)
     if (!radius_mode && prm.p_end > prm.p_begin) {
-        if (tc_status s = ensure(ctx, ctx->normals_hard, ((size_t)(prm.p_end - prm.p_begin) + 1) * sizeof(uint32_t))) return s;
+        const void *before = ctx->normals_hard.p;
+        if (tc_status s = ensure(ctx, ctx->normals_hard, ((size_t)(prm.p_end - prm.p_begin) + 2) * sizeof(uint32_t))) return s;
         prm.hard_list = (uint32_t *)ctx->normals_hard.p;
-        TC_HIP_TRY(ctx, hipMemsetAsync(prm.hard_list, 0, sizeof(uint32_t), ctx->stream));
+        // (count and exit ticket are zeroed when the buffer is new; afterwards the serving kernel leaves them zero)
+        if (ctx->normals_hard.p != before) TC_HIP_TRY(ctx, hipMemsetAsync(prm.hard_list, 0, 2 * sizeof(uint32_t), ctx->stream));
     }
     struct HardPass {
         tc_context *ctx; const GridView &gv; NormalParams &prm; float *out6;
         ~HardPass() {
             if (!prm.hard_list) return;
-            const uint32_t *hl = prm.hard_list;
+            uint32_t *hl = prm.hard_list;
             NormalParams p2 = prm;
             p2.hard_list = nullptr;
             ProfScope ps(ctx, "normals_coop");
