@@ -151,6 +151,7 @@ struct tc_context {
     hipStream_t copy_stream = nullptr;
     hipEvent_t upload_event = nullptr;
     bool upload_pending = false;
+    bool upload_used_copy_stream = false;   // some upload of the current call went to the copy stream (small ones do not)
 
     // persistent (grow-only) device buffers, reused across calls
     tc::DeviceIndex tgt_index;      // target / normals cloud
