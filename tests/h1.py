@@ -55,7 +55,7 @@ def normals_report(pts, k, gpu6, ref6, tol=1e-4, max_offenders=200):
         entry = {"point": int(i), "one_minus_abs_cos": float(1.0 - c[i]), "boundary_tie": tie, "d2_k": float(d2[min(k, len(d2) - 1)]),
                  "d2_k_plus_1": float(d2[min(k + 1, len(d2) - 1)]), "rel_eigen_gap": gap}
         if not (tie or gap < EIGEN_GAP_BOUND):
-            entry["reference_solver_discontinuous"] = reference_solver_spread(pts[first]) > tol
+            entry["reference_solver_discontinuous"] = reference_solver_spread(pts[first], query=pts[i]) > tol
         rep["offenders"].append(entry)
         assert tie or gap < EIGEN_GAP_BOUND or entry["reference_solver_discontinuous"], f"unexplained normal mismatch: {entry}"
     return rep
@@ -70,14 +70,29 @@ def reference_normal_of_cov(cov9):
     return q[:, m].astype(np.float64)
 
 
-def reference_solver_spread(nb_pts, trials=None, seed=0):
+def reference_solver_spread(nb_pts, trials=None, seed=0, query=None):
     """1 - |cos| spread of the reference's normal over rounding-level variants of ONE neighbourhood's covariance: the f32
     covariance in the order given (normals.rs:164-177), in permuted orders (tied neighbours have no defined order), and with
-    entries moved by an ulp."""
+    entries moved by an ulp.  With `query` (the point the neighbourhood belongs to) the neighbours at EXACTLY equal distance
+    are found and half of the permuted orders only reorder inside those groups -- the orders an implementation may legally
+    produce (the kd-tree's heap and the grid's position order differ there); such neighbourhoods (lattices) are sampled
+    densely: the orders at which the reference's eigen-solver flips can be a few per cent of all orders (fuzz seed 112 case
+    5754: a 17-point cross on a lattice, tie groups of 5 / 4 / 7, the solver pairs the smallest eigenvalue with the other
+    eigenvector of a 2 x 2 block whose diagonal entries agree to 1e-7 relative)."""
     rng = np.random.default_rng(seed)
     P = np.asarray(nb_pts, np.float32)
+    groups = []
+    if query is not None:
+        d2 = d2_f32(P, np.asarray(query, np.float32))
+        for v in np.unique(d2):
+            g = np.nonzero(d2 == v)[0]
+            if len(g) > 1: groups.append(g)
     if trials is None:          # (the bad summation orders can be a few per cent of all orders: sample small neighbourhoods densely)
-        trials = 240 if len(P) <= 12 else 96
+        trials = 600 if groups else (240 if len(P) <= 12 else 96)
+    def tie_permuted():
+        idx = np.arange(len(P))
+        for g in groups: idx[g] = g[rng.permutation(len(g))]
+        return idx
     def cov_of(Q):
         n = np.float32(len(Q))
         cen = np.zeros(3, np.float32)
@@ -90,7 +105,8 @@ def reference_solver_spread(nb_pts, trials=None, seed=0):
         return (C / n).astype(np.float32)
     normals = [reference_normal_of_cov(cov_of(P))]
     for t in range(trials):
-        C = cov_of(P[rng.permutation(len(P))]) if t % 2 == 0 else cov_of(P)
+        if t % 2 == 0: C = cov_of(P[tie_permuted()] if (groups and t % 8 != 0) else P[rng.permutation(len(P))])
+        else: C = cov_of(P)
         if t % 4 >= 2:
             C = (C * (1.0 + rng.choice([-1.0, 0.0, 1.0], (3, 3)) * np.float32(1.2e-7))).astype(np.float32)
             C = ((C + C.T) / 2).astype(np.float32)

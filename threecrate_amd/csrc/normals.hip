@@ -402,7 +402,7 @@ __device__ __forceinline__ float axis_gap_n(float q, float mn, float h, int c, i
 // with an infinite limit starts pruning as soon as the list is full).
 template <bool EXT, bool LIVE = false, typename F>
 __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q, int cx, int cy, int cz, int Rin, int R,
-                                            float lim, F &&f, const float *live = nullptr) {
+                                            float lim, F &&f, const float *live = nullptr, uint32_t *rowtag = nullptr) {
     const GridGeom &g = gv.g;
     const int x0 = max(cx - R, 0), x1 = min(cx + R, g.gx - 1);
     const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
@@ -429,6 +429,7 @@ __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q,
             }
             if (xa > xb) continue;
             const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
+            if (rowtag) *rowtag = (uint32_t)((((z - cz + 3) & 7) << 3) | ((y - cy + 3) & 7)) << 6;     // knn_tagged: the row's code (|dz|, |dy| <= 3 there)
             auto span = [&](int a, int b) {
                 if (a > b) return;
                 touched = true;
@@ -646,6 +647,181 @@ __device__ __forceinline__ bool knn_survivors(const GridView &gv, const NormalPa
 #undef TC_LOAD4
 }
 
+// ---- tagged-key k-NN (round 3): the neighbour's position rides in the low bits of its list key -----------------------------
+// The register-list path scans the neighbourhood twice: once for the sorted distances, once more to find WHICH records they
+// were (the collect pass: 41 % of a wave's time at k = 16).  Here the list holds 32-bit keys = squared-distance bits with the low
+// 12 mantissa bits replaced by a tag: 6 bits row code ((dz + 3) << 3 | (dy + 3): rings <= 3) and the record's position modulo 64.
+// Positive floats order like unsigned integers, so the list is a v_med3_u32 chain; the keys' order is the order of the distances
+// truncated to 11 mantissa bits.  After the scan a key names its record: the row from the code, the position = the one in the
+// row's 7-cell window that is congruent to the tag (windows of more than 64 records: fallback); the exact distances are computed
+// again from the records (19 gathers instead of a second scan), entries whose truncated distances collide are put in exact
+// (distance, position) order by counting inversions among neighbours within three places (runs of more than four equal truncated
+// values: fallback), and the list is PROVEN to hold the k + 1 nearest: every record that is not in it has a truncated distance
+// >= the last key's, so it suffices that the exact (k + 1)-th distance lies below the last key's truncated value -- with two
+// spare entries (L = k + 3) that fails for ~1e-4 of the points (three consecutive order statistics within 5e-4 relative).
+// Exactness rule and ring-3 continuation as in the register-list path, judged against the truncation's upper bound.  A lane that
+// fails any check returns false and runs the register-list path: same bits either way.
+constexpr uint32_t kTagMask = 0xFFFu, kKeyInf = 0x7f800000u;
+
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {          // -> v_med3_u32
+    const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+    const uint32_t t = mx < c ? mx : c;
+    return mn > t ? mn : t;
+}
+template <int L>
+__device__ __forceinline__ void list_insert_u(uint32_t (&d)[L], uint32_t v) {
+#pragma unroll
+    for (int t = L - 1; t >= 1; --t) d[t] = umed3(d[t - 1], v, d[t]);
+    d[0] = d[0] < v ? d[0] : v;
+}
+
+template <int L, int BLOCK, bool EXT>
+__device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParams &prm, uint32_t p, const float4 &q, int cx, int cy, int cz,
+                                           float mf, uint32_t *ldsA, uint8_t *ldsB, uint32_t &cnt, int &self_r, float &d1_out) {
+    const GridGeom &g = gv.g;
+    const uint32_t K1 = prm.k + 1;               // <= L - 2 (launch_normals)
+    uint32_t d[L];
+#pragma unroll
+    for (int t = 0; t < L; ++t) d[t] = kKeyInf;
+    auto lim_of = [](uint32_t key) { return __uint_as_float(key < kKeyInf ? key : kKeyInf); };     // a key read as a float bounds its distance from below within 5e-4
+    auto visit = [&](uint32_t j, const float4 &c, uint32_t rowtag) {
+        const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
+        list_insert_u<L>(d, (__float_as_uint(v) & ~kTagMask) | rowtag | (j & 63u));
+    };
+    int R = 2;
+    {
+        // the ring-2 block centre-out, pruned against the list's last key as soon as the list is full (normals_point's list pass)
+        float live0 = INFINITY;
+        for (int iz = 0; iz < 5; ++iz) {
+            const int mz = (iz + 1) >> 1, dz = (iz & 1) ? -mz : mz, z = cz + dz;
+            if (z < 0 || z >= g.gz) continue;
+            const float gzv = axis_gap_n<EXT>(q.z, g.minz, g.h, z, g.gz - 1);
+            for (int iy = 0; iy < 5; ++iy) {
+                const int my = (iy + 1) >> 1, dy = (iy & 1) ? -my : my, y = cy + dy;
+                if (y < 0 || y >= g.gy) continue;
+                const float gyv = axis_gap_n<EXT>(q.y, g.miny, g.h, y, g.gy - 1);
+                const float rg = gyv * gyv + gzv * gzv;
+                if (rg > live0) continue;
+                int xa = max(cx - 2, 0), xb = min(cx + 2, g.gx - 1);
+                const float r = TC_FAST_SQRT(fmaxf(live0 - rg, 0.0f)) + 4e-3f * g.h;
+                const float fa = fminf(fmaxf((q.x - r - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
+                const float fb = fmaxf(fminf((q.x + r - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
+                xa = max(xa, (int)fa);
+                xb = min(xb, (int)fb);
+                if (xa > xb) continue;
+                const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
+                const uint32_t rowtag = (uint32_t)(((dz + 3) << 3) | (dy + 3)) << 6;
+                const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
+                for (uint32_t j = s; j < e; j += 4) {
+                    const float4 c0 = gv.pts[j], c1 = gv.pts[j + 1], c2 = gv.pts[j + 2], c3 = gv.pts[j + 3];
+                    visit(j, c0, rowtag);
+                    if (j + 1 < e) visit(j + 1, c1, rowtag);
+                    if (j + 2 < e) visit(j + 2, c2, rowtag);
+                    if (j + 3 < e) visit(j + 3, c3, rowtag);
+                }
+                live0 = lim_of(d[L - 1]);
+            }
+        }
+    }
+    for (;;) {
+        uint32_t kk = d[0];
+#pragma unroll
+        for (int t = 1; t < L; ++t) kk = ((uint32_t)t == prm.k) ? d[t] : kk;
+        const float tau = kk >= kKeyInf ? INFINITY : __uint_as_float(kk | kTagMask);        // >= the exact (k+1)-th distance
+        const bool covers = (cx - R <= 0) && (cx + R >= g.gx - 1) && (cy - R <= 0) && (cy + R >= g.gy - 1) &&
+                            (cz - R <= 0) && (cz + R >= g.gz - 1);
+        const float bound = ((float)R + mf - 2e-3f) * g.h;
+        if (covers || tau <= bound * bound) break;
+        if (R >= 3) { TC_NSTAT(2, 1); return false; }         // the row code covers rings <= 3
+        if (tau != INFINITY && (int)fminf(ceilf(sqrtf(tau) * g.inv_h - mf + 0.01f), 1.0e9f) > 3) { TC_NSTAT(2, 1); return false; }
+        const bool growing = tau == INFINITY;
+        R = 3;
+        float live_lim = tau;
+        uint32_t rowtag = 0;
+        const bool touched = scan_pruned<EXT, true>(gv, q, cx, cy, cz, 2, 3, live_lim, [&](uint32_t j, const float4 &c) {
+            visit(j, c, rowtag);
+            if (growing) live_lim = lim_of(d[L - 1]);
+        }, &live_lim, &rowtag);
+        if (!touched) break;
+    }
+    // ---- the keys name their records ----
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t + 4 < L; ++t) bad |= d[t + 4] < kKeyInf && (d[t] & ~kTagMask) == (d[t + 4] & ~kTagMask);      // five equal truncated distances
+    const uint32_t last_floor = d[L - 1] & ~kTagMask;
+    const bool full = d[L - 1] < kKeyInf;
+    uint32_t nv = 0;
+#pragma unroll
+    for (int t = 0; t < L; ++t) { ldsA[t * BLOCK] = d[t]; nv += d[t] < kKeyInf ? 1u : 0u; }
+    cnt = min(K1, nv);
+    const int x0 = max(cx - 3, 0), x1 = min(cx + 3, g.gx - 1);
+    // The list leaves the registers (a decode step unrolled over all L entries keeps every gather in flight: 191 VGPRs): the keys
+    // are parked in ldsA, a rolled loop takes them four at a time -- key -> row window -> position -> record -> exact distance,
+    // the position written back over the key -- and the exact (distance, position) order comes out of a sliding window: a key's
+    // place is off by at most three (runs of <= 4 equal truncated distances), so an entry's rank is final once three later
+    // entries have been compared with it.
+    float wv0 = -INFINITY, wv1 = -INFINITY, wv2 = -INFINITY;         // window: 0 = oldest
+    uint32_t wj0 = 0, wj1 = 0, wj2 = 0, wr0 = 0, wr1 = 0, wr2 = 0, wt0 = 0xFFu, wt1 = 0xFFu, wt2 = 0xFFu;
+    float vk = INFINITY, v1 = INFINITY;
+    self_r = -1;
+    auto push = [&](float vn, uint32_t jn, uint32_t tn) {
+        uint32_t rn = tn;
+        const uint32_t c2 = (vn < wv2 || (vn == wv2 && jn < wj2)) ? 1u : 0u;
+        const uint32_t c1 = (vn < wv1 || (vn == wv1 && jn < wj1)) ? 1u : 0u;
+        const uint32_t c0 = (vn < wv0 || (vn == wv0 && jn < wj0)) ? 1u : 0u;
+        rn -= c0 + c1 + c2;
+        wr0 += c0; wr1 += c1; wr2 += c2;
+        if (wt0 != 0xFFu) {                      // the oldest entry's rank is final
+            vk = (wr0 + 1u == K1) ? wv0 : vk;
+            v1 = (wr0 == 1u) ? wv0 : v1;
+            if (wj0 == p && wr0 < cnt) self_r = (int)wr0;
+            ldsB[wr0 * BLOCK] = (uint8_t)wt0;
+        }
+        wv0 = wv1; wj0 = wj1; wr0 = wr1; wt0 = wt1;
+        wv1 = wv2; wj1 = wj2; wr1 = wr2; wt1 = wt2;
+        wv2 = vn; wj2 = jn; wr2 = rn; wt2 = tn;
+    };
+#pragma unroll 1
+    for (int t0 = 0; t0 < L; t0 += 4) {
+        uint32_t key[4], s0[4], e0[4], jx[4];
+        bool valid[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            key[i] = (t0 + i < L) ? ldsA[(t0 + i) * BLOCK] : kKeyInf;
+            valid[i] = key[i] < kKeyInf;
+            const uint32_t tag = key[i] & kTagMask;
+            const int z = valid[i] ? cz + (int)(tag >> 9) - 3 : cz, y = valid[i] ? cy + (int)((tag >> 6) & 7u) - 3 : cy;
+            const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
+            s0[i] = gv.cell_start[row + x0];
+            e0[i] = gv.cell_start[row + x1 + 1];
+        }
+        float4 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bad |= valid[i] && (e0[i] - s0[i] > 64u);
+            const uint32_t j = s0[i] + (((key[i] & 63u) - s0[i]) & 63u);
+            jx[i] = (valid[i] && j < e0[i]) ? j : p;
+            c[i] = gv.pts[jx[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ve = d2_nc(c[i].x, c[i].y, c[i].z, q.x, q.y, q.z);
+            bad |= valid[i] && ((__float_as_uint(ve) & ~kTagMask) != (key[i] & ~kTagMask));
+            if (t0 + i < L) {
+                ldsA[(t0 + i) * BLOCK] = valid[i] ? jx[i] : 0xFFFFFFFFu;
+                push(valid[i] ? ve : INFINITY, valid[i] ? jx[i] : 0xFFFFFFFFu, (uint32_t)(t0 + i));
+            }
+        }
+    }
+    push(INFINITY, 0xFFFFFFFFu, 0xFFu); push(INFINITY, 0xFFFFFFFFu, 0xFFu); push(INFINITY, 0xFFFFFFFFu, 0xFFu);
+    // every record outside the list has a truncated distance >= the last key's
+    if (full) bad |= !(vk < __uint_as_float(last_floor));
+    d1_out = v1;
+    if (bad) TC_NSTAT(3, 1); else TC_NSTAT(1, 1);
+    TC_NSTAT(0, 1);
+    return !bad;
+}
+
 template <int L, int BLOCK, bool RADIUS, bool EXT, int CAP = 0>
 __device__ __forceinline__ void normals_point(const GridView &gv, const NormalParams &prm, uint32_t p,
                                               float *__restrict__ out6, uint32_t *ldsA, uint8_t *ldsB
@@ -712,6 +888,18 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
             for (int t = 0; t < L; ++t) d[t] = INFINITY;
             R = prm.R0;
         }
+    }
+    if constexpr (CAP < 0 && !RADIUS) {
+        // the tagged-key path (knn_tagged): on success ldsA / ldsB hold the k+1 nearest and their ranks, d[1] the distance to the
+        // nearest other record; a lane it cannot serve runs the register-list path below
+        TC_NSTAMP(0);
+        float d1 = INFINITY;
+        have = knn_tagged<L, BLOCK, EXT>(gv, prm, p, q, cx, cy, cz, mf, ldsA, ldsB, cnt, self_r, d1);
+        if (have) d[1] = d1;
+#ifdef TC_NSTATS
+        if ((threadIdx.x & 63) == 0) TC_NSTAT(6, 1);
+        if (__any((int)!have) && (threadIdx.x & 63) == 0) TC_NSTAT(7, 1);
+#endif
     }
     auto visit1 = [&](uint32_t j, const float4 &c) {
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
@@ -1222,6 +1410,24 @@ __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, Nor
 #endif
 }
 
+// the tagged-key instantiation, held to the register-list path's six waves per SIMD (its decode step would otherwise keep all
+// its gathers in flight at once: 191 VGPRs)
+template <int L, int BLOCK, bool EXT>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) normals_tagged_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
+    __shared__ uint32_t ldsA[L * BLOCK];
+    __shared__ uint8_t ldsB[L * BLOCK];
+    const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t p = prm.p_begin + lb * BLOCK + threadIdx.x;
+    if (p >= prm.p_end) return;
+#ifdef TC_PHASE_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+    normals_point<L, BLOCK, false, EXT, -1>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x, ph, tl);
+    if (threadIdx.x == 0 && prm.stamps) for (int i = 0; i < 8; ++i) prm.stamps[8 * (size_t)blockIdx.x + i] = ph[i];
+#else
+    normals_point<L, BLOCK, false, EXT, -1>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+#endif
+}
+
 template <int L, int BLOCK, bool RADIUS = false, int CAP = 0>
 static void launch_variant(hipStream_t st, const GridView &gv, const NormalParams &prm, float *out6, tc_context *ctx) {
     const uint32_t n = prm.p_end - prm.p_begin;
@@ -1230,8 +1436,13 @@ static void launch_variant(hipStream_t st, const GridView &gv, const NormalParam
     nb = (nb + 7) / 8 * 8;   // xcd_remap needs a multiple of 8
     ProfScope ps(ctx, "normals_knn_pca");
     // two instantiations: with a clamped box the boundary cells are open on the outer side (costs 4 % on the gap tests)
-    if (gv.g.clamped) hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS, true, CAP>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
-    else hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS, false, CAP>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
+    if constexpr (CAP < 0) {
+        if (gv.g.clamped) hipLaunchKernelGGL((normals_tagged_kernel<L, BLOCK, true>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
+        else hipLaunchKernelGGL((normals_tagged_kernel<L, BLOCK, false>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
+    } else {
+        if (gv.g.clamped) hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS, true, CAP>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
+        else hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS, false, CAP>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
+    }
 }
 
 // ---- batch k-NN export -----------------------------------------------------
@@ -1548,6 +1759,22 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     // list holds the kernel to 4 waves per SIMD: 431-445 us against 435; k = 10: 309 against 334; depth-map surfaces 470 against
     // 406): the register-list path stays the default.
     static const int fast = [] { const char *e = getenv("TC_NORMALS_FAST"); return e ? atoi(e) : 0; }();
+    // TC_NORMALS_TAG: the tagged-key path (knn_tagged) -- the list carries the neighbours' positions, no collect pass.  Needs
+    // distances that cannot overflow (the keys are compared as integers; an infinite distance with a tag would read as NaN in the
+    // pruning radius) and two spare list entries.
+    const int tagged = [] { const char *e = getenv("TC_NORMALS_TAG"); return e ? atoi(e) : 0; }();        // (read per call: the tests flip it)
+    if (tagged && prm.R0 == 2) {
+        float ext = 0.0f;
+        for (int c = 0; c < 3; ++c) ext = std::max(ext, std::fabs(ix.exact_max[c] - ix.exact_min[c]));
+        if (ext < 1e17f && K1 <= 21) {
+            if (K1 <= 9)       launch_variant<11, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
+            else if (K1 <= 11) launch_variant<13, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
+            else if (K1 <= 17) launch_variant<19, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
+            else               launch_variant<23, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
+            TC_HIP_TRY(ctx, hipGetLastError());
+            return TC_OK;
+        }
+    }
     if (!fast) {
         if (K1 <= 9)       launch_variant<9, 256>(ctx->stream, gv, prm, d_out6, ctx);
         else if (K1 <= 11) launch_variant<11, 256>(ctx->stream, gv, prm, d_out6, ctx);

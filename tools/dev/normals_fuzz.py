@@ -45,7 +45,7 @@ def explain_offender(p, i, k, radius, tree):
     ev = np.linalg.eigvalsh(np.cov(p[nbh].astype(np.float64).T, bias=True))
     gap = float((ev[1] - ev[0]) / max(ev[2], 1e-300))
     if gap < h1.EIGEN_GAP_BOUND: return True, f"degenerate eigen-pair (gap {gap:.1e})"
-    spread = h1.reference_solver_spread(p[nbh])
+    spread = h1.reference_solver_spread(p[nbh], query=p[i])
     if spread > 1e-4: return True, f"reference solver discontinuous here (spread {spread:.1e})"
     return False, f"gap {gap:.2e} solver spread {spread:.1e} neighbourhood of {len(nbh)}"
 
