@@ -926,3 +926,47 @@ def test_device_inputs_are_ordered_after_the_torch_stream(ctx):
         torch.cuda.synchronize()
         r2 = ctx.icp_detailed(src, good, None, 3, None, 0.0, correspondences=False)
         assert np.array_equal(r1.transformation, r2.transformation)
+
+
+def _with_env(name, value, fn):
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if old is None: os.environ.pop(name, None)
+        else: os.environ[name] = old
+
+
+def test_tagged_key_normals_paths_give_the_register_list_paths_bits(ctx):
+    """Round 3: the k-NN list of the normals kernel carries the neighbours' positions in the low bits of its keys (knn_tagged:
+    no collect pass; TC_NORMALS_TAG = 1 row by row, 2 flattened row groups, 3 / unset = flattened where the index is
+    volumetric, decided on the device).  Every variant must return the register-list path's bits (TC_NORMALS_TAG=0) -- on clouds
+    that stay on the tagged path (uniform), that send lanes to the fallback (exact ties on a lattice, duplicates, dense rows of an
+    unadapted surface grid, a far outlier with a clamped box, grid-boundary points of a tiny cloud) and on the policy's other side."""
+    rng = np.random.default_rng(11)
+    lattice = np.stack(np.meshgrid(np.arange(20), np.arange(20), np.arange(20), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.1
+    dups = synth.uniform_cloud(30000, 9); dups[::7] = dups[1::7][: len(dups[::7])]
+    sheet = (rng.normal(0, 1, (60000, 3)) * np.array([1, 1, 0.02])).astype(np.float32)
+    outl = synth.uniform_cloud(50000, 4); outl[0] = (50, 50, 50)
+    clouds = [("uniform 300k", synth.uniform_cloud(300_000, 5), (16, 10)), ("uniform 20k", synth.uniform_cloud(20000, 1), (16, 8, 5, 20, 3)),
+              ("uniform 500", synth.uniform_cloud(500, 1), (16, 3)), ("uniform 12", synth.uniform_cloud(12, 1), (16, 10)),
+              ("lattice", lattice, (16, 6)), ("duplicates", dups, (16,)), ("sheet", sheet, (16, 10)), ("outlier", outl, (16,)),
+              ("lidar sweep", synth.kitti_shaped_cloud(seed=2), (16,))]
+    for name, pts, ks in clouds:
+        d = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
+        for k in ks:
+            ref = _with_env("TC_NORMALS_TAG", "0", lambda: ctx.estimate_normals(d, k).cpu().numpy())
+            for mode in ("1", "2", "3"):
+                got = _with_env("TC_NORMALS_TAG", mode, lambda: ctx.estimate_normals(d, k).cpu().numpy())
+                assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"{name} k={k} TC_NORMALS_TAG={mode}: {int((got.view(np.uint32) != ref.view(np.uint32)).any(1).sum())} rows differ"
+    # a cloud handle (its own grid edge, normals + the inscribed-ball bounds for ICP as by-products) and a slice of the sorted order
+    pts = synth.uniform_cloud(280_000, 3)
+    outs = []
+    for mode in ("0", "2", "3"):
+        def run():
+            h = tc.Cloud(ctx, pts)
+            try: return h.estimate_normals(16).copy()
+            finally: h.close()
+        outs.append(_with_env("TC_NORMALS_TAG", mode, run))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)) and np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))

@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kScanBlock) scan_reduce_kernel(const uint32_t 
 // the sums in front of it itself -- a few hundred values --, block 0 also the non-zero counts -> blocksum[2 * nb])
 __global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t n,
                                                                 uint32_t *__restrict__ blocksum,
-                                                                uint32_t *__restrict__ out /* n+1 */) {
+                                                                uint32_t *__restrict__ out /* n+1 */, uint32_t *__restrict__ occ_out) {
     __shared__ uint32_t wtot[kScanBlock / 64];
     __shared__ uint32_t wpre[kScanBlock / 64], wnz[kScanBlock / 64];
     uint32_t pre = 0, nzt = 0;
@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *
         uint32_t t = 0;
         for (int w = 0; w < kScanBlock / 64; ++w) t += wnz[w];
         blocksum[2 * gridDim.x] = t;
+        if (occ_out) *occ_out = t;          // (build_index: kept in front of the prefix sums -- the normals kernel picks its path by it)
     }
     uint32_t run = block_pre + woff + inc - s;
 #pragma unroll
@@ -377,12 +378,12 @@ TileGeom make_tiles(const GridGeom &g, int tx, int ty, int tz) {
     return t;
 }
 
-tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out, DevBuf &blocksum) {
+tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out, DevBuf &blocksum, uint32_t *occ_out) {
     hipStream_t st = ctx->stream;
     const uint32_t nscan = (n + kScanTile - 1) / kScanTile;
     if (tc_status s = ensure(ctx, blocksum, ((size_t)2 * nscan + 1) * sizeof(uint32_t))) return s;   // sums | non-zero counts | their total
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p, d_out);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p, d_out, occ_out);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
 }
@@ -511,7 +512,8 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         }
         {
             ProfScope ps(ctx, "cell_scan");
-            if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, nkeys + 1, cs, ix.blocksum)) return s;
+            // (the number of occupied cells also goes to the first word in front of the prefix sums: view.cell_start[-kCellStartFront])
+            if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, nkeys + 1, cs, ix.blocksum, (uint32_t *)ix.cell_start.p)) return s;
         }
         const bool check = adapt && attempt < 3;
         uint32_t *h_occ = (uint32_t *)((char *)ctx->pinned + 2048 + 8192);

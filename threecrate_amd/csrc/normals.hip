@@ -50,6 +50,8 @@ struct NormalParams {
                                 // [1] = the serving kernel's exit ticket, entries from [2]) and served by normals_coop_kernel, a block per point
     uint32_t p_begin, p_end;    // cell-sorted positions handled by this launch (a multi-GPU shard: SURVEY 8e)
     int      slice_out;         // 1: record of position p goes to row p - p_begin (sorted order) instead of its original index
+    int      tag_policy;        // tagged-key kernels: 1 = take the tagged path only on a volumetric index (decided on the device from the
+                                // occupied-cell count build_index leaves in front of the prefix sums), 0 = always try it
 #ifdef TC_PHASE_STAMPS
     unsigned long long *stamps; // dev build: 8 per block (wave 0's shader clocks per phase)
 #endif
@@ -662,6 +664,19 @@ __device__ __forceinline__ bool knn_survivors(const GridView &gv, const NormalPa
 // Exactness rule and ring-3 continuation as in the register-list path, judged against the truncation's upper bound.  A lane that
 // fails any check returns false and runs the register-list path: same bits either way.
 constexpr uint32_t kTagMask = 0xFFFu, kKeyInf = 0x7f800000u;
+typedef float nf32x3 __attribute__((ext_vector_type(3)));
+// raw buffer descriptor over the record array: 32-bit byte offsets per lane, the four records of a step share one offset register
+// (launch_normals takes this path only below 2^28 records)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t nrm_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0xFFFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ uint32_t tag_key(const nf32x3 &c, const float4 &q, uint32_t rowtag, uint32_t j) {
+    // two bit-field inserts (the compiler's own choice for the C expression is and + and + or3)
+    uint32_t t, key;
+    asm("v_bfi_b32 %0, 63, %1, %2" : "=v"(t) : "v"(j), "v"(rowtag));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "s"(kTagMask), "v"(t), "v"(__float_as_uint(d2_nc(c.x, c.y, c.z, q.x, q.y, q.z))));
+    return key;
+}
 
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {          // -> v_med3_u32
     const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
@@ -675,7 +690,21 @@ __device__ __forceinline__ void list_insert_u(uint32_t (&d)[L], uint32_t v) {
     d[0] = d[0] < v ? d[0] : v;
 }
 
-template <int L, int BLOCK, bool EXT>
+// FLAT (round 3, third form): the lockstep row walk -- a row costs the wave its longest span, ~246 candidate slots per lane for a mean
+// need of 80 at k = 16 -- becomes three groups of rows (the central 3 x 3, then the outer 16 in two halves, nearest first): the
+// row logic of a group runs converged for all lanes (windows judged against the limit the list holds when the group starts, the
+// cell_start pairs of all its rows in flight together), the non-empty spans go to a per-lane LDS list, and ONE flattened loop
+// walks them -- a lane moves to its next span when its current one ends, so a group costs the wave the longest SUM of spans
+// (simulated on the uniform cloud: ~155 slots).  The loop body is branch-free: a slot beyond its span inserts the key
+// 0xFFFFFFFF (a no-op for the list), the next span is prefetched from LDS at the top of every step.
+struct FlatRows { int8_t dz[9], dy[9]; int n; };
+__device__ constexpr FlatRows kFlatRows[3] = {
+    {{0, 0, 0, -1, 1, -1, -1, 1, 1}, {0, -1, 1, 0, 0, -1, 1, -1, 1}, 9},
+    {{0, 0, -2, 2, -1, -1, 1, 1, 0}, {-2, 2, 0, 0, -2, 2, -2, 2, 0}, 8},
+    {{-2, -2, 2, 2, -2, -2, 2, 2, 0}, {-1, 1, -1, 1, -2, 2, -2, 2, 0}, 8},
+};
+
+template <int L, int BLOCK, bool EXT, bool FLAT = false>
 __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParams &prm, uint32_t p, const float4 &q, int cx, int cy, int cz,
                                            float mf, uint32_t *ldsA, uint8_t *ldsB, uint32_t &cnt, int &self_r, float &d1_out) {
     const GridGeom &g = gv.g;
@@ -684,12 +713,93 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
 #pragma unroll
     for (int t = 0; t < L; ++t) d[t] = kKeyInf;
     auto lim_of = [](uint32_t key) { return __uint_as_float(key < kKeyInf ? key : kKeyInf); };     // a key read as a float bounds its distance from below within 5e-4
+    // pruning limit of the block scan: the last key -- or, when k + 1 = L - 2 (k = 16 with L = 19), the (k+1)-th key's upper bound:
+    // a record beyond it cannot be among the k + 1 nearest, and the two spare entries only have to bound the records that WERE
+    // visited and rejected (the certificate below)
+    const bool tight = K1 + 2u == (uint32_t)L;
+    auto lim_hi = [](uint32_t key) { return key < kKeyInf ? __uint_as_float(key | kTagMask) : INFINITY; };
+    const __amdgpu_buffer_rsrc_t pt_rsrc = nrm_rsrc(gv.pts);
     auto visit = [&](uint32_t j, const float4 &c, uint32_t rowtag) {
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
         list_insert_u<L>(d, (__float_as_uint(v) & ~kTagMask) | rowtag | (j & 63u));
     };
     int R = 2;
-    {
+    if constexpr (FLAT) {
+        float live0 = INFINITY;
+        bool fail = false;
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+            constexpr int NR = 9;
+            uint32_t ss[NR], ee[NR];
+            bool ok[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                ok[i] = false; ss[i] = 0; ee[i] = 0;
+                if (i >= kFlatRows[grp].n) continue;
+                const int dz = kFlatRows[grp].dz[i], dy = kFlatRows[grp].dy[i];
+                const int z = cz + dz, y = cy + dy;
+                const bool inb = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+                const int zc = inb ? z : cz, yc = inb ? y : cy;
+                const float gzv = axis_gap_n<EXT>(q.z, g.minz, g.h, zc, g.gz - 1);
+                const float gyv = axis_gap_n<EXT>(q.y, g.miny, g.h, yc, g.gy - 1);
+                const float rg = gyv * gyv + gzv * gzv;
+                int xa = max(cx - 2, 0), xb = min(cx + 2, g.gx - 1);
+                const float r = TC_FAST_SQRT(fmaxf(live0 - rg, 0.0f)) + 4e-3f * g.h;
+                const float fa = fminf(fmaxf((q.x - r - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
+                const float fb = fmaxf(fminf((q.x + r - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
+                xa = max(xa, (int)fa);
+                xb = min(xb, (int)fb);
+                ok[i] = inb && !(rg > live0) && xa <= xb;
+                xb = max(xb, xa);
+                const uint32_t row = ((uint32_t)zc * g.gy + yc) * g.gx;
+                ss[i] = gv.cell_start[row + xa];
+                ee[i] = gv.cell_start[row + xb + 1];
+            }
+            uint32_t ns = 0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                if (i >= kFlatRows[grp].n) continue;
+                const uint32_t len = ok[i] ? ee[i] - ss[i] : 0u;
+                fail |= len > 0xFFFFu;
+                const uint32_t rowtag = (uint32_t)(((kFlatRows[grp].dz[i] + 3) << 3) | (kFlatRows[grp].dy[i] + 3)) << 6;
+                ldsA[(2u * ns) * BLOCK] = ss[i];
+                ldsA[(2u * ns + 1u) * BLOCK] = (len & 0xFFFFu) | (rowtag << 16);
+                ns += len ? 1u : 0u;
+            }
+            uint32_t k = 0;
+            uint32_t j = 0, e = 0, tag = 0;
+            {
+                const uint32_t w1 = ldsA[0], w2 = ldsA[BLOCK];
+                j = ns ? w1 : 0u;
+                e = ns ? w1 + (w2 & 0xFFFFu) : 0u;
+                tag = w2 >> 16;
+            }
+            // (if + do-while: as a plain while loop the compiler copies the whole list at the loop header, 19 v_mov per step)
+            if (__any((int)(j < e))) do {
+                const uint32_t kn = min(k + 1u, (uint32_t)(NR - 1));
+                const uint32_t n1 = ldsA[(2u * kn) * BLOCK], n2 = ldsA[(2u * kn + 1u) * BLOCK];
+                const uint32_t o = j << 4;
+                const nf32x3 c0 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o, 0, 0));
+                const nf32x3 c1 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u, 0, 0));
+                const nf32x3 c2 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 32u, 0, 0));
+                const nf32x3 c3 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 48u, 0, 0));
+                const uint32_t k0 = tag_key(c0, q, tag, j), k1 = tag_key(c1, q, tag, j + 1u), k2 = tag_key(c2, q, tag, j + 2u), k3 = tag_key(c3, q, tag, j + 3u);
+                list_insert_u<L>(d, j < e ? k0 : 0xFFFFFFFFu);
+                list_insert_u<L>(d, j + 1u < e ? k1 : 0xFFFFFFFFu);
+                list_insert_u<L>(d, j + 2u < e ? k2 : 0xFFFFFFFFu);
+                list_insert_u<L>(d, j + 3u < e ? k3 : 0xFFFFFFFFu);
+                j += 4u;
+                const bool adv = j >= e;
+                k += adv ? 1u : 0u;
+                const bool more = k < ns;
+                j = adv ? (more ? n1 : 0u) : j;
+                tag = adv ? (n2 >> 16) : tag;
+                e = adv ? (more ? n1 + (n2 & 0xFFFFu) : 0u) : e;
+            } while (__any((int)(j < e)));
+            live0 = tight ? lim_hi(d[L - 3]) : lim_of(d[L - 1]);
+        }
+        if (fail) { TC_NSTAT(2, 1); return false; }
+    } else {
         // the ring-2 block centre-out, pruned against the list's last key as soon as the list is full (normals_point's list pass)
         float live0 = INFINITY;
         for (int iz = 0; iz < 5; ++iz) {
@@ -713,13 +823,17 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
                 const uint32_t rowtag = (uint32_t)(((dz + 3) << 3) | (dy + 3)) << 6;
                 const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
                 for (uint32_t j = s; j < e; j += 4) {
-                    const float4 c0 = gv.pts[j], c1 = gv.pts[j + 1], c2 = gv.pts[j + 2], c3 = gv.pts[j + 3];
-                    visit(j, c0, rowtag);
-                    if (j + 1 < e) visit(j + 1, c1, rowtag);
-                    if (j + 2 < e) visit(j + 2, c2, rowtag);
-                    if (j + 3 < e) visit(j + 3, c3, rowtag);
+                    const uint32_t o = j << 4;
+                    const nf32x3 c0 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o, 0, 0));
+                    const nf32x3 c1 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u, 0, 0));
+                    const nf32x3 c2 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 32u, 0, 0));
+                    const nf32x3 c3 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 48u, 0, 0));
+                    list_insert_u<L>(d, tag_key(c0, q, rowtag, j));
+                    if (j + 1 < e) list_insert_u<L>(d, tag_key(c1, q, rowtag, j + 1u));
+                    if (j + 2 < e) list_insert_u<L>(d, tag_key(c2, q, rowtag, j + 2u));
+                    if (j + 3 < e) list_insert_u<L>(d, tag_key(c3, q, rowtag, j + 3u));
                 }
-                live0 = lim_of(d[L - 1]);
+                live0 = tight ? lim_hi(d[L - 3]) : lim_of(d[L - 1]);
             }
         }
     }
@@ -756,10 +870,10 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
     cnt = min(K1, nv);
     const int x0 = max(cx - 3, 0), x1 = min(cx + 3, g.gx - 1);
     // The list leaves the registers (a decode step unrolled over all L entries keeps every gather in flight: 191 VGPRs): the keys
-    // are parked in ldsA, a rolled loop takes them four at a time -- key -> row window -> position -> record -> exact distance,
-    // the position written back over the key -- and the exact (distance, position) order comes out of a sliding window: a key's
-    // place is off by at most three (runs of <= 4 equal truncated distances), so an entry's rank is final once three later
-    // entries have been compared with it.
+    // are parked in ldsA, a rolled loop takes them four at a time -- key -> row window -> position -> record -> exact distance --
+    // and the exact (distance, position) order comes out of a sliding window: a key's place is off by at most three (runs of <= 4
+    // equal truncated distances), so an entry's rank is final once three later entries have been compared with it; its position
+    // then goes to ldsA[rank] (never ahead of the keys still to be read).
     float wv0 = -INFINITY, wv1 = -INFINITY, wv2 = -INFINITY;         // window: 0 = oldest
     uint32_t wj0 = 0, wj1 = 0, wj2 = 0, wr0 = 0, wr1 = 0, wr2 = 0, wt0 = 0xFFu, wt1 = 0xFFu, wt2 = 0xFFu;
     float vk = INFINITY, v1 = INFINITY;
@@ -775,40 +889,50 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
             vk = (wr0 + 1u == K1) ? wv0 : vk;
             v1 = (wr0 == 1u) ? wv0 : v1;
             if (wj0 == p && wr0 < cnt) self_r = (int)wr0;
-            ldsB[wr0 * BLOCK] = (uint8_t)wt0;
+#ifdef TC_TAG_NOBATCH
+            ldsB[wr0 * BLOCK] = (uint8_t)wr0;
+#endif
+            ldsA[wr0 * BLOCK] = wj0;             // rank order (ranks <= the entry last read from ldsA: its key is in a register by now)
         }
         wv0 = wv1; wj0 = wj1; wr0 = wr1; wt0 = wt1;
         wv1 = wv2; wj1 = wj2; wr1 = wr2; wt1 = wt2;
         wv2 = vn; wj2 = jn; wr2 = rn; wt2 = tn;
     };
+    // (requesting the keys and row windows of the NEXT four entries before the current four are resolved was measured: no gain at
+    // k = 10, and at k = 16 the extra live registers spill -- 382 instead of 325 us)
+    uint32_t keyN[4], sN[4], eN[4];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            keyN[i] = (t0 + i < L) ? ldsA[(t0 + i) * BLOCK] : kKeyInf;
+            const bool valid = keyN[i] < kKeyInf;
+            const uint32_t tag = keyN[i] & kTagMask;
+            const int z = valid ? cz + (int)(tag >> 9) - 3 : cz, y = valid ? cy + (int)((tag >> 6) & 7u) - 3 : cy;
+            const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
+            sN[i] = gv.cell_start[row + x0];
+            eN[i] = gv.cell_start[row + x1 + 1];
+        }
+    };
 #pragma unroll 1
     for (int t0 = 0; t0 < L; t0 += 4) {
-        uint32_t key[4], s0[4], e0[4], jx[4];
+        fetch(t0);
+        uint32_t key[4], jx[4];
         bool valid[4];
+        nf32x3 c[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            key[i] = (t0 + i < L) ? ldsA[(t0 + i) * BLOCK] : kKeyInf;
+            key[i] = keyN[i];
             valid[i] = key[i] < kKeyInf;
-            const uint32_t tag = key[i] & kTagMask;
-            const int z = valid[i] ? cz + (int)(tag >> 9) - 3 : cz, y = valid[i] ? cy + (int)((tag >> 6) & 7u) - 3 : cy;
-            const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
-            s0[i] = gv.cell_start[row + x0];
-            e0[i] = gv.cell_start[row + x1 + 1];
-        }
-        float4 c[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bad |= valid[i] && (e0[i] - s0[i] > 64u);
-            const uint32_t j = s0[i] + (((key[i] & 63u) - s0[i]) & 63u);
-            jx[i] = (valid[i] && j < e0[i]) ? j : p;
-            c[i] = gv.pts[jx[i]];
+            bad |= valid[i] && (eN[i] - sN[i] > 64u);
+            const uint32_t j = sN[i] + (((key[i] & 63u) - sN[i]) & 63u);
+            jx[i] = (valid[i] && j < eN[i]) ? j : p;
+            c[i] = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, jx[i] << 4, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float ve = d2_nc(c[i].x, c[i].y, c[i].z, q.x, q.y, q.z);
             bad |= valid[i] && ((__float_as_uint(ve) & ~kTagMask) != (key[i] & ~kTagMask));
             if (t0 + i < L) {
-                ldsA[(t0 + i) * BLOCK] = valid[i] ? jx[i] : 0xFFFFFFFFu;
                 push(valid[i] ? ve : INFINITY, valid[i] ? jx[i] : 0xFFFFFFFFu, (uint32_t)(t0 + i));
             }
         }
@@ -856,7 +980,9 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     float mf = fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz));
     mf = fmaxf(mf, 0.0f);
 
-    float d[L];
+    // (inside a tagged-key kernel this is the fallback path: its list needs k + 1 entries, not the tagged list's k + 3)
+    constexpr int LO = (CAP < 0) ? L - 2 : L;
+    float d[LO];
     float tau = INFINITY;
     int R = prm.R0;
     // radius mode (normals.rs:141-146): neighbours = every record within `radius` except the query
@@ -867,7 +993,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     bool use_radius = false;
 #pragma unroll
-    for (int t = 0; t < L; ++t) d[t] = INFINITY;
+    for (int t = 0; t < LO; ++t) d[t] = INFINITY;
     // the survivor-list path (k-NN mode): on success d[] holds the sorted distances, ldsA / ldsB the k+1 nearest and their ranks
     bool have = false;
     uint32_t cnt = 0;
@@ -885,7 +1011,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
 #endif
         if (!have) {
 #pragma unroll
-            for (int t = 0; t < L; ++t) d[t] = INFINITY;
+            for (int t = 0; t < LO; ++t) d[t] = INFINITY;
             R = prm.R0;
         }
     }
@@ -893,9 +1019,23 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         // the tagged-key path (knn_tagged): on success ldsA / ldsB hold the k+1 nearest and their ranks, d[1] the distance to the
         // nearest other record; a lane it cannot serve runs the register-list path below
         TC_NSTAMP(0);
-        float d1 = INFINITY;
-        have = knn_tagged<L, BLOCK, EXT>(gv, prm, p, q, cx, cy, cz, mf, ldsA, ldsB, cnt, self_r, d1);
-        if (have) d[1] = d1;
+        // Where it pays is decided per index, on the device (no host round trip): the tagged path wins where the cells are
+        // filled like a volume (uniform 1 M points, k = 16: 435 -> 315 us) and loses on surfaces and dense cells -- few rows of a
+        // block hold points there, the old collect pass is cheap, and row windows of more than 64 records send lanes to the
+        // fallback (TUM-shaped 1 M: 407 -> 440 us, a 120 k-point LiDAR sweep on an unadapted grid 190 -> 355).  The index
+        // build leaves the number of occupied cells in front of the prefix sums: at least 20 % of the cells occupied (a uniform
+        // cloud: 40 - 76 % depending on k; an adapted surface grid: 3 - 6 %) and at most 4 points per occupied cell = volumetric.
+        bool try_tag = true;
+        if (prm.tag_policy) {
+            const uint32_t occ = gv.cell_start[-(int)kCellStartFront];
+            try_tag = (unsigned long long)occ * 5ull >= (unsigned long long)g.ncell && (unsigned long long)g.n <= (unsigned long long)occ * 4ull;
+        }
+        if (try_tag) {
+            float d1 = INFINITY;
+            have = knn_tagged<L, BLOCK, EXT, (CAP < -1)>(gv, prm, p, q, cx, cy, cz, mf, ldsA, ldsB, cnt, self_r, d1);
+            if (have) d[1] = d1;
+            TC_NSTAMP(1);
+        }
 #ifdef TC_NSTATS
         if ((threadIdx.x & 63) == 0) TC_NSTAT(6, 1);
         if (__any((int)!have) && (threadIdx.x & 63) == 0) TC_NSTAT(7, 1);
@@ -903,7 +1043,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     }
     auto visit1 = [&](uint32_t j, const float4 &c) {
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
-        list_insert<L>(d, v);
+        list_insert<LO>(d, v);
         if (RADIUS && j != p && v <= r2) {
             const double dx = (double)c.x - (double)q.x, dy = (double)c.y - (double)q.y, dz = (double)c.z - (double)q.z;
             ++cnt_r;
@@ -915,7 +1055,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
 #define TC_KTH(OUT)                                                                 \
     do {                                                                            \
         float tk_ = d[0];                                                           \
-        _Pragma("unroll") for (int t = 1; t < L; ++t) tk_ = ((uint32_t)t == prm.k) ? d[t] : tk_; \
+        _Pragma("unroll") for (int t = 1; t < LO; ++t) tk_ = ((uint32_t)t == prm.k) ? d[t] : tk_; \
         (OUT) = tk_;                                                                \
     } while (0)
     // ring R0: the whole block (no bound known yet)
@@ -955,11 +1095,11 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
                     if (j + 2 < e) visit1(j + 2, c2);
                     if (j + 3 < e) visit1(j + 3, c3);
                 }
-                live0 = fmaxf(d[L - 1], need0);
+                live0 = fmaxf(d[LO - 1], need0);
             }
         }
     }
-    { float sink_ = d[L - 1]; asm volatile("" :: "v"(sink_)); }
+    { float sink_ = d[LO - 1]; asm volatile("" :: "v"(sink_)); }
     TC_NSTAMP(1);
     for (;;) {
         TC_KTH(tau);
@@ -996,7 +1136,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
             visit1(j, c);
             // only the growing lanes tighten their limit; the list's last entry bounds the k-th (no dynamic index: that
             // sends the list to scratch here)
-            if (growing) live_lim = fmaxf(d[L - 1], need2);
+            if (growing) live_lim = fmaxf(d[LO - 1], need2);
         }, &live_lim);
         if (!touched) { TC_KTH(tau); use_radius = RADIUS && cnt_r >= prm.k; break; }
     }
@@ -1011,13 +1151,13 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     // cnt_r + 1 entries, so it goes through the k-NN epilogue with k + 1 := cnt_r + 1 -- neighbours in ascending distance, the
     // query last, f32 centroid / covariance in the reference's order (normals.rs:141-146, :164-177), nalgebra's eigen solve:
     // bit-comparable like the k-NN path.  A larger set keeps the order-free f64 moments + closed form below.
-    const bool radius_fit = RADIUS && use_radius && cnt_r + 1u <= (uint32_t)L;
+    const bool radius_fit = RADIUS && use_radius && cnt_r + 1u <= (uint32_t)LO;
     uint32_t K1e = K1;
     if (radius_fit) {
         K1e = cnt_r + 1u;
         float tr = d[0];
 #pragma unroll
-        for (int t = 1; t < L; ++t) tr = ((uint32_t)t == cnt_r) ? d[t] : tr;
+        for (int t = 1; t < LO; ++t) tr = ((uint32_t)t == cnt_r) ? d[t] : tr;
         tau = tr;
     }
     if (RADIUS && use_radius && !radius_fit) {
@@ -1034,7 +1174,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     // phase 2: collect the positions of the K1 nearest records
     uint32_t n_lt = 0;
 #pragma unroll
-    for (int t = 0; t < L; ++t) n_lt += (d[t] < tau) ? 1u : 0u;
+    for (int t = 0; t < LO; ++t) n_lt += (d[t] < tau) ? 1u : 0u;
     const uint32_t quota = K1e - min(n_lt, K1e);
     uint32_t ties = 0;
     cnt = 0;
@@ -1064,7 +1204,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
         uint32_t r = 0;
 #pragma unroll
-        for (int t = 0; t < L; ++t) r += (d[t] < v) ? 1u : 0u;
+        for (int t = 0; t < LO; ++t) r += (d[t] < v) ? 1u : 0u;
         while (is_taken(r)) ++r;
         if (r < 64) taken_lo |= 1ull << r; else if (r < 128) taken_hi |= 1ull << (r - 64); else taken_x |= 1ull << (r - 128);
         ldsB[r * BLOCK] = (uint8_t)e;           // rank -> entry index (one byte; the positions stay in ldsA)
@@ -1078,21 +1218,55 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     if (npts >= 3) {
         // centroid (normals.rs:165-169): sequential f32 adds, neighbours ascending then self
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        float cxx = 0.0f, cxy = 0.0f, cxz = 0.0f, cyy = 0.0f, cyz = 0.0f, czz = 0.0f;
+        const float nf = (float)npts;
+        float mx, my, mz;
+        bool batched = false;
+#ifndef TC_TAG_NOBATCH
+        if constexpr (CAP < 0 && !RADIUS) batched = have;
+#endif
+        if (batched) {
+            // tagged path: ldsA holds the positions in rank order.  The k + 1 records are requested TOGETHER and kept in registers
+            // (the list's registers are free by now) for both passes, instead of two loops of LDS -> LDS -> gather round trips
+            // (34 dependent gathers were 12 % of a wave's time); the additions keep the reference's order, slots beyond the
+            // neighbourhood and the dropped entry are skipped by predicate.
+            if constexpr (CAP < 0) {
+                constexpr int KM = L - 2;
+                const __amdgpu_buffer_rsrc_t pt_rsrc = nrm_rsrc(gv.pts);
+                float nx[KM], ny[KM], nz[KM];
+#pragma unroll
+                for (int t = 0; t < KM; ++t) {
+                    const uint32_t j = ((uint32_t)t < cnt) ? ldsA[t * BLOCK] : p;
+                    const nf32x3 c = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, j << 4, 0, 0));
+                    nx[t] = c.x; ny[t] = c.y; nz[t] = c.z;
+                }
+#pragma unroll
+                for (int t = 0; t < KM; ++t)
+                    if ((uint32_t)t < cnt && t != drop_r) { sx += nx[t]; sy += ny[t]; sz += nz[t]; }
+                sx += q.x; sy += q.y; sz += q.z;
+                mx = sx / nf; my = sy / nf; mz = sz / nf;
+#pragma unroll
+                for (int t = 0; t < KM; ++t)
+                    if ((uint32_t)t < cnt && t != drop_r) {
+                        const float dx = nx[t] - mx, dy = ny[t] - my, dz = nz[t] - mz;
+                        cxx += dx * dx; cxy += dx * dy; cxz += dx * dz; cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
+                    }
+            }
+        } else {
         for (uint32_t r = 0; r < cnt; ++r) {
             if ((int)r == drop_r) continue;
             const float4 c = gv.pts[ldsA[(uint32_t)ldsB[r * BLOCK] * BLOCK]];
             sx += c.x; sy += c.y; sz += c.z;
         }
         sx += q.x; sy += q.y; sz += q.z;
-        const float nf = (float)npts;
-        const float mx = sx / nf, my = sy / nf, mz = sz / nf;
+        mx = sx / nf; my = sy / nf; mz = sz / nf;
         // covariance (normals.rs:172-177)
-        float cxx = 0.0f, cxy = 0.0f, cxz = 0.0f, cyy = 0.0f, cyz = 0.0f, czz = 0.0f;
         for (uint32_t r = 0; r < cnt; ++r) {
             if ((int)r == drop_r) continue;
             const float4 c = gv.pts[ldsA[(uint32_t)ldsB[r * BLOCK] * BLOCK]];
             const float dx = c.x - mx, dy = c.y - my, dz = c.z - mz;
             cxx += dx * dx; cxy += dx * dy; cxz += dx * dz; cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
+        }
         }
         {
             const float dx = q.x - mx, dy = q.y - my, dz = q.z - mz;
@@ -1412,19 +1586,22 @@ __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, Nor
 
 // the tagged-key instantiation, held to the register-list path's six waves per SIMD (its decode step would otherwise keep all
 // its gathers in flight at once: 191 VGPRs)
-template <int L, int BLOCK, bool EXT>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) normals_tagged_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
-    __shared__ uint32_t ldsA[L * BLOCK];
+#ifndef TC_TAG_WAVES
+#define TC_TAG_WAVES 6
+#endif
+template <int L, int BLOCK, bool EXT, int CAP>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(TC_TAG_WAVES, TC_TAG_WAVES))) normals_tagged_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
+    __shared__ uint32_t ldsA[(L > 18 ? L : 18) * BLOCK];        // (the flattened walk parks up to nine spans of two words here)
     __shared__ uint8_t ldsB[L * BLOCK];
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t p = prm.p_begin + lb * BLOCK + threadIdx.x;
     if (p >= prm.p_end) return;
 #ifdef TC_PHASE_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
-    normals_point<L, BLOCK, false, EXT, -1>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x, ph, tl);
+    normals_point<L, BLOCK, false, EXT, CAP>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x, ph, tl);
     if (threadIdx.x == 0 && prm.stamps) for (int i = 0; i < 8; ++i) prm.stamps[8 * (size_t)blockIdx.x + i] = ph[i];
 #else
-    normals_point<L, BLOCK, false, EXT, -1>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
+    normals_point<L, BLOCK, false, EXT, CAP>(gv, prm, p, out6, ldsA + threadIdx.x, ldsB + threadIdx.x);
 #endif
 }
 
@@ -1437,8 +1614,8 @@ static void launch_variant(hipStream_t st, const GridView &gv, const NormalParam
     ProfScope ps(ctx, "normals_knn_pca");
     // two instantiations: with a clamped box the boundary cells are open on the outer side (costs 4 % on the gap tests)
     if constexpr (CAP < 0) {
-        if (gv.g.clamped) hipLaunchKernelGGL((normals_tagged_kernel<L, BLOCK, true>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
-        else hipLaunchKernelGGL((normals_tagged_kernel<L, BLOCK, false>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
+        if (gv.g.clamped) hipLaunchKernelGGL((normals_tagged_kernel<L, BLOCK, true, CAP>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
+        else hipLaunchKernelGGL((normals_tagged_kernel<L, BLOCK, false, CAP>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
     } else {
         if (gv.g.clamped) hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS, true, CAP>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
         else hipLaunchKernelGGL((normals_knn_pca_kernel<L, BLOCK, RADIUS, false, CAP>), dim3(nb), dim3(BLOCK), 0, st, gv, prm, out6);
@@ -1647,6 +1824,7 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     if (cfg.k_neighbors + 1 > 2048) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 2047 is not supported by the HIP backend");
     NormalParams prm;
     prm.hard_list = nullptr;
+    prm.tag_policy = 0;
     prm.k = (uint32_t)cfg.k_neighbors;
     prm.orient = cfg.consistent_orientation ? 1 : 0;
     prm.vx = vp[0]; prm.vy = vp[1]; prm.vz = vp[2];
@@ -1762,12 +1940,21 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     // TC_NORMALS_TAG: the tagged-key path (knn_tagged) -- the list carries the neighbours' positions, no collect pass.  Needs
     // distances that cannot overflow (the keys are compared as integers; an infinite distance with a tag would read as NaN in the
     // pruning radius) and two spare list entries.
-    const int tagged = [] { const char *e = getenv("TC_NORMALS_TAG"); return e ? atoi(e) : 0; }();        // (read per call: the tests flip it)
+    // 0: the register-list kernels; 1 / 2: the tagged path forced, row by row / flattened; 3 (default): flattened, taken where the
+    // index is volumetric (NormalParams::tag_policy)
+    const int tagged = [] { const char *e = getenv("TC_NORMALS_TAG"); return e ? atoi(e) : 3; }();        // (read per call: the tests flip it)
+    prm.tag_policy = tagged >= 3 ? 1 : 0;
     if (tagged && prm.R0 == 2) {
         float ext = 0.0f;
         for (int c = 0; c < 3; ++c) ext = std::max(ext, std::fabs(ix.exact_max[c] - ix.exact_min[c]));
-        if (ext < 1e17f && K1 <= 21) {
-            if (K1 <= 9)       launch_variant<11, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
+        if (ext < 1e17f && K1 <= 21 && ix.geom.n < (1u << 28)) {
+            if (tagged >= 2) {
+                if (K1 <= 9)       launch_variant<11, 256, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
+                else if (K1 <= 11) launch_variant<13, 256, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
+                else if (K1 <= 17) launch_variant<19, 256, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
+                else               launch_variant<23, 256, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
+            }
+            else if (K1 <= 9)  launch_variant<11, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
             else if (K1 <= 11) launch_variant<13, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
             else if (K1 <= 17) launch_variant<19, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
             else               launch_variant<23, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);

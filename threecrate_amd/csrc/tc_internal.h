@@ -218,7 +218,7 @@ tc_status gather_normals(tc_context *ctx, DeviceIndex &ix, const float *d_normal
 GridView view_of(const DeviceIndex &ix);
 
 // grid.hip (shared with voxel.hip)
-tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out /* n+1 */, DevBuf &blocksum);
+tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out /* n+1 */, DevBuf &blocksum, uint32_t *occ_out = nullptr);
 tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3]);
 
 // voxel.hip
