@@ -446,6 +446,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
                       float min_cell_edge, float target_ppo, bool strict_order) {
     if (n == 0 || n >= 0xFFFFFFF0ull) return fail(ctx, TC_INVALID_DATA, "build_index: bad point count");
     ix.vor_valid = false;
+    ix.occ_host_valid = false;
     hipStream_t st = ctx->stream;
     const uint32_t n32 = (uint32_t)n;
     const int nb = (int)((n + 255) / 256);
@@ -537,6 +538,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         // the rest of the build is already enqueued (the usual outcome is to keep it)
         TC_HIP_TRY(ctx, hipStreamSynchronize(st));
         const double ppo = (double)n / (double)std::max<uint32_t>(*h_occ, 1u);
+        ix.occ_host = *h_occ; ix.occ_host_valid = true;        // (of THIS attempt's grid: reset below when another attempt follows)
         if (dbg & 256)
             fprintf(stderr, "[tc] index: n %zu h %.5f grid %d x %d x %d = %u cells (%.2f n), %u occupied, %.2f points each (want %.1f)\n", n,
                     g.h, g.gx, g.gy, g.gz, g.ncell, (double)g.ncell / (double)n, *h_occ, ppo, target_ppo);
@@ -547,6 +549,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         set_cell_edge(ng, h, n, 32.0);      // measured on a 1 M-point depth-map surface: 16 -> 32 cells per point -8 % normals, -10 % ICP; 64: no further gain
         if (!(ng.h < 0.95f * g.h)) break;                     // budget or minimum edge reached
         ix.geom = ng;
+        ix.occ_host_valid = false;
     }
     if (strict_order) {
         // Ranks that split the cell-sorted order between them (TC_SHARD_SPATIAL, sharded normals) need the SAME order on every

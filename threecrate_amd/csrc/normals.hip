@@ -46,8 +46,8 @@ struct NormalParams {
     float4 *sorted_nrm;     // optional: the normal of cell-sorted position p -> sorted_nrm[p] (a cloud handle keeps them: the ICP target layout)
     float4 *vor_out;        // optional: {x, y, z, inscribed-ball bound} per position (icp.hip: the bound is a quarter of the squared
                             // distance to the nearest OTHER record = the second entry of the k-NN list, for free here)
-    uint32_t *hard_list;        // optional: positions whose search would outgrow kHardRing rings are appended here (hard_list[0] = count,
-                                // [1] = the serving kernel's exit ticket, entries from [2]) and served by normals_coop_kernel, a block per point
+    uint32_t *hard_list;        // optional: positions whose search would outgrow kHardRing rings are appended here (hard_list[0] = count, entries from [4];
+                                // [1] = the serving kernel's exit ticket) and served by normals_coop_kernel, a block per point
     uint32_t p_begin, p_end;    // cell-sorted positions handled by this launch (a multi-GPU shard: SURVEY 8e)
     int      slice_out;         // 1: record of position p goes to row p - p_begin (sorted order) instead of its original index
     int      tag_policy;        // tagged-key kernels: 1 = take the tagged path only on a volumetric index (decided on the device from the
@@ -1125,7 +1125,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         // An isolated point (a far outlier: its neighbours are a hundred extents away; a point in an empty region) would walk
         // thousands of rows -- the whole grid -- through ONE lane: handed to normals_coop_kernel instead, a wave per point.
         if (!RADIUS && prm.hard_list != nullptr && R > kHardRing) {
-            prm.hard_list[2u + atomicAdd(&prm.hard_list[0], 1u)] = p;
+            prm.hard_list[4u + atomicAdd(&prm.hard_list[0], 1u)] = p;
             return;
         }
         // one call site for both cases (lanes of a wave differ): only the growing lanes refresh their limit
@@ -1444,7 +1444,7 @@ __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv,
     const uint32_t count = hard ? hard[0] : prm.p_end - prm.p_begin;
     const uint32_t nfin = gv.cell_start[g.ncell];
     for (uint32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const uint32_t p = hard ? hard[2u + idx] : prm.p_begin + idx;
+        const uint32_t p = hard ? hard[4u + idx] : prm.p_begin + idx;
         const float4 q = gv.pts[p];
         const uint32_t orig = __float_as_uint(q.w);
         float nrm_x = 0.0f, nrm_y = 0.0f, nrm_z = 1.0f;
@@ -1520,7 +1520,7 @@ __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv,
     }
     // the list is left empty for the next normals launch by the LAST block to leave (every block has read the count by then): no
     // memset launch per call
-    if (hard && tid == 0 && atomicAdd(&hard[1], 1u) == gridDim.x - 1u) { hard[0] = 0u; hard[1] = 0u; }
+    if (hard && tid == 0 && atomicAdd(&hard[1], 1u) == gridDim.x - 1u) { hard[0] = 0u; hard[1] = 0u; hard[2] = 0u; hard[3] = 0u; }
 }
 
 // NearestNeighborSearch::find_k_nearest beyond the register list's 129 entries (k up to 2048): a block per query, the same
@@ -1585,12 +1585,13 @@ __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, Nor
 }
 
 // the tagged-key instantiation, held to the register-list path's six waves per SIMD (its decode step would otherwise keep all
-// its gathers in flight at once: 191 VGPRs)
+// its gathers in flight at once: 191 VGPRs); five for the 19-entry list and above: at six it spills 21 registers (96 B of scratch
+// per lane = 84 MB of extra write traffic at 1 M points) for the same time (321 vs 325 us)
 #ifndef TC_TAG_WAVES
 #define TC_TAG_WAVES 6
 #endif
 template <int L, int BLOCK, bool EXT, int CAP>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(TC_TAG_WAVES, TC_TAG_WAVES))) normals_tagged_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(L >= 19 ? TC_TAG_WAVES - 1 : TC_TAG_WAVES, L >= 19 ? TC_TAG_WAVES - 1 : TC_TAG_WAVES))) normals_tagged_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
     __shared__ uint32_t ldsA[(L > 18 ? L : 18) * BLOCK];        // (the flattened walk parks up to nine spans of two words here)
     __shared__ uint8_t ldsB[L * BLOCK];
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -1876,10 +1877,10 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     // wave-per-point kernel behind it (k-NN mode)
     if (!radius_mode && prm.p_end > prm.p_begin) {
         const void *before = ctx->normals_hard.p;
-        if (tc_status s = ensure(ctx, ctx->normals_hard, ((size_t)(prm.p_end - prm.p_begin) + 2) * sizeof(uint32_t))) return s;
+        if (tc_status s = ensure(ctx, ctx->normals_hard, ((size_t)(prm.p_end - prm.p_begin) + 4) * sizeof(uint32_t))) return s;
         prm.hard_list = (uint32_t *)ctx->normals_hard.p;
         // (count and exit ticket are zeroed when the buffer is new; afterwards the serving kernel leaves them zero)
-        if (ctx->normals_hard.p != before) TC_HIP_TRY(ctx, hipMemsetAsync(prm.hard_list, 0, 2 * sizeof(uint32_t), ctx->stream));
+        if (ctx->normals_hard.p != before) TC_HIP_TRY(ctx, hipMemsetAsync(prm.hard_list, 0, 4 * sizeof(uint32_t), ctx->stream));
     }
     struct HardPass {
         tc_context *ctx; const GridView &gv; NormalParams &prm; float *out6;
@@ -1944,7 +1945,16 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     // index is volumetric (NormalParams::tag_policy)
     const int tagged = [] { const char *e = getenv("TC_NORMALS_TAG"); return e ? atoi(e) : 3; }();        // (read per call: the tests flip it)
     prm.tag_policy = tagged >= 3 ? 1 : 0;
-    if (tagged && prm.R0 == 2) {
+    // (a build that read its occupied-cell count back -- edge adaptation, clouds of >= 2^18 points -- lets the HOST apply the same
+    // rule and launch the register-list kernels directly: their fallback copy inside the 19-entry tagged kernel runs at five waves
+    // per SIMD, 4 % slower on a TUM-shaped 1 M-point surface)
+    bool host_says_no = false;
+    if (tagged >= 3 && ix.occ_host_valid) {
+        const unsigned long long occ = ix.occ_host;
+        if (occ * 5ull >= (unsigned long long)ix.geom.ncell && (unsigned long long)ix.geom.n <= occ * 4ull) prm.tag_policy = 0;
+        else host_says_no = true;
+    }
+    if (tagged && !host_says_no && prm.R0 == 2) {
         float ext = 0.0f;
         for (int c = 0; c < 3; ++c) ext = std::max(ext, std::fabs(ix.exact_max[c] - ix.exact_min[c]));
         if (ext < 1e17f && K1 <= 21 && ix.geom.n < (1u << 28)) {

@@ -120,6 +120,8 @@ struct DeviceIndex {
     DevBuf normals;     // float4 * n   (cell-sorted target normals; optional)
     DevBuf vor;         // float4 * n   (ICP target: x, y, z + inscribed-ball bound, icp_target_nn_bound_kernel; optional)
     bool vor_valid = false;     // vor belongs to the current contents of pts (build_index resets it)
+    uint32_t occ_host = 0;      // occupied cells of the final grid, when the build read them back (edge adaptation: clouds of >= 2^18 points)
+    bool occ_host_valid = false;
     DevBuf cell_of;     // u32 * n      (scratch: cell id per original point)
     DevBuf slot;        // u32 * n      (scratch: atomic scatter order)
     DevBuf arrival;     // u32 * n      (scratch: arrival rank of a point inside its cell)
