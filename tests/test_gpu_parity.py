@@ -970,3 +970,28 @@ def test_tagged_key_normals_paths_give_the_register_list_paths_bits(ctx):
             finally: h.close()
         outs.append(_with_env("TC_NORMALS_TAG", mode, run))
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)) and np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
+
+
+def test_a_plateau_of_duplicates_just_beyond_the_neighbourhood_is_cut_off_exactly(ctx):
+    """Fuzz seed 611 case 3568: 1 500 exact duplicates of one point, and a query whose (k+1)-th neighbour lies 9e-6 (relative, squared
+    distance) NEARER than that cluster.  The block-per-point selection (k > 128, isolated points, k-NN export beyond 129) used to
+    cut its ball by a squared radius with 1e-5 safety factors: the cluster could not be cut off, the buffer overflowed and the
+    neighbours were whichever records arrived first.  The cut is now an exact 64-bit key (distance bits, position)."""
+    rng = np.random.default_rng([611, 3568])
+    n = int(rng.choice([2, 3, 7, 40, 300, 1500, 6000])); kind = int(rng.integers(0, 6))
+    assert (n, kind) == (6000, 5)
+    p = rng.random((n, 3)); p[: n // 4] = p[0]
+    p = (p * rng.choice([1e-2, 1.0, 50.0])).astype(np.float32)
+    for k in (129, 200):
+        gpu = ctx.estimate_normals_with_config(p, tc.NormalEstimationConfig(k_neighbors=k, consistent_orientation=False))
+        ref = O.estimate_normals(p, k, consistent_orientation=False)
+        h1.normals_report(p, k, gpu, ref, max_offenders=n)          # raises on an unexplained offender (point 5346 was one)
+    # the exported neighbour lists of the same selection: distances equal to the kd-tree's, entry by entry
+    q = p[[5346, 0, 1499, 1500, 3155]]
+    idx, dist, cnt = ctx.find_k_nearest_batch(p, q, 300)
+    for r in range(len(q)):
+        oi, od = O.KdTree(p).find_k_nearest(q[r], 300)
+        assert cnt[r] == 300 and np.array_equal(dist[r], od), r
+    # ... and duplicates IN the neighbourhood: the plateau is cut by position, lowest first (same rule as every other path)
+    idx2, dist2, cnt2 = ctx.find_k_nearest_batch(p, p[:1], 700)
+    assert cnt2[0] == 700 and np.array_equal(np.sort(idx2[0][:700]), np.arange(700)) and np.all(dist2[0] == 0.0)

@@ -1340,15 +1340,22 @@ __device__ __forceinline__ uint32_t coop_nearest(const GridView &gv, float qx, f
     const float d_box2 = (bxo * bxo + byo * byo + bzo * bzo) * 0.9999f;
     const float r_box = sqrtf(d_box2) + 2.0f * g.h;
     float r = 2.0f * g.h * cbrtf((float)K1 / 17.0f);
-    float lo2 = 0.0f;                           // a squared radius known to hold fewer than K1 records
+    // The ball is cut by KEY = (distance bits << 32 | position), compared exactly: khi = the largest key admitted to the buffer, klo =
+    // a key known to have fewer than K1 records at or below it.  (The cut used to be a squared radius with relative safety factors
+    // of 1e-5: a plateau of 1 500 exact duplicates 9e-6 beyond the (k+1)-th neighbour could not be cut off, the buffer overflowed and
+    // the neighbours were whichever 512 records arrived first -- fuzz seed 611 case 3568.)
+    unsigned long long klo = (!g.clamped && d_box2 > 0.0f) ? ((unsigned long long)__float_as_uint(d_box2) << 32) : 0ull;
+    unsigned long long khi = ((unsigned long long)__float_as_uint(r * r) << 32) | 0xFFFFFFFFull;
     uint32_t total = 0;
     for (int guard = 0; guard < 200; ++guard) {
         if (tid == 0) sh.cnt = 0;
         sh.hist[tid] = 0;
         __syncthreads();
-        const float lim = r * r;
-        const float hlo = fminf(fmaxf(lo2, d_box2), lim);          // the histogram's range: (hlo, lim]
-        const float hscale = 256.0f / fmaxf(lim - hlo, 1e-30f);
+        const float lim = __uint_as_float((uint32_t)(khi >> 32));          // every admitted record lies within this squared radius
+        r = sqrtf(lim) * 1.000001f;
+        // 256 bins over the keys in (klo, khi]: bin = (key - klo - 1) >> sh
+        const unsigned long long range = khi - klo;
+        const int sh_bits = max(0, 64 - (int)__clzll((long long)(range - 1ull) | 1ll) - 8);
         const float ry = r * 1.0001f + 4e-3f * g.h;
         const int y0 = cell_coord(fminf(fmaxf(qy - ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy), y1 = cell_coord(fminf(fmaxf(qy + ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy);
         const int z0 = cell_coord(fminf(fmaxf(qz - ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz), z1 = cell_coord(fminf(fmaxf(qz + ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz);
@@ -1356,10 +1363,11 @@ __device__ __forceinline__ uint32_t coop_nearest(const GridView &gv, float qx, f
         const uint32_t nrows = (uint32_t)ny * (uint32_t)(z1 - z0 + 1);
         auto take = [&](uint32_t j, const float4 &c) {
             const float v = d2_nc(c.x, c.y, c.z, qx, qy, qz);
-            if (v <= lim) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | j;
+            if (key <= khi) {
                 const uint32_t slot = atomicAdd(&sh.cnt, 1u);
-                if (slot < (uint32_t)CAPB) sh.buf[slot] = ((unsigned long long)__float_as_uint(v) << 32) | j;
-                atomicAdd(&sh.hist[min((uint32_t)(fmaxf(v - hlo, 0.0f) * hscale), 255u)], 1u);
+                if (slot < (uint32_t)CAPB) sh.buf[slot] = key;
+                if (key > klo) atomicAdd(&sh.hist[(uint32_t)min((key - klo - 1ull) >> sh_bits, 255ull)], 1u);
             }
         };
         for (uint32_t ri = (uint32_t)tid; ri < nrows; ri += kCoopThreads) {
@@ -1385,35 +1393,35 @@ __device__ __forceinline__ uint32_t coop_nearest(const GridView &gv, float qx, f
         __syncthreads();
         total = sh.cnt;
         if (total > (uint32_t)CAPB) {
-            // too many for the buffer: cut the ball at the histogram bin in which the count reaches K1 (everything binned at
-            // or below it lies within the bin's upper edge: the new ball still holds >= K1 records, and ~1/256 of the excess)
+            // too many for the buffer: cut at the bin in which the count reaches K1 -- the new range holds the K1-th key and 1/256
+            // of the old one; a range of <= 256 keys has one key per bin, the cut is then the K1-th key itself (keys are unique:
+            // the position is part of them), so a plateau of exact ties is cut by position, lowest first, like every other path
             if (tid == 0) {
-                uint32_t cum = 0; int b = 0;
+                uint32_t in_bins = 0;
+                for (int b = 0; b < 256; ++b) in_bins += sh.hist[b];
+                uint32_t cum = total - in_bins;            // records at or below klo
+                int b = 0;
                 for (; b < 255; ++b) { cum += sh.hist[b]; if (cum >= K1) break; }
                 sh.bin = b;
             }
             __syncthreads();
-            const int mybin = sh.bin;
-            const float width = (lim - hlo) / 256.0f;
-            const float new_lim = fminf((hlo + (float)(mybin + 1) * width) * 1.00001f + 1e-37f, lim);
-            const float new_lo = fmaxf(hlo + (float)mybin * width * 0.99999f - 1e-37f, lo2);
-            const bool stuck = !(new_lim < lim) && !(new_lo > lo2);
+            const unsigned long long mybin = (unsigned long long)sh.bin;
+            const unsigned long long width = 1ull << sh_bits;
+            const unsigned long long cut = klo + (mybin + 1ull) * width;          // (bin 255 also holds everything beyond it)
+            if (mybin < 255ull && cut < khi) khi = cut;
+            klo = klo + mybin * width;
             __syncthreads();
-            if (stuck) break;                                       // a plateau of ties wider than the buffer
-            lo2 = (mybin > 0) ? new_lo : fmaxf(lo2, fminf(hlo, new_lim) * 0.99999f);
-            r = sqrtf(new_lim) * 1.000001f;
             continue;
         }
         __syncthreads();
         if (total >= K1 || total >= nfin || r >= r_all) break;
-        lo2 = lim * 0.99999f;                    // too few: grow towards the expected count (at most 2x per step), and at least to the box
+        klo = khi;                                // too few: grow towards the expected count (at most 2x per step), and at least to the box
         float rn = r * fminf(2.0f, fmaxf(1.26f, cbrtf(1.5f * (float)K1 / (float)max(total, 1u))));
         if (r < r_box) rn = fmaxf(rn, r_box);
         r = fminf(rn, r_all);
+        khi = ((unsigned long long)__float_as_uint(r * r) << 32) | 0xFFFFFFFFull;
     }
-    // (total > CAPB here only for a tie plateau wider than the buffer: the launch code sizes CAPB >= 2 K1, such a cloud holds
-    // thousands of points at exactly the same distance; which of them are used is then not reproducible)
-    total = min(total, (uint32_t)CAPB);
+    total = min(total, (uint32_t)CAPB);            // (cannot bind: the loop ends with K1 <= total <= CAPB, or with the whole cloud)
     // bitonic sort of the first n2 = 2^m >= total entries (padding: all ones)
     uint32_t n2 = 2 * kCoopThreads;
     while (n2 < total) n2 <<= 1;
