@@ -23,6 +23,10 @@
 //            symmetric_eigen algorithm (sym_eigen3_f32), column of the smallest eigenvalue; the radius-set path keeps an
 //            f64 closed form (trigonometric estimate + monotone Newton polish + largest cross product).
 //
+//   round 3  on volumetric indexes the list carries the neighbours' positions in the low bits of its keys and the rows of the
+//            block are walked as three flattened groups (knn_tagged below: no phase 2; the register-list path above is its
+//            fallback, and the path for surfaces, dense cells, radius mode and lists beyond 23 entries).
+//
 // Algorithmic HBM bytes per point: 12 (query) + 12*k (neighbours) + 24 (out).
 #include "tc_internal.h"
 
@@ -660,7 +664,8 @@ __device__ __forceinline__ bool knn_survivors(const GridView &gv, const NormalPa
 // (distance, position) order by counting inversions among neighbours within three places (runs of more than four equal truncated
 // values: fallback), and the list is PROVEN to hold the k + 1 nearest: every record that is not in it has a truncated distance
 // >= the last key's, so it suffices that the exact (k + 1)-th distance lies below the last key's truncated value -- with two
-// spare entries (L = k + 3) that fails for ~1e-4 of the points (three consecutive order statistics within 5e-4 relative).
+// spare entries (L = k + 3) that fails for ~1e-5 of uniform points (three consecutive order statistics within 5e-4 relative; measured:
+// 5 - 15 lanes per million).
 // Exactness rule and ring-3 continuation as in the register-list path, judged against the truncation's upper bound.  A lane that
 // fails any check returns false and runs the register-list path: same bits either way.
 constexpr uint32_t kTagMask = 0xFFFu, kKeyInf = 0x7f800000u;
@@ -690,7 +695,7 @@ __device__ __forceinline__ void list_insert_u(uint32_t (&d)[L], uint32_t v) {
     d[0] = d[0] < v ? d[0] : v;
 }
 
-// FLAT (round 3, third form): the lockstep row walk -- a row costs the wave its longest span, ~246 candidate slots per lane for a mean
+// FLAT (round 3, third form): the lockstep row walk -- a row costs the wave its longest span, ~214 candidate slots per lane for a mean
 // need of 80 at k = 16 -- becomes three groups of rows (the central 3 x 3, then the outer 16 in two halves, nearest first): the
 // row logic of a group runs converged for all lanes (windows judged against the limit the list holds when the group starts, the
 // cell_start pairs of all its rows in flight together), the non-empty spans go to a per-lane LDS list, and ONE flattened loop
