@@ -348,9 +348,6 @@ constexpr int kHardRing = 6;        // a search that would go beyond this many r
 // square root for pruning radii: the raw v_sqrt_f32 (1 ulp; the callers add the cell-assignment fuzz, thousands of ulps, as slack;
 // sqrtf's correctly rounded sequence costs ~10 instructions per row: 434 -> 421 us at 1 M points)
 #define TC_FAST_SQRT(x) __builtin_amdgcn_sqrtf(x)
-#ifndef TC_CAP17
-#define TC_CAP17 32      // survivor-list capacity of the k <= 16 instantiation (A/B: build_variant.sh -DTC_CAP17=..)
-#endif
 
 // ---- sorted register list -------------------------------------------------------------------
 template <int L>
@@ -457,201 +454,13 @@ __device__ __forceinline__ bool scan_pruned(const GridView &gv, const float4 &q,
 }
 
 
-// ---- survivor-list k-NN (round 3): one scan, candidates parked in LDS, the list built from survivors only -----------------
-// The sorted register list costs one v_med3 per slot for EVERY candidate of a lockstep scan (17 per candidate at k = 16, paid by
-// the whole wave whatever a pre-filter decides), and the neighbours' positions needed a second scan of the block.  Here a
-// candidate costs its squared distance, one compare and one predicated ds_write: records with d2 <= lim go to a per-lane list
-// of cell-sorted positions in LDS (CAP entries).  `lim` starts at infinity and is set by ROUNDS: whenever some lane of the wave
-// could overflow its list with the next row (count + row length > CAP, known before the row is scanned), every lane inserts its
-// new entries into the register list, takes lim = the (k+1)-th smallest so far -- an upper bound of the final one -- and
-// compacts its list to the entries within it.  Rows are visited nearest first, so the first round (after ~5 of the 25 rows of
-// the ring-2 block) leaves a tight limit and every later row is trimmed (closed form, as in the pruned scans) and filtered by it.
-// After the last row the remaining entries are inserted: d[] = the exact sorted distances of the block, every record within
-// tau = d[k] is in LDS: no second scan.  Exactness rule, ring continuation (visit = insert + append) and tie semantics are the
-// old path's; a lane that overflows its list after a round, or that holds an exact distance tie among its k+1 nearest (the
-// scan-order rule of the old collect pass then decides), returns false and runs the old path.
+// dev build (-DTC_NSTATS): lanes served / fallen back by the tagged-key path, printed per launch
 #ifdef TC_NSTATS
-__device__ unsigned long long g_nstats[16];     // dev build: 0 lanes, 1 ok, 2 ovf in the block, 3 ovf in the continuation, 4 tie, 5 rounds (per wave), 6 waves, 7 waves with a fallback lane, 8 continuation lanes, 9 sum of final cnt, 10 sum of candidates scanned
+__device__ unsigned long long g_nstats[16];     // 0 lanes, 1 served, 2 needs a ring beyond 3 / a span beyond 65535 records, 3 a check failed, 6 waves, 7 waves with a fallback lane
 #define TC_NSTAT(i, v) atomicAdd(&g_nstats[i], (unsigned long long)(v))
 #else
 #define TC_NSTAT(i, v) do { } while (0)
 #endif
-// (dy + 2) | (dz + 2) << 3 of the ring-2 block's 25 rows, nearest first, ten rows per word: the row order costs scalar shifts, no load
-constexpr unsigned long long kRowCodes[3] = {
-#define TC_RC(dy, dz) ((unsigned long long)(((dy) + 2) | (((dz) + 2) << 3)))
-    TC_RC(0, 0) | TC_RC(-1, 0) << 6 | TC_RC(1, 0) << 12 | TC_RC(0, -1) << 18 | TC_RC(0, 1) << 24 | TC_RC(-1, -1) << 30 | TC_RC(1, -1) << 36 |
-        TC_RC(-1, 1) << 42 | TC_RC(1, 1) << 48 | TC_RC(-2, 0) << 54,
-    TC_RC(2, 0) | TC_RC(0, -2) << 6 | TC_RC(0, 2) << 12 | TC_RC(-2, -1) << 18 | TC_RC(2, -1) << 24 | TC_RC(-2, 1) << 30 | TC_RC(2, 1) << 36 |
-        TC_RC(-1, -2) << 42 | TC_RC(1, -2) << 48 | TC_RC(-1, 2) << 54,
-    TC_RC(1, 2) | TC_RC(-2, -2) << 6 | TC_RC(2, -2) << 12 | TC_RC(-2, 2) << 18 | TC_RC(2, 2) << 24 | 63ull << 30};
-#undef TC_RC
-
-template <int L, int BLOCK, int CAP, bool EXT>
-__device__ __forceinline__ bool knn_survivors(const GridView &gv, const NormalParams &prm, uint32_t p, const float4 &q, int cx, int cy, int cz,
-                                              float mf, float (&d)[L], uint32_t *ldsA, uint8_t *ldsB, uint32_t &cnt_out, int &self_r_out,
-                                              int &R_out
-#ifdef TC_PHASE_STAMPS
-                                              , unsigned long long (&ph)[8], unsigned long long &tl
-#endif
-                                              ) {
-    static_assert(CAP % 4 == 0 && CAP > L, "survivor list capacity");
-    const GridGeom &g = gv.g;
-    const uint32_t K1 = prm.k + 1;
-    constexpr int R = 2;
-    uint32_t cnt = 0, n_ins = 0;
-    float lim = INFINITY;
-    bool ovf = false;
-#define TC_KTH_F(OUT)                                                               \
-    do {                                                                            \
-        float tk_ = d[0];                                                           \
-        _Pragma("unroll") for (int t = 1; t < L; ++t) tk_ = ((uint32_t)t == prm.k) ? d[t] : tk_; \
-        (OUT) = tk_;                                                                \
-    } while (0)
-    // the loops over the LDS list take four entries per step (their records requested together: a lone gather per step is a
-    // dependent LDS -> L1 round trip, and at this kernel's occupancy those chains were a third of a wave's time)
-#define TC_LOAD4(e_, n_)                                                                                             \
-    const uint32_t j0 = ldsA[(e_) * BLOCK], j1 = ldsA[min((e_) + 1, (n_) - 1) * BLOCK], j2 = ldsA[min((e_) + 2, (n_) - 1) * BLOCK], \
-                   j3 = ldsA[min((e_) + 3, (n_) - 1) * BLOCK];                                                        \
-    const float4 c0 = gv.pts[j0], c1 = gv.pts[j1], c2 = gv.pts[j2], c3 = gv.pts[j3];                                  \
-    const float v0 = d2_nc(c0.x, c0.y, c0.z, q.x, q.y, q.z), v1 = d2_nc(c1.x, c1.y, c1.z, q.x, q.y, q.z),             \
-                v2 = d2_nc(c2.x, c2.y, c2.z, q.x, q.y, q.z), v3 = d2_nc(c3.x, c3.y, c3.z, q.x, q.y, q.z)
-    auto insert_new = [&]() {       // entries [n_ins, cnt) into the register list
-        for (uint32_t e = n_ins; e < cnt; e += 4) {
-            TC_LOAD4(e, cnt);
-            list_insert<L>(d, v0);
-            if (e + 1 < cnt) list_insert<L>(d, v1);
-            if (e + 2 < cnt) list_insert<L>(d, v2);
-            if (e + 3 < cnt) list_insert<L>(d, v3);
-        }
-        n_ins = cnt;
-    };
-    // the x window of block row `code` the ball of `lim` reaches -> its record span [s, e) (empty: s == e)
-    auto row_span = [&](uint32_t code, uint32_t &s, uint32_t &e) {
-        s = 0; e = 0;
-        const int y = cy + (int)(code & 7u) - 2, z = cz + (int)(code >> 3) - 2;
-        if (ovf || y < 0 || y >= g.gy || z < 0 || z >= g.gz) return;
-        const float gzv = axis_gap_n<EXT>(q.z, g.minz, g.h, z, g.gz - 1), gyv = axis_gap_n<EXT>(q.y, g.miny, g.h, y, g.gy - 1);
-        const float rg = gyv * gyv + gzv * gzv;
-        if (!(rg <= lim)) return;
-        int xa = max(cx - R, 0), xb = min(cx + R, g.gx - 1);
-        const float r = TC_FAST_SQRT(fmaxf(lim - rg, 0.0f)) + 4e-3f * g.h;
-        const float fa = fminf(fmaxf((q.x - r - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
-        const float fb = fmaxf(fminf((q.x + r - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
-        xa = max(xa, (int)fa);
-        xb = min(xb, (int)fb);
-        if (xa > xb) return;
-        const uint32_t row = ((uint32_t)z * g.gy + y) * g.gx;
-        s = gv.cell_start[row + xa]; e = gv.cell_start[row + xb + 1];
-    };
-    uint32_t s, e;
-    row_span((uint32_t)(kRowCodes[0] & 63ull), s, e);
-    for (int w = 0; w < 3; ++w) {
-        unsigned long long codes = kRowCodes[w] >> 6;          // the NEXT row's code is the low six bits
-        if (w < 2) codes |= (kRowCodes[w + 1] & 63ull) << 54;
-        const int rows = w == 0 ? 10 : (w == 1 ? 10 : 5);
-        for (int i = 0; i < rows; ++i, codes >>= 6) {
-            // the next row's span is requested now, with the limit as it stands (a round of this row may shrink it: the window
-            // is then a little wide, the filter below uses the limit of its own time)
-            uint32_t sn = 0, en = 0;
-            const uint32_t next = (uint32_t)(codes & 63ull);
-            if (next != 63u) row_span(next, sn, en);
-            for (;;) {
-                if (__any((int)(e - s > (uint32_t)CAP - cnt))) {
-                    TC_NSTAMP(1);
-                    // a ROUND: list <- new entries, limit <- the (k+1)-th smallest so far, LDS list <- the entries within it
-                    insert_new();
-                    float nl;
-                    TC_KTH_F(nl);
-                    lim = fminf(lim, nl);
-                    uint32_t wr = 0;
-                    for (uint32_t t = 0; t < cnt; t += 4) {
-                        TC_LOAD4(t, cnt);
-                        if (v0 <= lim) { ldsA[wr * BLOCK] = j0; ++wr; }
-                        if (t + 1 < cnt && v1 <= lim) { ldsA[wr * BLOCK] = j1; ++wr; }
-                        if (t + 2 < cnt && v2 <= lim) { ldsA[wr * BLOCK] = j2; ++wr; }
-                        if (t + 3 < cnt && v3 <= lim) { ldsA[wr * BLOCK] = j3; ++wr; }
-                    }
-                    cnt = wr; n_ins = wr;
-                    if ((threadIdx.x & 63) == 0) TC_NSTAT(5, 1);
-                    if (cnt >= (uint32_t)CAP && s < e) { ovf = true; e = s; en = sn; }      // a tie plateau fills the list: the old path's job
-                    TC_NSTAMP(2);
-                }
-                const uint32_t stop = s + min(e - s, (uint32_t)CAP - cnt);      // a row longer than the room left is taken in pieces
-                for (uint32_t j = s; j < stop; j += 4) {
-                    const float4 c0 = gv.pts[j], c1 = gv.pts[j + 1], c2 = gv.pts[j + 2], c3 = gv.pts[j + 3];
-                    if (d2_nc(c0.x, c0.y, c0.z, q.x, q.y, q.z) <= lim) { ldsA[cnt * BLOCK] = j; ++cnt; }
-                    if (j + 1 < stop && d2_nc(c1.x, c1.y, c1.z, q.x, q.y, q.z) <= lim) { ldsA[cnt * BLOCK] = j + 1; ++cnt; }
-                    if (j + 2 < stop && d2_nc(c2.x, c2.y, c2.z, q.x, q.y, q.z) <= lim) { ldsA[cnt * BLOCK] = j + 2; ++cnt; }
-                    if (j + 3 < stop && d2_nc(c3.x, c3.y, c3.z, q.x, q.y, q.z) <= lim) { ldsA[cnt * BLOCK] = j + 3; ++cnt; }
-                }
-                s = stop;
-                if (!__any((int)(s < e))) break;
-            }
-            s = sn; e = en;
-        }
-    }
-    TC_NSTAT(0, 1);
-    TC_NSTAMP(1);
-    if (ovf) { TC_NSTAT(2, 1); return false; }
-    insert_new();
-    float tau;
-    int Rc = R;
-    for (;;) {      // exactness / ring continuation: the old path's rules (normals_point), visit = insert + append
-        TC_KTH_F(tau);
-        const bool covers = (cx - Rc <= 0) && (cx + Rc >= g.gx - 1) && (cy - Rc <= 0) && (cy + Rc >= g.gy - 1) && (cz - Rc <= 0) && (cz + Rc >= g.gz - 1);
-        const float bound = ((float)Rc + mf - 2e-3f) * g.h;
-        if (covers || tau <= bound * bound) break;
-        const int Rin = Rc;
-        TC_NSTAT(8, 1);
-        if (tau == INFINITY) Rc += max(1, Rc / 2);
-        else Rc = max(Rc + 1, (int)fminf(ceilf(sqrtf(tau) * g.inv_h - mf + 0.01f), 1.0e9f));
-        const bool growing = tau == INFINITY || Rc > Rin + 1;
-        float live_lim = tau;
-        const bool touched = scan_pruned<EXT, true>(gv, q, cx, cy, cz, Rin, Rc, live_lim, [&](uint32_t j, const float4 &c) {
-            const float v = d2_nc(c.x, c.y, c.z, q.x, q.y, q.z);
-            if (v <= live_lim) {
-                list_insert<L>(d, v);
-                if (cnt < (uint32_t)CAP) { ldsA[cnt * BLOCK] = j; ++cnt; } else ovf = true;
-                if (growing) live_lim = d[L - 1];
-            }
-        }, &live_lim);
-        if (!touched) { TC_KTH_F(tau); break; }
-    }
-    if (ovf) { TC_NSTAT(3, 1); return false; }
-    TC_NSTAT(9, cnt);
-    TC_NSTAMP(3);
-    // exact ties among the k+1 nearest (or at their boundary): the old path's scan-order rule decides who is in and in which order
-    bool tie = false;
-#pragma unroll
-    for (int t = 0; t + 1 < L; ++t) tie = tie || (d[t] == d[t + 1] && d[t] <= tau && d[t] < INFINITY);
-    // ranks: entry -> position in ascending-distance order (no ties: the number of list values below it)
-    uint32_t taken = 0, n_at_tau = 0;
-    int self_r = -1;
-    auto rank_one = [&](uint32_t t, uint32_t j, float v) {
-        if (v <= tau) {
-            uint32_t r = 0;
-#pragma unroll
-            for (int i = 0; i < L; ++i) r += (d[i] < v) ? 1u : 0u;
-            ldsB[r * BLOCK] = (uint8_t)t;
-            ++taken;
-            n_at_tau += (v == tau) ? 1u : 0u;
-            if (j == p) self_r = (int)r;
-        }
-    };
-    for (uint32_t t = 0; t < cnt; t += 4) {
-        TC_LOAD4(t, cnt);
-        rank_one(t, j0, v0);
-        if (t + 1 < cnt) rank_one(t + 1, j1, v1);
-        if (t + 2 < cnt) rank_one(t + 2, j2, v2);
-        if (t + 3 < cnt) rank_one(t + 3, j3, v3);
-    }
-    if (tie || n_at_tau > 1u || taken > K1) { TC_NSTAT(4, 1); return false; }
-    TC_NSTAT(1, 1);
-    cnt_out = taken; self_r_out = self_r; R_out = Rc;
-    return true;
-#undef TC_KTH_F
-#undef TC_LOAD4
-}
 
 // ---- tagged-key k-NN (round 3): the neighbour's position rides in the low bits of its list key -----------------------------
 // The register-list path scans the neighbourhood twice: once for the sorted distances, once more to find WHICH records they
@@ -999,27 +808,9 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
     bool use_radius = false;
 #pragma unroll
     for (int t = 0; t < LO; ++t) d[t] = INFINITY;
-    // the survivor-list path (k-NN mode): on success d[] holds the sorted distances, ldsA / ldsB the k+1 nearest and their ranks
     bool have = false;
     uint32_t cnt = 0;
     int self_r = -1;
-    if constexpr (CAP > 0 && !RADIUS) {
-        TC_NSTAMP(0);
-#ifdef TC_PHASE_STAMPS
-        have = knn_survivors<L, BLOCK, CAP, EXT>(gv, prm, p, q, cx, cy, cz, mf, d, ldsA, ldsB, cnt, self_r, R, ph, tl);
-#else
-        have = knn_survivors<L, BLOCK, CAP, EXT>(gv, prm, p, q, cx, cy, cz, mf, d, ldsA, ldsB, cnt, self_r, R);
-#endif
-#ifdef TC_NSTATS
-        if ((threadIdx.x & 63) == 0) TC_NSTAT(6, 1);
-        if (__any((int)!have) && (threadIdx.x & 63) == 0) TC_NSTAT(7, 1);
-#endif
-        if (!have) {
-#pragma unroll
-            for (int t = 0; t < LO; ++t) d[t] = INFINITY;
-            R = prm.R0;
-        }
-    }
     if constexpr (CAP < 0 && !RADIUS) {
         // the tagged-key path (knn_tagged): on success ldsA / ldsB hold the k+1 nearest and their ranks, d[1] the distance to the
         // nearest other record; a lane it cannot serve runs the register-list path below
@@ -1225,7 +1016,7 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
         float cxx = 0.0f, cxy = 0.0f, cxz = 0.0f, cyy = 0.0f, cyz = 0.0f, czz = 0.0f;
         const float nf = (float)npts;
-        float mx, my, mz;
+        float mx = 0.0f, my = 0.0f, mz = 0.0f;
         bool batched = false;
 #ifndef TC_TAG_NOBATCH
         if constexpr (CAP < 0 && !RADIUS) batched = have;
@@ -1583,7 +1374,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
 
 template <int L, int BLOCK, bool RADIUS, bool EXT, int CAP = 0>
 __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
-    __shared__ uint32_t ldsA[(CAP > L ? CAP : L) * BLOCK];
+    __shared__ uint32_t ldsA[L * BLOCK];
     __shared__ uint8_t ldsB[L * BLOCK];       // ranks as bytes: 88 instead of 136 B of LDS per lane -> 7 instead of 4 waves per SIMD
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t p = prm.p_begin + lb * BLOCK + threadIdx.x;
@@ -1869,7 +1660,7 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
             double m[8] = {0}; size_t cnt = 0;
             for (size_t b = 0; b < nb; ++b) { if (!h[8 * b + 1]) continue; ++cnt; for (int i = 0; i < 8; ++i) m[i] += (double)h[8 * b + i]; }
             for (int i = 0; i < 8; ++i) m[i] /= std::max<size_t>(cnt, 1);
-            fprintf(stderr, "[tc] normals wave 0 phases, mean s_memtime ticks over %zu blocks: setup %.0f  block scan (+ list) %.0f  continuation (survivor path: rounds) %.0f  collect (survivor path: final inserts + continuation) %.0f  rank %.0f  centroid + covariance %.0f  eigen + orient %.0f  store %.0f\n",
+            fprintf(stderr, "[tc] normals wave 0 phases, mean s_memtime ticks over %zu blocks: setup %.0f  block scan + list (tagged path: everything up to the neighbour list) %.0f  continuation %.0f  collect %.0f  rank %.0f  centroid + covariance %.0f  eigen + orient %.0f  store %.0f\n",
                     cnt, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
         }
     } stamp_dump{ctx, stamp_blocks, prm.stamps != nullptr};
@@ -1917,8 +1708,8 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
             (void)hipStreamSynchronize(st);
             unsigned long long h[16];
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nstats), sizeof h);
-            fprintf(stderr, "[tc] normals survivor path: lanes %llu ok %llu ovf(block) %llu ovf(cont) %llu tie %llu | rounds/wave %.2f | waves %llu with fallback %llu | continuation calls %llu | mean final list %.1f\n",
-                    h[0], h[1], h[2], h[3], h[4], (double)h[5] / (double)(h[6] ? h[6] : 1), h[6], h[7], h[8], (double)h[9] / (double)(h[0] ? h[0] : 1));
+            fprintf(stderr, "[tc] normals tagged path: lanes %llu served %llu | beyond ring 3 / oversized span %llu | a check failed %llu | waves %llu with a fallback lane %llu\n",
+                    h[0] + h[2], h[1], h[2], h[3], h[6], h[7]);
         }
     } stat_dump{ctx->stream};
 #endif
@@ -1946,11 +1737,6 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
         TC_HIP_TRY(ctx, hipGetLastError());
         return TC_OK;
     }
-    // TC_NORMALS_FAST=1: the survivor-list path (knn_survivors) for k <= 20 -- bit-identical results, measured in round 3 and NOT
-    // faster on the whole (198 M instead of 226 M VALU instructions per launch at 1 M points / k = 16, but its LDS
-    // list holds the kernel to 4 waves per SIMD: 431-445 us against 435; k = 10: 309 against 334; depth-map surfaces 470 against
-    // 406): the register-list path stays the default.
-    static const int fast = [] { const char *e = getenv("TC_NORMALS_FAST"); return e ? atoi(e) : 0; }();
     // TC_NORMALS_TAG: the tagged-key path (knn_tagged) -- the list carries the neighbours' positions, no collect pass.  Needs
     // distances that cannot overflow (the keys are compared as integers; an infinite distance with a tag would read as NaN in the
     // pruning radius) and two spare list entries.
@@ -1985,21 +1771,10 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
             return TC_OK;
         }
     }
-    if (!fast) {
-        if (K1 <= 9)       launch_variant<9, 256>(ctx->stream, gv, prm, d_out6, ctx);
-        else if (K1 <= 11) launch_variant<11, 256>(ctx->stream, gv, prm, d_out6, ctx);
-        else if (K1 <= 17) launch_variant<17, 256>(ctx->stream, gv, prm, d_out6, ctx);
-        else if (K1 <= 21) launch_variant<21, 256>(ctx->stream, gv, prm, d_out6, ctx);
-        else if (K1 <= 33) launch_variant<33, 128>(ctx->stream, gv, prm, d_out6, ctx);
-        else if (K1 <= 65) launch_variant<65, 64>(ctx->stream, gv, prm, d_out6, ctx);
-        else               launch_variant<129, 64>(ctx->stream, gv, prm, d_out6, ctx);
-        TC_HIP_TRY(ctx, hipGetLastError());
-        return TC_OK;
-    }
-    if (K1 <= 9)       launch_variant<9, 128, false, 24>(ctx->stream, gv, prm, d_out6, ctx);
-    else if (K1 <= 11) launch_variant<11, 128, false, 28>(ctx->stream, gv, prm, d_out6, ctx);
-    else if (K1 <= 17) launch_variant<17, 128, false, TC_CAP17>(ctx->stream, gv, prm, d_out6, ctx);
-    else if (K1 <= 21) launch_variant<21, 128, false, 48>(ctx->stream, gv, prm, d_out6, ctx);
+    if (K1 <= 9)       launch_variant<9, 256>(ctx->stream, gv, prm, d_out6, ctx);
+    else if (K1 <= 11) launch_variant<11, 256>(ctx->stream, gv, prm, d_out6, ctx);
+    else if (K1 <= 17) launch_variant<17, 256>(ctx->stream, gv, prm, d_out6, ctx);
+    else if (K1 <= 21) launch_variant<21, 256>(ctx->stream, gv, prm, d_out6, ctx);
     else if (K1 <= 33) launch_variant<33, 128>(ctx->stream, gv, prm, d_out6, ctx);
     else if (K1 <= 65) launch_variant<65, 64>(ctx->stream, gv, prm, d_out6, ctx);
     else               launch_variant<129, 64>(ctx->stream, gv, prm, d_out6, ctx);

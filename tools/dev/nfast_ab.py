@@ -1,6 +1,7 @@
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-"""dev: the survivor-list normals path against the register-list path (TC_NORMALS_FAST=0), bit for bit, + kernel times.
-usage: python tools/dev/nfast_ab.py run <tag>      (in a process with TC_NORMALS_FAST set as wanted; writes /tmp/nfast_<tag>.npz)
+"""dev: two settings of the normals kernel family (TC_NORMALS_TAG = 0 register list, 1 tagged keys, 2 + flattened row groups, 3 / unset
+policy) on 26 clouds, bit for bit, + kernel times.
+usage: python tools/dev/nfast_ab.py run <tag>      (in a process with TC_NORMALS_TAG set as wanted; writes /tmp/nfast_<tag>.npz)
        python tools/dev/nfast_ab.py cmp <a> <b>"""
 import numpy as np
 
