@@ -1394,6 +1394,12 @@ __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, Nor
 #ifndef TC_TAG_WAVES
 #define TC_TAG_WAVES 6
 #endif
+// One wave per block for the flattened tagged kernels: a block's LDS and wave slots are held until its slowest wave is done, and a
+// wave's time spreads over p10 - p90 = 106 k - 179 k cycles: 320 -> 293 us at 1 M uniform points / k = 16 (128 threads: 297; no effect
+// at k = 10, and none on the register-list kernels: 438 -> 433)
+#ifndef TC_TAG_BLOCK
+#define TC_TAG_BLOCK 64
+#endif
 template <int L, int BLOCK, bool EXT, int CAP>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(L >= 19 ? TC_TAG_WAVES - 1 : TC_TAG_WAVES, L >= 19 ? TC_TAG_WAVES - 1 : TC_TAG_WAVES))) normals_tagged_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
     __shared__ uint32_t ldsA[(L > 18 ? L : 18) * BLOCK];        // (the flattened walk parks up to nine spans of two words here)
@@ -1660,6 +1666,20 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
             double m[8] = {0}; size_t cnt = 0;
             for (size_t b = 0; b < nb; ++b) { if (!h[8 * b + 1]) continue; ++cnt; for (int i = 0; i < 8; ++i) m[i] += (double)h[8 * b + i]; }
             for (int i = 0; i < 8; ++i) m[i] /= std::max<size_t>(cnt, 1);
+            {
+                // spread of a block's wave-0 time (all phases) and where the long ones sit in launch order
+                std::vector<double> tot;
+                for (size_t b = 0; b < nb; ++b) { if (!h[8 * b + 1]) continue; double t = 0; for (int i = 0; i < 8; ++i) t += (double)h[8 * b + i]; tot.push_back(t); }
+                if (!tot.empty()) {
+                    std::vector<double> srt = tot;
+                    std::sort(srt.begin(), srt.end());
+                    auto q = [&](double f) { return srt[std::min(srt.size() - 1, (size_t)(f * (double)srt.size()))]; };
+                    const size_t tenth = std::max<size_t>(tot.size() / 10, 1);
+                    fprintf(stderr, "[tc] normals wave 0 total ticks per block: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f | mean by tenth of the launch order:", q(0.1), q(0.5), q(0.9), q(0.99), srt.back());
+                    for (size_t d0 = 0; d0 + tenth <= tot.size(); d0 += tenth) { double a = 0; for (size_t i = d0; i < d0 + tenth; ++i) a += tot[i]; fprintf(stderr, " %.0f", a / (double)tenth); }
+                    fprintf(stderr, "\n");
+                }
+            }
             fprintf(stderr, "[tc] normals wave 0 phases, mean s_memtime ticks over %zu blocks: setup %.0f  block scan + list (tagged path: everything up to the neighbour list) %.0f  continuation %.0f  collect %.0f  rank %.0f  centroid + covariance %.0f  eigen + orient %.0f  store %.0f\n",
                     cnt, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
         }
@@ -1758,10 +1778,10 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
         for (int c = 0; c < 3; ++c) ext = std::max(ext, std::fabs(ix.exact_max[c] - ix.exact_min[c]));
         if (ext < 1e17f && K1 <= 21 && ix.geom.n < (1u << 28)) {
             if (tagged >= 2) {
-                if (K1 <= 9)       launch_variant<11, 256, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
-                else if (K1 <= 11) launch_variant<13, 256, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
-                else if (K1 <= 17) launch_variant<19, 256, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
-                else               launch_variant<23, 256, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
+                if (K1 <= 9)       launch_variant<11, TC_TAG_BLOCK, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
+                else if (K1 <= 11) launch_variant<13, TC_TAG_BLOCK, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
+                else if (K1 <= 17) launch_variant<19, TC_TAG_BLOCK, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
+                else               launch_variant<23, TC_TAG_BLOCK, false, -2>(ctx->stream, gv, prm, d_out6, ctx);
             }
             else if (K1 <= 9)  launch_variant<11, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
             else if (K1 <= 11) launch_variant<13, 256, false, -1>(ctx->stream, gv, prm, d_out6, ctx);
