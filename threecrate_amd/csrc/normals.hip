@@ -610,7 +610,13 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
                 tag = adv ? (n2 >> 16) : tag;
                 e = adv ? (more ? n1 + (n2 & 0xFFFFu) : 0u) : e;
             } while (__any((int)(j < e)));
-            live0 = tight ? lim_hi(d[L - 3]) : lim_of(d[L - 1]);
+            // (three times per lane: the (k+1)-th key by a select over the list is affordable here whatever k is)
+            {
+                uint32_t kk = d[0];
+#pragma unroll
+                for (int t = 1; t < L; ++t) kk = ((uint32_t)t == prm.k) ? d[t] : kk;
+                live0 = lim_hi(kk);
+            }
         }
         if (fail) { TC_NSTAT(2, 1); return false; }
     } else {

@@ -111,6 +111,20 @@ def explain_by_replay(grun, orun, src, tgt, init, iters, thr, ext, nrm_t=None):
                 reach = cond * 1e-6 * float(np.linalg.norm(x)) * (1.0 + coord)
                 if fro <= 10.0 * reach:
                     return True, f"ill-conditioned 6x6 system at iteration {k} (cond {cond:.2e}, {len(c)} pairs): transforms {fro:.3e} apart, rounding reaches {reach:.3e}"
+            if nrm_t is None and len(o.correspondences) >= 1:
+                # point-to-point with a rank-deficient cross-covariance (a handful of pairs, several sources on one target point, pairs
+                # on a line): the optimal rotation is a FAMILY (any turn about the remaining axis), which member comes out is the SVD
+                # routine's business (registration.rs:163-201 through nalgebra's SVD; here a one-sided Jacobi in f64) -- explained iff
+                # the second singular value vanishes and both sides' transforms leave the same residual on the pairs
+                Tm = po.transformation if po is not None else (O.IDENTITY if init is None else np.asarray(init, np.float32))
+                c = o.correspondences
+                sp = O.isometry_apply(Tm, src)[c[:, 0]].astype(np.float64); q = tgt[c[:, 1]].astype(np.float64)
+                sv = np.linalg.svd((sp - sp.mean(0)).T @ (q - q.mean(0)), compute_uv=False)
+                res = lambda r_: float(np.mean(np.sum((O.isometry_apply(r_.transformation, src)[c[:, 0]].astype(np.float64) - q) ** 2, axis=1)))
+                rg, ro = res(g), res(o)
+                if sv[1] <= 1e-6 * max(sv[0], 1e-300) and abs(rg - ro) <= 1e-4 * max(rg, ro) + 1e-30:
+                    return True, (f"rank-deficient Kabsch at iteration {k} ({len(c)} pairs, singular values {sv[0]:.2e} {sv[1]:.2e} {sv[2]:.2e}): the optimal "
+                                  f"rotation is not unique, both sides' residuals {rg:.6e} / {ro:.6e} agree")
             return False, f"same pairs up to iteration {k} but transforms {fro:.3e} apart"
         if g.converged: return True, "agree until both stop"
         ppg, ppo, pg, po = pg, po, g, o
