@@ -217,7 +217,9 @@ tc_status    tc_cloud_upload(tc_context *ctx, const float *xyz, size_t n, tc_clo
 tc_status    tc_cloud_upload_device(tc_context *ctx, const float *d_xyz, size_t n, tc_cloud **out);   /* HBM -> HBM copy */
 size_t       tc_cloud_size(const tc_cloud *cloud);
 const float *tc_cloud_points_device(const tc_cloud *cloud);      /* n x 3, device */
-const float *tc_cloud_normals_device(const tc_cloud *cloud);     /* n x 6 NormalPoint3f in input order, or NULL if not kept */
+const float *tc_cloud_normals_device(const tc_cloud *cloud);     /* n x 6 NormalPoint3f in input order; NULL if the handle has no normals.
+                                                                  * Only the host-output estimate keeps that copy; otherwise it is made from the
+                                                                  * cell-sorted normals by this call (one kernel + a stream synchronisation). */
 tc_status    tc_cloud_estimate_normals(tc_cloud *cloud, const tc_normal_config *config, float *out_normal_points);
 tc_status    tc_cloud_estimate_normals_device(tc_cloud *cloud, const tc_normal_config *config, float *d_out_normal_points);
 tc_status    tc_cloud_set_normals_device(tc_cloud *cloud, const float *d_normals, size_t n_normals, size_t normal_stride);

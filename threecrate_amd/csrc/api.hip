@@ -559,8 +559,12 @@ tc_status tc_multiscale_icp_point_to_point(tc_context *ctx, const float *source,
     tc_status st = TC_OK;
     if ((st = ensure(ctx, full_s, ns * 12)) || (st = ensure(ctx, full_t, nt * 12)) || (st = ensure(ctx, down_s, ns * 12)) ||
         (st = ensure(ctx, down_t, nt * 12))) { cleanup(); return st; }
-    (void)hipMemcpyAsync(full_s.p, source, ns * 12, hipMemcpyHostToDevice, ctx->stream);
-    (void)hipMemcpyAsync(full_t.p, target, nt * 12, hipMemcpyHostToDevice, ctx->stream);
+    if (hipMemcpyAsync(full_s.p, source, ns * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(full_t.p, target, nt * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        cleanup();
+        return fail(ctx, TC_GPU, "multiscale ICP: uploading the caller's clouds failed");
+    }
     float cur[7];
     std::memcpy(cur, init, sizeof(cur));
     uint64_t total_iters = 0;

@@ -161,7 +161,23 @@ tc_status tc_cloud_upload(tc_context *ctx, const float *xyz, size_t n, tc_cloud 
 tc_status tc_cloud_upload_device(tc_context *ctx, const float *d_xyz, size_t n, tc_cloud **out) { return cloud_create(ctx, d_xyz, n, false, out); }
 size_t tc_cloud_size(const tc_cloud *c) { return c ? c->n : 0; }
 const float *tc_cloud_points_device(const tc_cloud *c) { return c ? (const float *)c->xyz.p : nullptr; }
-const float *tc_cloud_normals_device(const tc_cloud *c) { return (c && c->has_normals6) ? (const float *)c->normals6.p : nullptr; }
+// The input-order N x 6 copy is kept by the host-output variant of tc_cloud_estimate_normals; after the device-output variant,
+// a NULL output or tc_cloud_set_normals_device the handle holds the cell-sorted normals only and the copy is made here on demand.
+const float *tc_cloud_normals_device(const tc_cloud *cc) {
+    tc_cloud *c = const_cast<tc_cloud *>(cc);
+    if (!c || c->n == 0) return nullptr;
+    if (c->has_normals6) return (const float *)c->normals6.p;
+    if (!c->has_normals || !c->indexed) return nullptr;
+    tc_context *ctx = c->ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (ensure(ctx, c->normals6, c->n * 6 * sizeof(float)) != TC_OK) return nullptr;
+    hipLaunchKernelGGL(cloud_unsort_normals_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float4 *)c->ix.pts.p, (const float4 *)c->ix.normals.p, (const float *)c->xyz.p, (uint32_t)c->n,
+                       (float *)c->normals6.p);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+    c->has_normals6 = true;
+    return (const float *)c->normals6.p;
+}
 
 static tc_status cloud_normals(tc_cloud *c, const tc_normal_config *cfg, float *out, bool out_on_host, bool keep6) {
     if (!c || !cfg) return TC_INVALID_DATA;
@@ -170,6 +186,10 @@ static tc_status cloud_normals(tc_cloud *c, const tc_normal_config *cfg, float *
     if (cfg->k_neighbors < 3) return fail(ctx, TC_INVALID_DATA, "k_neighbors must be at least 3");   // :265-269
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const float min_h = cfg->has_radius ? cfg->radius * 0.5005f : 0.0f;
+    // the handle's previous normals are superseded from here on: should the index be rebuilt for this k, ensure_index must not
+    // spend an unsort kernel and an n x 24 B block on recovering them
+    c->has_normals = false;
+    c->has_normals6 = false;
     if (tc_status s = ensure_index(c, normals_cell_factor(cfg->k_neighbors, c->n >= kAdaptMinPoints), normals_target_ppo(cfg->k_neighbors), min_h)) return s;
     if (tc_status s = ensure(ctx, c->ix.normals, c->n * sizeof(float4))) return s;
     // the N x 6 records in input order (24-byte scattered stores) are only produced when somebody wants them
@@ -204,6 +224,9 @@ tc_status tc_cloud_set_normals_device(tc_cloud *c, const float *d_normals, size_
     if (stride < 3) return fail(ctx, TC_INVALID_DATA, "normal_stride must be >= 3");
     if (c->n == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the handle's previous normals (estimated or set) are superseded: were has_normals left set, an index rebuild inside
+    // adopt_normals would "recover" the OLD normals into the input-order copy and mark them valid
+    c->has_normals = false;
     c->has_normals6 = false;
     if (tc_status s = adopt_normals(c, d_normals, stride)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the caller's array is free on return

@@ -115,18 +115,32 @@ tc_status comm_allgather(tc_comm *c, void *d_buf, size_t bytes_per_rank) {
 tc_status comm_agree(tc_comm *c, tc_status local) {
     if (!c || c->nranks <= 1) return local;
     tc_context *ctx = c->ctx;
-    if (!c->agree_word && hipMalloc(&c->agree_word, 64) != hipSuccess) c->agree_word = nullptr;
-    // (no device word: this rank cannot take part -- it still has to tell: the peers' all-reduce would wait for it.  Nothing
-    // sane is left to do but to fail loudly; a 64-byte allocation failing means the device is gone.)
-    if (!c->agree_word) return fail(ctx, TC_GPU, "communicator: cannot allocate the agreement word");
+    // The agreement word is allocated when the communicator is created (alloc_agree_word), so that nothing fallible sits in
+    // front of the all-reduce here: whatever happens to this rank on the way, it JOINS the collective -- a rank that returned
+    // early would leave its peers waiting in it for ever -- and reports its own failure afterwards.
+    if (!c->agree_word) return fail(ctx, TC_GPU, "communicator: no agreement word (created for one rank?)");
     uint32_t *h = (uint32_t *)((char *)ctx->pinned + 2048 + 8192 + 128);
     *h = local == TC_OK ? 0u : 1u;
-    TC_HIP_TRY(ctx, hipMemcpyAsync(c->agree_word, h, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (tc_status s = comm_allreduce_u32(c, (uint32_t *)c->agree_word, 1)) return s;
-    TC_HIP_TRY(ctx, hipMemcpyAsync(h, c->agree_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (local != TC_OK) return local;
+    tc_status mine = local;
+    if (hipMemcpyAsync(c->agree_word, h, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess && mine == TC_OK)
+        mine = fail(ctx, TC_GPU, "communicator: writing the agreement word failed");
+    const tc_status ar = comm_allreduce_u32(c, (uint32_t *)c->agree_word, 1);
+    if (mine == TC_OK && ar != TC_OK) mine = ar;
+    if (hipMemcpyAsync(h, c->agree_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess && mine == TC_OK)
+        mine = fail(ctx, TC_GPU, "communicator: reading the agreement word failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && mine == TC_OK) mine = fail(ctx, TC_GPU, "communicator: stream synchronisation failed");
+    if (mine != TC_OK) return mine;
     if (*h != 0u) return fail(ctx, TC_GPU, "sharded call: the set-up failed on " + std::to_string(*h) + " peer rank(s); no rank entered the loop");
+    return TC_OK;
+}
+
+// every creator calls it: a failure surfaces at creation, on every rank, not inside the first sharded call on one of them
+tc_status alloc_agree_word(tc_comm *c) {
+    if (c->nranks <= 1) return TC_OK;
+    if (hipSetDevice(c->ctx->device) != hipSuccess || hipMalloc(&c->agree_word, 64) != hipSuccess) {
+        c->agree_word = nullptr;
+        return fail(c->ctx, TC_GPU, "communicator: cannot allocate the agreement word");
+    }
     return TC_OK;
 }
 
@@ -164,6 +178,7 @@ tc_status tc_comm_create(tc_context *ctx, int nranks, int rank, const uint8_t id
     if (rc != kNcclSuccess) return tc::fail(ctx, TC_GPU, nccl_err(rc));
     tc_comm *c = new tc_comm();
     c->ctx = ctx; c->rank = rank; c->nranks = nranks; c->nccl = nc; c->own_nccl = true;
+    if (tc_status s = tc::alloc_agree_word(c)) { tc_comm_destroy(c); return s; }
     *out = c;
     return TC_OK;
 }
@@ -175,6 +190,7 @@ tc_status tc_comm_adopt(tc_context *ctx, void *nccl_comm, int nranks, int rank, 
     if (!r.ok) return tc::fail(ctx, TC_UNSUPPORTED, r.why);
     tc_comm *c = new tc_comm();
     c->ctx = ctx; c->rank = rank; c->nranks = nranks; c->nccl = nccl_comm; c->own_nccl = false;
+    if (tc_status s = tc::alloc_agree_word(c)) { tc_comm_destroy(c); return s; }
     *out = c;
     return TC_OK;
 }
@@ -184,6 +200,7 @@ tc_status tc_comm_create_host(tc_context *ctx, int nranks, int rank, tc_host_col
     if (!fn && nranks > 1) return tc::fail(ctx, TC_INVALID_DATA, "communicator: a host collective callback is required for nranks > 1");
     tc_comm *c = new tc_comm();
     c->ctx = ctx; c->rank = rank; c->nranks = nranks; c->host_fn = fn; c->host_user = user;
+    if (tc_status s = tc::alloc_agree_word(c)) { tc_comm_destroy(c); return s; }
     *out = c;
     return TC_OK;
 }

@@ -176,13 +176,40 @@ __global__ void __launch_bounds__(kScanBlock) scan_reduce_kernel(const uint32_t 
 
 // (the exclusive scan of the block sums used to be a launch of its own, ~4.6 us of a 16 us scan: every apply block now adds up
 // the sums in front of it itself -- a few hundred values --, block 0 also the non-zero counts -> blocksum[2 * nb])
+// (that re-summing is quadratic in the number of scan blocks: fine for the few hundred of a uniform 1 M-point grid, 5.8 us;
+// an adapted grid -- up to 32 cells per point -- of 16 M points has 250 k of them = 3e10 loads.  Beyond kScanFusedMax blocks a
+// one-block kernel turns the block sums into their exclusive prefix first and the apply blocks read theirs: `prefixed`.)
+constexpr uint32_t kScanFusedMax = 2048;
+__global__ void __launch_bounds__(1024) scan_top_kernel(uint32_t *__restrict__ blocksum, uint32_t nb) {
+    __shared__ uint32_t wtot[16];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? blocksum[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if ((threadIdx.x & 63) >= (unsigned)o) inc += t;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < (int)(threadIdx.x >> 6)) woff += wtot[w]; tot += wtot[w]; }
+        if (i < nb) blocksum[i] = carry + woff + inc - v;
+        carry += tot;
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t n,
                                                                 uint32_t *__restrict__ blocksum,
-                                                                uint32_t *__restrict__ out /* n+1 */, uint32_t *__restrict__ occ_out) {
+                                                                uint32_t *__restrict__ out /* n+1 */, uint32_t *__restrict__ occ_out, int prefixed) {
     __shared__ uint32_t wtot[kScanBlock / 64];
     __shared__ uint32_t wpre[kScanBlock / 64], wnz[kScanBlock / 64];
     uint32_t pre = 0, nzt = 0;
-    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kScanBlock) pre += blocksum[i];
+    if (prefixed) { if (threadIdx.x == 0) pre = blocksum[blockIdx.x]; }
+    else for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kScanBlock) pre += blocksum[i];
     if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < gridDim.x; i += kScanBlock) nzt += blocksum[gridDim.x + i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o); nzt += __shfl_xor(nzt, o); }
@@ -383,7 +410,11 @@ tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, 
     const uint32_t nscan = (n + kScanTile - 1) / kScanTile;
     if (tc_status s = ensure(ctx, blocksum, ((size_t)2 * nscan + 1) * sizeof(uint32_t))) return s;   // sums | non-zero counts | their total
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p, d_out, occ_out);
+    // (TC_SCAN_FUSED_MAX, read per call: the tests force the two-level path on small grids)
+    const char *fm = getenv("TC_SCAN_FUSED_MAX");
+    const bool prefixed = nscan > (fm ? (uint32_t)atoi(fm) : kScanFusedMax);
+    if (prefixed) hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, (uint32_t *)blocksum.p, nscan);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p, d_out, occ_out, prefixed ? 1 : 0);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
 }

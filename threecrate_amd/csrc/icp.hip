@@ -41,6 +41,28 @@ __device__ __forceinline__ void iso_apply(const float q[4], const float t[3], fl
     oz = ((tz * q[3] + cz) + z) + t[2];
 }
 
+// The first 64 bytes of the IcpState (rotation, translation, mse words, iteration count, flags, max_dist) in ONE scalar load
+// issued before anything else: a kernel that tests `done`, then fetches the transform, then the distance cut starts with three
+// dependent round trips to memory (~0.5 us each), and every kernel of an iteration starts like that.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+struct IcpHeader {
+    float q[4], t[3];
+    float max_dist;
+    uint32_t iterations;
+    int32_t done;
+};
+static_assert(offsetof(IcpState, done) == 48 && offsetof(IcpState, max_dist) == 60 && offsetof(IcpState, iterations) == 36, "IcpState header layout");
+__device__ __forceinline__ IcpHeader load_header(const IcpState *st) {
+    const u32x16 h = *reinterpret_cast<const u32x16 *>(st);
+    IcpHeader o;
+    o.q[0] = __uint_as_float(h[0]); o.q[1] = __uint_as_float(h[1]); o.q[2] = __uint_as_float(h[2]); o.q[3] = __uint_as_float(h[3]);
+    o.t[0] = __uint_as_float(h[4]); o.t[1] = __uint_as_float(h[5]); o.t[2] = __uint_as_float(h[6]);
+    o.iterations = h[9];
+    o.done = (int32_t)h[12];
+    o.max_dist = __uint_as_float(h[15]);
+    return o;
+}
+
 __device__ __forceinline__ uint32_t xcd_remap_icp(uint32_t b, uint32_t nb) {
     const uint32_t per = nb >> 3;          // nb is a multiple of 8
     return (b & 7u) * per + (b >> 3);
@@ -467,7 +489,8 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     unsigned long long t_begin = 0;
     if (blk_times) t_begin = __builtin_amdgcn_s_memrealtime();          // TC_DEBUG & 1024: per-block start / end stamps (100 MHz)
     constexpr int NACC = MODE == 0 ? TC_ICP_SUMS_P2P : TC_ICP_SUMS_P2PLANE;
-    if (st->done) return;
+    const IcpHeader hd = load_header(st);
+    if (hd.done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
     __shared__ uint2 spans[kSpanRows][kIcpBlock];
     // Refine entries (source index, best known position) go straight to global memory: every wave owns a region
@@ -478,10 +501,10 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     uint4 *__restrict__ const wseg = refine_entries(rlist) + 2 * ((size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * wave_cap;
     uint32_t wcnt = 0;                                     // this wave's entries so far (wave-uniform)
     const GridGeom &g = tgt.g;
-    const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
-    const float t[3] = {st->t[0], st->t[1], st->t[2]};
-    const float max_dist = st->max_dist;
-    const bool warm = st->iterations > 0 && !(dbg & 1);
+    const float q[4] = {hd.q[0], hd.q[1], hd.q[2], hd.q[3]};
+    const float t[3] = {hd.t[0], hd.t[1], hd.t[2]};
+    const float max_dist = hd.max_dist;
+    const bool warm = hd.iterations > 0 && !(dbg & 1);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane < TC_ICP_SUMS_STRIDE) red[w][lane] = 0.0;          // each wave owns one row
 
@@ -829,34 +852,55 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     const float4 *__restrict__ src_cov, int dbg) {
     constexpr bool P2PLANE = MODE == 1;
     constexpr int NACC = MODE == 0 ? TC_ICP_SUMS_P2P : TC_ICP_SUMS_P2PLANE;
-    if (st->done) return;
+    // Everything the block needs before its first query is REQUESTED before anything is waited for: the state header, its
+    // share of the main pass's rows and its four segment counts.  (Until round 4 these were a `done` test, then a loop of
+    // four dependent row loads, then two loops of four dependent count loads: ~10 round trips to memory in a row = most of the
+    // 5.2 us this launch took with an empty list.)
+    const IcpHeader hd = load_header(st);
     const bool dbg_shells = (dbg & 8192) != 0;          // TC_DEBUG & 8192: shells only, as before round 3 (A/B)
     __shared__ float lacc[kRefineThreads / kRG][TC_ICP_SUMS_STRIDE];
     // every refine block also folds its share of the main pass's per-block rows (written by the
     // previous launch) into its own row, in a fixed order: icp_finalize then reads kRefineBlocks rows
     const uint32_t rows_per = (n_main_rows + gridDim.x - 1) / gridDim.x;
     const uint32_t mr0 = min(blockIdx.x * rows_per, n_main_rows), mr1 = min(mr0 + rows_per, n_main_rows);
-    double folded = 0.0;
-    if (threadIdx.x < TC_ICP_SUMS_STRIDE)
-        for (uint32_t r = mr0; r < mr1; ++r) folded += main_rows[(size_t)r * TC_ICP_SUMS_STRIDE + threadIdx.x];
-    const GridGeom &g = tgt.g;
-    const float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};      // (GICP: the rotation of the pair terms)
-    const float max_dist = st->max_dist;
+    constexpr int kFoldBatch = kMaxPartialBlocks / kRefineBlocks;          // rows per block at the largest main grid
+    double fr[kFoldBatch];
+#pragma unroll
+    for (int k = 0; k < kFoldBatch; ++k) {          // (unconditional, clamped reads: a predicated read is an exec-mask region with its own wait)
+        const double v = main_rows[(size_t)min(mr0 + k, n_main_rows - 1) * TC_ICP_SUMS_STRIDE + (threadIdx.x & (TC_ICP_SUMS_STRIDE - 1))];
+        fr[k] = (mr0 + k < mr1) ? v : 0.0;
+    }
     // refine list = the main blocks' segments; exclusive scan of their counts (every block computes
     // the same scan), then query i -> (segment, local index) by binary search: balanced and
     // deterministic without a global counter
     constexpr int kSegPerRow = kIcpBlock / 64;                         // one segment per wave of a main block
+    constexpr int kCntPer = kMaxPartialBlocks * kSegPerRow / kRefineThreads;       // counts per thread at the largest main grid
     const uint32_t n_segs = n_main_rows * kSegPerRow;
+    // thread t owns the kCntPer consecutive counts starting at t * kCntPer (a per-lane bound check: a uniform one becomes a
+    // branch with the read and its wait inside)
+    constexpr uint32_t per = kCntPer;
+    uint32_t cnt[kCntPer];
+#pragma unroll
+    for (int k = 0; k < kCntPer; ++k) {
+        const uint32_t b = threadIdx.x * per + k;
+        const uint32_t v = rlist[min(b, n_segs - 1)];
+        cnt[k] = b < n_segs ? v : 0u;
+    }
+    if (hd.done) return;
+    double folded = 0.0;
+#pragma unroll
+    for (int k = 0; k < kFoldBatch; ++k) folded += fr[k];              // (rows mr0 .. in order; + 0.0 is exact)
+    if (threadIdx.x < TC_ICP_SUMS_STRIDE)
+        for (uint32_t r = mr0 + kFoldBatch; r < mr1; ++r) folded += main_rows[(size_t)r * TC_ICP_SUMS_STRIDE + threadIdx.x];   // (never: n_main_rows <= kMaxPartialBlocks)
+    const GridGeom &g = tgt.g;
+    const float q[4] = {hd.q[0], hd.q[1], hd.q[2], hd.q[3]};          // (GICP: the rotation of the pair terms)
+    const float max_dist = hd.max_dist;
     __shared__ uint32_t seg_off[kMaxPartialBlocks * kSegPerRow + 1];
     __shared__ uint32_t wave_tot[kRefineThreads / 64];
     {
-        // thread t owns the `per` consecutive counts starting at t * per (per = 1 up to 1024 main blocks)
-        const uint32_t per = (n_segs + kRefineThreads - 1) / kRefineThreads;
         uint32_t run = 0;
-        for (uint32_t k = 0; k < per; ++k) {
-            const uint32_t b = threadIdx.x * per + k;
-            run += b < n_segs ? rlist[b] : 0u;
-        }
+#pragma unroll
+        for (int k = 0; k < kCntPer; ++k) run += cnt[k];
         uint32_t inc = run;                                 // inclusive scan over the block: wave scan + wave totals
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -867,12 +911,13 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
         __syncthreads();
         uint32_t ex = inc - run;
         for (int w2 = 0; w2 < (int)(threadIdx.x >> 6); ++w2) ex += wave_tot[w2];
-        for (uint32_t k = 0; k < per; ++k) {
+#pragma unroll
+        for (int k = 0; k < kCntPer; ++k) {
             const uint32_t b = threadIdx.x * per + k;
             if (b <= n_segs) seg_off[b] = ex;
-            ex += b < n_segs ? rlist[b] : 0u;
+            ex += cnt[k];
         }
-        if (threadIdx.x == kRefineThreads - 1) seg_off[n_segs] = ex;    // total
+        if (threadIdx.x == kRefineThreads - 1) seg_off[n_segs] = ex;    // total (n_segs == kCntPer * kRefineThreads: no thread owns slot n_segs)
         __syncthreads();
     }
     const uint32_t count = seg_off[n_segs];
@@ -992,6 +1037,9 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
         }
         partial_rows[(size_t)blockIdx.x * TC_ICP_SUMS_STRIDE + threadIdx.x] = sum + folded;
     }
+    // (Round 4 measured this launch FUSED with icp_finalize -- rows stored write-through, an agent-scope ticket, the last block
+    // folds and solves behind sc1 loads, MI355X_MICROARCH.md's hand-off recipe: 12.8 us instead of 4.9 + 4.7 in the aligned phase,
+    // 17.9 instead of 16.0 on average; profiles/r04_ab_fused_tail.txt.  The boundary is cheaper than the hand-off.)
 }
 
 // ICPResult.correspondences (registration.rs:22-23): matched ORIGINAL target index per ORIGINAL
@@ -1253,7 +1301,7 @@ constexpr int kFinalizeThreads = 512;
 // the calling block (kFinalizeThreads threads): fixed-order sum of the rows, solve, compose, bookkeeping
 template <int MODE>
 __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
-                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE]) {
+                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE], bool done = false) {
     constexpr bool P2PLANE = MODE != 0;        // GICP solves the same 6x6 system from the same 29 words (gicp.rs:258-281)
     if (do_sum) {
         // 16 row groups x 32 columns (512 threads): every group folds its rows in a fixed order, then column t folds the 16
@@ -1286,13 +1334,13 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
         if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) tot += sm[gi][threadIdx.x];
-            st->sums[threadIdx.x] = tot;
+            if (!done) st->sums[threadIdx.x] = tot;
         }
         __syncthreads();
         if (threadIdx.x < TC_ICP_SUMS_STRIDE) sm[0][threadIdx.x] = tot;      // the solve reads them from LDS, not back from memory
         __syncthreads();
     }
-    if (!do_apply || threadIdx.x != 0) return;
+    if (!do_apply || threadIdx.x != 0 || done) return;
     const double *S = do_sum ? &sm[0][0] : st->sums;
     if (P2PLANE) {
         const double cnt = S[28];
@@ -1363,8 +1411,12 @@ template <int MODE>
 __global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
                                                            IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply,
                                                            int32_t *__restrict__ done_out) {
-    if (st->done) { if (done_out && threadIdx.x == 0) *done_out = 1; return; }
+    // (the rows are requested before `done` is known: the test is one more round trip to memory in front of them otherwise)
+    const IcpHeader hd = load_header(st);
     __shared__ double sm[kFinalizeThreads / 32][TC_ICP_SUMS_STRIDE];
+    // (done_out: 1 = the registration is over, 2 = this chunk of the host's enqueue schedule has run and it is not; the host
+    // polls the word, which lives in pinned host memory: run_chunked)
+    if (hd.done && !do_sum) { if (done_out && threadIdx.x == 0) __hip_atomic_store(done_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
 #ifdef TC_PHASE_STAMPS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     finalize_body<MODE>(partials, nblocks, st, g, do_sum, 0, sm);
@@ -1373,9 +1425,10 @@ __global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const do
     const unsigned long long t2 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) { st->refine_ring_hist[0] += (uint32_t)(t1 - t0); st->refine_ring_hist[1] += (uint32_t)(t2 - t1); }
 #else
-    finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm);
+    finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm, hd.done != 0);
 #endif
-    if (done_out && threadIdx.x == 0) *done_out = st->done;      // (thread 0 wrote st->done itself)
+    if (done_out && threadIdx.x == 0)      // (thread 0 wrote st->done itself)
+        __hip_atomic_store(done_out, (hd.done || st->done) ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // after the last iteration: not-converged epilogue (registration.rs:343-369 / :595-601)
@@ -1598,28 +1651,34 @@ static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate
     auto chunk_len = [](size_t c) -> size_t { return c == 0 ? 6 : c == 1 ? 2 : c == 2 ? 4 : 8; };
     size_t nchunks = 0;
     for (size_t covered = 0; covered < max_iters; ++nchunks) covered += chunk_len(nchunks);
-    int32_t *flags = (int32_t *)((char *)ctx->pinned + 1024);
+    // The last launch of chunk c writes 1 (registration over) or 2 (chunk over, registration not) into word c of the pinned,
+    // device-visible block, and the host POLLS that word: no event on the stream (a recorded event is a 5.5 us bubble between two
+    // iterations, eight of them per 50-iteration call: round 4).
+    volatile int32_t *flags = (volatile int32_t *)((char *)ctx->pinned + 1024);
     int32_t *d_flags = nullptr;                                    // the same words as the device sees them
-    TC_HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d_flags, flags, 0));
+    TC_HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d_flags, (void *)flags, 0));
     const size_t max_flags = 200;                                  // pinned bytes 1024 .. 2048 hold them (the bbox partials follow)
     size_t it = 0;
     for (size_t c = 0; c < nchunks; ++c) {
         if (c >= 2 && c - 2 < max_flags) {
-            TC_HIP_TRY(ctx, hipEventSynchronize(ctx->chunk_events[(c - 2) & 3]));
-            if (flags[c - 2]) break;
+            // wait for chunk c - 2 (chunk c - 1 keeps the device busy meanwhile)
+            for (unsigned spins = 0; flags[c - 2] == 0; ++spins) {
+                if ((spins & 1023u) == 1023u) {
+                    // (a stream that has drained without writing the word, or an error: never spin on a dead device)
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q == hipSuccess) { if (flags[c - 2] == 0) return fail(ctx, TC_GPU, "internal error: an ICP chunk finished without reporting"); break; }
+                    if (q != hipErrorNotReady) return fail(ctx, TC_GPU, std::string("ICP loop: ") + hipGetErrorString(q));
+                }
+                __builtin_ia32_pause();
+            }
+            if (flags[c - 2] == 1) break;
         }
         if (c < max_flags) flags[c] = 0;
         for (size_t k = 0; k < chunk_len(c) && it < max_iters; ++k, ++it) {
-            // the chunk's last finalize launch writes the `done` flag straight into the pinned block
+            // the chunk's last launch writes the word straight into the pinned block
             const bool last = k + 1 == chunk_len(c) || it + 1 == max_iters;
             if (tc_status s = enqueue_iteration((last && c < max_flags) ? d_flags + c : nullptr)) return s;
         }
-        while (ctx->chunk_events.size() < 4) {
-            hipEvent_t ev;
-            TC_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            ctx->chunk_events.push_back(ev);
-        }
-        TC_HIP_TRY(ctx, hipEventRecord(ctx->chunk_events[c & 3], st));     // the event of chunk c - 4 was waited for two chunks ago
     }
     return TC_OK;
 }

@@ -1709,8 +1709,12 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
         const void *before = ctx->normals_hard.p;
         if (tc_status s = ensure(ctx, ctx->normals_hard, ((size_t)(prm.p_end - prm.p_begin) + 4) * sizeof(uint32_t))) return s;
         prm.hard_list = (uint32_t *)ctx->normals_hard.p;
-        // (count and exit ticket are zeroed when the buffer is new; afterwards the serving kernel leaves them zero)
-        if (ctx->normals_hard.p != before) TC_HIP_TRY(ctx, hipMemsetAsync(prm.hard_list, 0, 4 * sizeof(uint32_t), ctx->stream));
+        // (count and exit ticket are zeroed when the buffer is new or the last serving launch is not known to have gone through;
+        // afterwards the serving kernel leaves them zero)
+        if (ctx->normals_hard.p != before || !ctx->normals_hard_clean) {
+            TC_HIP_TRY(ctx, hipMemsetAsync(prm.hard_list, 0, 4 * sizeof(uint32_t), ctx->stream));
+            ctx->normals_hard_clean = true;
+        }
     }
     struct HardPass {
         tc_context *ctx; const GridView &gv; NormalParams &prm; float *out6;
@@ -1720,7 +1724,9 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
             NormalParams p2 = prm;
             p2.hard_list = nullptr;
             ProfScope ps(ctx, "normals_coop");
+            ctx->normals_hard_clean = false;       // until the launch that resets the header is known to be enqueued
             hipLaunchKernelGGL(normals_coop_kernel<512>, dim3(256), dim3(kCoopThreads), 0, ctx->stream, gv, p2, out6, hl);
+            if (hipGetLastError() == hipSuccess) ctx->normals_hard_clean = true;
         }
     } hard_pass{ctx, gv, prm, d_out6};
 #ifdef TC_NSTATS

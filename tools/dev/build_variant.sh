@@ -1,15 +1,18 @@
 #!/bin/bash
 # dev: build a variant of the library with extra compiler flags (A/B experiments on the GPU box):
-#   bash tools/dev/build_variant.sh <name> "<extra flags>"   ->  threecrate_amd/variants/libthreecrate_hip_<name>.so
-# (git-ignored, travels with gpurun; select it with TC_HIP_LIB=threecrate_amd/variants/libthreecrate_hip_<name>.so)
+#   bash tools/dev/build_variant.sh <name> "<extra flags>" [files...]  ->  threecrate_amd/variants/libthreecrate_hip_<name>.so
+# Only the listed source files (default: icp) are recompiled with the flags; the rest are the objects of the default build
+# (run `make -C threecrate_amd/csrc` first).  Git-ignored, travels with gpurun; select with TC_HIP_LIB=<path>.
 set -eu
-NAME=$1; EXTRA=${2:-}
+NAME=$1; EXTRA=${2:-}; shift; shift || true
+FILES=${@:-icp}
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 SRC=$ROOT/threecrate_amd/csrc
 OBJ=$ROOT/build/var_$NAME
-mkdir -p "$OBJ" "$ROOT/threecrate_amd/variants"
+rm -rf "$OBJ"; mkdir -p "$OBJ" "$ROOT/threecrate_amd/variants"
+for f in api grid normals icp voxel stream comm cloud; do cp "$SRC/$f.o" "$OBJ/$f.o"; done
 pids=()
-for f in api grid normals icp voxel stream comm cloud; do
+for f in $FILES; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result $EXTRA -c "$SRC/$f.hip" -o "$OBJ/$f.o" &
   pids+=($!)
 done

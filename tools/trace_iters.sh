@@ -18,7 +18,12 @@ rows.sort()
 for pat in ("icp_correspond", "icp_refine", "icp_finalize"):
     d = [(e - s) / 1e3 for s, e, k in rows if pat in k]
     d = d[-50:]
+    if not d: continue
     print(pat, "last call, us per launch:")
     print("  " + " ".join(f"{x:.0f}" for x in d))
-    print(f"  mean {sum(d)/len(d):.1f}   launches 2-37 {sum(d[1:37])/36:.1f}   last 8 {sum(d[-8:])/8:.1f}")
+    print(f"  mean {sum(d)/len(d):.1f}   launches 2-37 {sum(d[1:37])/36:.1f}   launches 12-37 {sum(d[11:37])/26:.1f}   last 8 {sum(d[-8:])/8:.1f}")
+starts = [s for s, e, k in rows if "icp_correspond" in k][-50:]
+if len(starts) == 50:
+    it = [(starts[i + 1] - starts[i]) / 1e3 for i in range(49)]
+    print(f"iteration (start of a main pass to the start of the next), us: mean {sum(it)/len(it):.1f}   2-37 {sum(it[1:37])/36:.1f}   last 8 {sum(it[-9:-1])/8:.1f}")
 PY
