@@ -11,6 +11,9 @@ use std::os::raw::{c_char, c_int, c_void};
 pub const TC_COMM_ID_BYTES: usize = 128;
 pub const TC_SHARD_SPATIAL: c_int = 0;
 pub const TC_SHARD_LOCAL: c_int = 1;
+pub const TC_SHARD_INDEX: c_int = 2;
+pub const TC_COUNTER_INDEXED_POINTS: c_int = 0;
+pub const TC_COUNTER_INDEX_BUILDS: c_int = 1;
 pub const TC_COLL_SUM_F64: c_int = 0;
 pub const TC_COLL_SUM_U32: c_int = 1;
 pub const TC_COLL_ALLGATHER_U8: c_int = 2;
@@ -144,6 +147,10 @@ extern "C" {
                                           res: *mut tc_icp_result) -> c_int;
     pub fn tc_sharded_estimate_normals_device(ctx: *mut tc_context, comm: *mut tc_comm, d_xyz: *const f32, n: usize,
                                               cfg: *const tc_normal_config, d_out: *mut f32) -> c_int;
+    pub fn tc_sharded_estimate_normals_local_device(ctx: *mut tc_context, comm: *mut tc_comm, d_xyz: *const f32, n: usize,
+                                                    cfg: *const tc_normal_config, d_out_slice: *mut f32, d_orig_index: *mut u32,
+                                                    first: *mut usize, count: *mut usize) -> c_int;
+    pub fn tc_debug_counter(ctx: *const tc_context, which: c_int) -> u64;
     // ---- device-resident cloud handles ----
     pub fn tc_cloud_upload(ctx: *mut tc_context, xyz: *const f32, n: usize, out: *mut *mut tc_cloud) -> c_int;
     pub fn tc_cloud_upload_device(ctx: *mut tc_context, d_xyz: *const f32, n: usize, out: *mut *mut tc_cloud) -> c_int;

@@ -132,8 +132,8 @@ void        tc_normal_config_default(tc_normal_config *cfg);   /* normals.rs:28-
  * xyz: n x 3 f32.  out: n x 6 f32 (NormalPoint3f).  n == 0 -> TC_OK before the k check.
  * Limits of this backend (the reference has none): k_neighbors <= 2047 (up to 128 the k + 1 nearest incl. the point itself live in
  * a 129-entry register list, one lane per point; beyond that a block-per-point kernel serves every point; the k-NN / radius
- * exports below return up to 2048 entries per query) -> TC_UNSUPPORTED beyond; k_neighbors > 128 together with a radius:
- * TC_UNSUPPORTED.
+ * exports below return up to 2048 entries per query) -> TC_UNSUPPORTED (an error with a message, never undefined behaviour) beyond.
+ * k_neighbors > 128 together with a radius: the block-per-point kernel folds the radius ball itself (no cap on its members).
  * Non-finite points (NaN / +-inf coordinates) are inert: never a neighbour, their own normal is the default (0, 0, 1). */
 tc_status tc_estimate_normals(tc_context *ctx, const float *xyz, size_t n,
                               const tc_normal_config *cfg, float *out_normal_points);
@@ -309,10 +309,16 @@ void      tc_comm_destroy(tc_comm *comm);
  *       (one all-reduce of n_source words after the loop).
  *   TC_SHARD_LOCAL: every rank passes ITS OWN part of the source (any partition; may be empty on some ranks);
  *       corr_target then has n_source (local) entries.
+ *   TC_SHARD_INDEX: every rank passes the SAME full source cloud; rank r takes the ORIGINAL-index range
+ *       [r rows, min((r + 1) rows, ns)), rows = ceil(ns / W), and orders only those points by target cell: the per-call set-up
+ *       (the source's counting sort) shrinks with 1 / W like the iterations do -- with TC_SHARD_SPATIAL every rank sorts the
+ *       whole source.  corr_target (device, n_source entries, optional) is completed on every rank by ONE all-gather of the
+ *       ranks' slices (4 ns bytes in total) instead of an all-reduce of n_source words.  The default of the Python mirror for
+ *       more than one rank.
  * Point-to-point: the post-loop mse of a run that did not converge (registration.rs:343-361) is reduced over the ranks
  * too.  All ranks must call with the same arguments apart from the source in TC_SHARD_LOCAL mode; validation failures are
  * the single-GPU entry points' and identical on every rank. */
-typedef enum tc_shard_mode { TC_SHARD_SPATIAL = 0, TC_SHARD_LOCAL = 1 } tc_shard_mode;
+typedef enum tc_shard_mode { TC_SHARD_SPATIAL = 0, TC_SHARD_LOCAL = 1, TC_SHARD_INDEX = 2 } tc_shard_mode;
 tc_status tc_sharded_icp_point_to_plane_device(tc_context *ctx, tc_comm *comm, int shard_mode,
                           const float *d_source, size_t n_source, const float *d_target, size_t n_target,
                           const float *d_target_normals, size_t n_target_normals, size_t normal_stride,
@@ -327,6 +333,17 @@ tc_status tc_sharded_icp_detailed_device(tc_context *ctx, tc_comm *comm, int sha
  * stream, a local kernel restores the input order.  Every rank receives all n records in d_out (n x 6). */
 tc_status tc_sharded_estimate_normals_device(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n,
                                              const tc_normal_config *config, float *d_out_normal_points);
+/* The same without the all-gather (240 MB at 10 M points: it, not the kernel, bounds the call on 8 GPUs): this rank's records only.
+ * d_out_slice: ceil(n / W) x 6 floats (position, normal) for the cell-sorted positions [*first, *first + *count);
+ * d_orig_index (optional): the input index of each of those records.  No collective is issued. */
+tc_status tc_sharded_estimate_normals_local_device(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n,
+                                                   const tc_normal_config *config, float *d_out_slice, uint32_t *d_orig_index,
+                                                   size_t *first, size_t *count);
+
+/* Diagnostics (tests): work counters of a context since its creation.  TC_COUNTER_INDEXED_POINTS: points that went through an
+ * index build (counting sort) -- the per-call set-up work of the sharded entry points, which must shrink with the rank count. */
+typedef enum tc_counter { TC_COUNTER_INDEXED_POINTS = 0, TC_COUNTER_INDEX_BUILDS = 1 } tc_counter;
+unsigned long long tc_debug_counter(const tc_context *ctx, int which);
 
 /* One registration over the ranks of a communicator (see tc_sharded_icp_point_to_plane_device) against a TARGET HANDLE: every
  * rank holds the same target cloud in its own handle, whose index, cell-sorted normals and inscribed-ball bounds are built once

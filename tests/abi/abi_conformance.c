@@ -64,7 +64,8 @@ static int layout(void) {
     OFF(tc_frame_stream_metrics, max_depth_seen);
     VAL(TC_ABI_VERSION); VAL(TC_OK); VAL(TC_INVALID_DATA); VAL(TC_ALGORITHM); VAL(TC_GPU); VAL(TC_UNSUPPORTED);
     VAL(TC_ICP_SUMS_P2PLANE); VAL(TC_ICP_SUMS_P2P); VAL(TC_ICP_SUMS_STRIDE); VAL(TC_COMM_ID_BYTES);
-    VAL(TC_COLL_SUM_F64); VAL(TC_COLL_SUM_U32); VAL(TC_COLL_ALLGATHER_U8); VAL(TC_SHARD_SPATIAL); VAL(TC_SHARD_LOCAL);
+    VAL(TC_COLL_SUM_F64); VAL(TC_COLL_SUM_U32); VAL(TC_COLL_ALLGATHER_U8); VAL(TC_SHARD_SPATIAL); VAL(TC_SHARD_LOCAL); VAL(TC_SHARD_INDEX);
+    VAL(TC_COUNTER_INDEXED_POINTS); VAL(TC_COUNTER_INDEX_BUILDS);
     /* the library this program is linked against answers for itself (no device needed) */
     printf("call.tc_abi_version %d\n", tc_abi_version());
     return 0;

@@ -61,6 +61,15 @@ def normals_report(pts, k, gpu6, ref6, tol=1e-4, max_offenders=200):
     return rep
 
 
+def offender_reasons(rep):
+    """per-reason histogram of a normals_report's offenders (each offender counted once, by the first explanation that holds)"""
+    out = {"boundary_tie": 0, "degenerate_eigen_pair": 0, "reference_solver_discontinuous": 0}
+    for o in rep["offenders"]:
+        out["boundary_tie" if o["boundary_tie"] else "degenerate_eigen_pair" if o["rel_eigen_gap"] < EIGEN_GAP_BOUND
+            else "reference_solver_discontinuous"] += 1
+    return out
+
+
 def reference_normal_of_cov(cov9):
     """normals.rs:181-194 on a 3x3 f32 covariance: column of the first strictly smallest eigenvalue of symmetric_eigen"""
     ev, q = O.symmetric_eigen3(cov9)

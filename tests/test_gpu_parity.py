@@ -56,10 +56,38 @@ def test_normals_beyond_128_neighbours(ctx, n, k):
     rep = h1.normals_report(pts, min(k, n - 1), gpu, ref)        # offenders explained (ties at the boundary / degenerate eigen-pairs)
     assert rep["n_beyond"] <= max(3, n // 500), rep
     assert rep["n_bit_identical"] >= 0.98 * n
-    with pytest.raises(tc.Unsupported):
+    with pytest.raises(tc.Unsupported):          # the documented limit (threecrate_hip.h): k_neighbors <= 2047 -- an error, never UB
         ctx.estimate_normals(pts, 2048)
-    with pytest.raises(tc.Unsupported):          # (a documented limit: the radius set of such a launch has no list to live in)
-        ctx.estimate_normals_with_config(pts, tc.NormalEstimationConfig(k_neighbors=200, radius=0.1))
+    with pytest.raises(tc.Unsupported):
+        ctx.estimate_normals_with_config(pts, tc.NormalEstimationConfig(k_neighbors=5000, radius=0.1))
+
+
+def test_normals_radius_mode_beyond_128_neighbours(ctx):
+    """k_neighbors > 128 TOGETHER with a radius (normals.rs:17-26: both unbounded; :141-146 the radius set, :315-323
+    the k-NN fallback when it has fewer than k members).  The wave-per-point kernel folds the radius ball's moments in f64
+    (coop_radius_moments): points with >= k members within the radius take the radius set -- here most of the interior --, the
+    rest (the box's faces and corners) the k nearest; both against the oracle."""
+    pts = synth.uniform_cloud(6000, seed=4, scale=(1.0, 1.0, 0.3))
+    k, r = 200, 0.16
+    cfg = tc.NormalEstimationConfig(k_neighbors=k, radius=r)
+    gpu = ctx.estimate_normals_with_config(pts, cfg)
+    ref = O.estimate_normals(pts, k, radius=r)
+    assert np.array_equal(gpu[:, :3], pts)
+    # members of every radius set, by brute force on the f32 formula the searches use
+    d2 = ((pts[:, None, :].astype(np.float32) - pts[None, :, :].astype(np.float32)) ** 2)
+    d2 = ((d2[..., 0] + d2[..., 1]).astype(np.float32) + d2[..., 2]).astype(np.float32)
+    members = (d2 <= np.float32(r) * np.float32(r)).sum(1) - 1
+    by_radius, by_knn = members >= k + 2, members <= k - 2
+    assert by_radius.sum() > 1000 and by_knn.sum() > 500, (by_radius.sum(), by_knn.sum())
+    c = cos_abs(gpu[:, 3:], ref[:, 3:])
+    # radius sets of hundreds of members: the reference's f32 ascending-order sums against order-free f64 moments -- rounding only
+    assert (c[by_radius] < 1 - COS_TOL).sum() == 0, (c[by_radius] < 1 - COS_TOL).sum()
+    # the k-NN fallback is the k > 128 path of test_normals_beyond_128_neighbours: bit-identical up to explained ties
+    knn_ref = O.estimate_normals(pts, k)
+    assert (ref[by_knn, 3:] == knn_ref[by_knn, 3:]).all()              # (the oracle itself: fallback == plain k-NN there)
+    assert ((gpu[by_knn, 3:] == ref[by_knn, 3:]).all(1)).mean() >= 0.98
+    assert (c < 1 - COS_TOL).sum() <= 3, (c < 1 - COS_TOL).sum()       # (members within +-1 of k: a boundary tie decides the branch)
+    assert np.abs(np.linalg.norm(gpu[:, 3:], axis=1) - 1).max() < 1e-5
 
 
 def test_isolated_points_take_the_wave_per_point_kernel_with_the_same_bits(ctx):
@@ -354,6 +382,12 @@ def test_large_surface_cloud_adapted_cell_edge(ctx):
                         FROB_TOL, scale=max(1.0, float(np.abs(tgt).max())))
 
 
+# measured on the seed-1 frame (round 4, profiles/r04_h1_kitti_frame_normals.json): NONE beyond 1e-4, all 120 000 normals bit-identical
+# to the oracle's.  The bound leaves room for a handful of explained boundary ties on another box / build (1e-4 of the frame); it
+# used to be "<= 3 % of the frame"
+KITTI_FRAME_NORMALS_BEYOND_MAX = 12
+
+
 def test_kitti_shaped_lidar_frame(ctx):
     """BASELINE config [4] shape: 120k-point LiDAR frame (1/r^2 density, ground + walls)."""
     frame = synth.kitti_shaped_cloud(seed=1)
@@ -363,7 +397,14 @@ def test_kitti_shaped_lidar_frame(ctx):
     # ring-shaped scan lines give near-collinear neighbourhoods (two vanishing eigenvalues: the normal is rounding noise in
     # the reference's own solve too): every point beyond the budget must be one of those, or an exact boundary tie (H1)
     rep = h1.normals_report(frame, 16, gpu, ref, max_offenders=6000)
-    assert rep["n_beyond"] <= 0.03 * len(frame)
+    # the count and what explains it go into a tracked report (profiles/r04_h1_kitti_frame_normals.json is the committed copy)
+    import json, os
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "h1_kitti_frame_normals.json"), "w") as fh:
+        json.dump({"points": len(frame), "k": 16, "beyond_1e-4": rep["n_beyond"], "bit_identical": rep["n_bit_identical"], "worst_1_minus_abs_cos": rep["worst"],
+                   "offenders_by_reason": h1.offender_reasons(rep),
+                   "gap_quantiles_of_the_degenerate_ones": [float(q) for q in np.quantile([o["rel_eigen_gap"] for o in rep["offenders"]] or [0.0], [0.5, 0.9, 0.99, 1.0])]}, fh, indent=1)
+    assert rep["n_beyond"] <= KITTI_FRAME_NORMALS_BEYOND_MAX, rep["n_beyond"]
     assert np.abs(np.linalg.norm(gpu[:, 3:], axis=1) - 1).max() < 1e-5
     # ego-motion step: 1 m forward + 0.5 deg yaw between frames (point-to-point, then point-to-plane)
     T = synth.yaw_isometry((1.0, 0.0, 0.0), np.deg2rad(0.5))

@@ -83,10 +83,7 @@ def test_config4_pipeline_end_to_end_against_the_oracle_chain(ctx):
         ref_n = O.estimate_normals(prev, K)
         gpu_n = ctx.estimate_normals(prev, K)
         nrep = h1.normals_report(prev, K, gpu_n, ref_n, max_offenders=max(200, len(prev) // 20))
-        reasons = {"boundary_tie": 0, "degenerate_eigen_pair": 0, "reference_solver_discontinuous": 0}
-        for o in nrep["offenders"]:
-            reasons["boundary_tie" if o["boundary_tie"] else "degenerate_eigen_pair" if o["rel_eigen_gap"] < h1.EIGEN_GAP_BOUND
-                    else "reference_solver_discontinuous"] += 1
+        reasons = h1.offender_reasons(nrep)
         # 3. registration current -> previous
         gn = np.ascontiguousarray(gpu_n[:, 3:])
         on = np.ascontiguousarray(ref_n[:, 3:])

@@ -52,9 +52,9 @@ def test_one_rank_sharded_entry_equals_fused_loop(ctx, kind):
     try:
         for iters, thr in ((12, 0.0), (50, 1e-6)):
             b = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, iters, None, thr)
-            for local in (False, True):
+            for local, shard in ((False, "spatial"), (True, None), (False, "index")):
                 a = D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, iters, None, thr, comm=comm, source_is_local_slice=local,
-                                                 correspondences=True)
+                                                 correspondences=True, shard=shard)
                 assert (a.converged, a.iterations, a.mse) == (b.converged, b.iterations, b.mse)
                 assert np.array_equal(a.transformation, b.transformation)
                 assert np.array_equal(a.correspondences, b.correspondences)
@@ -66,8 +66,11 @@ def test_one_rank_sharded_entry_equals_fused_loop(ctx, kind):
         b = ctx.icp_detailed(ds, dt, None, 40, None, 1e-9)
         a = D.sharded_icp_detailed(ctx, ds, dt, None, 40, None, 1e-9, comm=comm)
         assert (a.converged, a.iterations, a.mse) == (b.converged, b.iterations, b.mse) and np.array_equal(a.transformation, b.transformation)
-        # normals: slice + all-gather + unsort == the single call
+        # normals: slice + all-gather + unsort == the single call; the local variant (no collective): the same records by input index
         assert torch.equal(D.sharded_estimate_normals(ctx, dt, 16, comm=comm), nrm)
+        rec, idx, first = D.sharded_estimate_normals_local(ctx, dt, 16, comm=comm)
+        assert first == 0 and len(rec) == len(nrm) and torch.equal(torch.sort(idx.long()).values, torch.arange(len(nrm), device=idx.device))
+        assert torch.equal(rec, nrm[idx.long()])
         # against a target HANDLE (index, normals, bounds built once): the handle-based single-GPU call, bit for bit, twice
         th, sh = tc.Cloud(ctx, dt), tc.Cloud(ctx, ds)
         th.estimate_normals(16, out=False)
@@ -131,6 +134,21 @@ def _rank_main(rank, world, port, q):
         out["normals"] = nrm.cpu().numpy()
         a = D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 12, None, 0.0, comm=comm, correspondences=True)
         out["p2plane"] = (a.transformation, a.mse, a.iterations, a.converged, a.correspondences)
+        # explicit spatial sharding (every rank orders the WHOLE source) against the default index ranges (ns / W points per rank):
+        # the per-call set-up work is read off the context's counter of points that went through an index build
+        th = tc.Cloud(ctx, dt)
+        th.set_normals(nrm)
+        c0 = ctx.debug_counter("indexed_points")
+        a = D.sharded_icp_against_cloud(ctx, ds, th, None, 12, None, 0.0, comm=comm, correspondences=True, shard="spatial")
+        c1 = ctx.debug_counter("indexed_points")
+        b2 = D.sharded_icp_against_cloud(ctx, ds, th, None, 12, None, 0.0, comm=comm, correspondences=True)        # default: index ranges
+        c2 = ctx.debug_counter("indexed_points")
+        out["setup_points"] = (c1 - c0, c2 - c1, len(ds))
+        out["p2plane_spatial_handle"] = (a.transformation, a.mse, a.iterations, a.converged, a.correspondences)
+        out["p2plane_index_handle"] = (b2.transformation, b2.mse, b2.iterations, b2.converged, b2.correspondences)
+        th.close()
+        rec, idx, first = D.sharded_estimate_normals_local(ctx, dt, 16, comm=comm)
+        out["normals_local"] = (rec.cpu().numpy(), idx.cpu().numpy(), first)
         a = D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 50, 0.05, 1e-7, comm=comm)
         out["p2plane_conv"] = (a.transformation, a.mse, a.iterations, a.converged)
         a = D.sharded_icp_detailed(ctx, ds, dt, None, 6, None, 0.0, comm=comm, correspondences=True)
@@ -165,10 +183,26 @@ def test_ranks_sharing_the_gpu_drive_the_c_entry_points(ctx, world):
         p.join(timeout=120)
         assert p.exitcode == 0
     r0 = outs[0]
-    assert set(r0) == {"normals", "p2plane", "p2plane_conv", "p2p", "local_empty", "bigcell"}, "rank 0 failed: " + str(list(r0))
+    assert set(r0) == {"normals", "p2plane", "p2plane_conv", "p2p", "local_empty", "bigcell", "setup_points", "p2plane_spatial_handle",
+                       "p2plane_index_handle", "normals_local"}, "rank 0 failed: " + str(list(r0))
+    # with index ranges a rank's set-up orders ns / W source points (the spatial mode: all ns on every rank)
+    n_src = r0["setup_points"][2]
+    for r in range(world):
+        spatial_pts, index_pts, _ = outs[r]["setup_points"]
+        assert spatial_pts == n_src, (r, spatial_pts)
+        assert index_pts <= -(-n_src // world), (r, index_pts)
+    assert sum(outs[r]["setup_points"][1] for r in range(world)) == n_src
+    # the ranks' local normals slices tile the cloud: every input index exactly once, records = the gathered call's
+    seen = np.concatenate([outs[r]["normals_local"][1] for r in range(world)])
+    assert np.array_equal(np.sort(seen), np.arange(len(r0["normals"])))
+    for r in range(world):
+        rec, idx, first = outs[r]["normals_local"]
+        assert np.array_equal(rec, r0["normals"][idx])
     # every rank ends with bit-identical state
     for r in range(1, world):
         for key in r0:
+            if key in ("setup_points", "normals_local"):
+                continue
             if key == "normals":
                 assert np.array_equal(r0[key], outs[r][key])
                 continue
@@ -182,6 +216,9 @@ def test_ranks_sharing_the_gpu_drive_the_c_entry_points(ctx, world):
     T, mse, it, conv, corr = r0["p2plane"]
     assert (it, conv) == (b.iterations, b.converged) and _frob(T, b.transformation) <= 1e-5 and abs(mse - b.mse) <= 1e-6 * max(b.mse, 1e-12) + 1e-12
     assert np.array_equal(corr, b.correspondences)
+    for key in ("p2plane_spatial_handle", "p2plane_index_handle"):      # both partitions: the single-GPU pairs, transforms within the budget
+        T, mse, it, conv, corr = r0[key]
+        assert (it, conv) == (b.iterations, b.converged) and _frob(T, b.transformation) <= 1e-5 and np.array_equal(corr, b.correspondences), key
     b = ctx.icp_point_to_plane_detailed(ds, dt, nrm, None, 50, 0.05, 1e-7)
     T, mse, it, conv = r0["p2plane_conv"]
     assert (it, conv) == (b.iterations, b.converged) and _frob(T, b.transformation) <= 1e-5

@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("TC_HIP_LIB") or os.path.join(_HERE, "libthreecrate_hi
 TC_OK, TC_INVALID_DATA, TC_ALGORITHM, TC_GPU, TC_UNSUPPORTED = 0, 1, 2, 3, 4
 TC_COMM_ID_BYTES = 128
 TC_COLL_SUM_F64, TC_COLL_SUM_U32, TC_COLL_ALLGATHER_U8 = 0, 1, 2
-TC_SHARD_SPATIAL, TC_SHARD_LOCAL = 0, 1
+TC_SHARD_SPATIAL, TC_SHARD_LOCAL, TC_SHARD_INDEX = 0, 1, 2
+TC_COUNTER_INDEXED_POINTS, TC_COUNTER_INDEX_BUILDS = 0, 1
 # int (*tc_host_collective_fn)(void *user, int op, void *host_buf, size_t count)
 HOST_COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 SUMS_P2PLANE, SUMS_P2P, SUMS_STRIDE = 29, 17, 32
@@ -94,6 +95,7 @@ EXPORTS = [
     "tc_cloud_icp_detailed", "tc_cloud_sharded_icp", "tc_cloud_destroy",
     "tc_comm_unique_id", "tc_comm_create", "tc_comm_adopt", "tc_comm_create_host", "tc_comm_create_local", "tc_comm_rank", "tc_comm_size",
     "tc_comm_destroy", "tc_sharded_icp_point_to_plane_device", "tc_sharded_icp_detailed_device", "tc_sharded_estimate_normals_device",
+    "tc_sharded_estimate_normals_local_device", "tc_debug_counter",
     "tc_multiscale_icp_point_to_point", "tc_gicp", "tc_gicp_device", "tc_kiss_icp", "tc_kiss_icp_device", "tc_knn", "tc_knn_device", "tc_radius_search", "tc_radius_search_device",
     "tc_search_index_create", "tc_search_index_create_device", "tc_search_index_size", "tc_search_index_query",
     "tc_search_index_query_device", "tc_search_index_radius_count", "tc_search_index_radius_fill", "tc_search_index_destroy", "tc_voxel_grid_filter", "tc_voxel_grid_filter_device",
@@ -204,6 +206,9 @@ def load():
     L.tc_sharded_icp_point_to_plane_device.argtypes = [vp, vp, i, f32p, sz, f32p, sz, f32p, sz, sz, f32p, sz, f, f, resp]
     L.tc_sharded_icp_detailed_device.argtypes = [vp, vp, i, f32p, sz, f32p, sz, f32p, sz, f, f, resp]
     L.tc_sharded_estimate_normals_device.argtypes = [vp, vp, f32p, sz, C.POINTER(NormalConfig), f32p]
+    L.tc_sharded_estimate_normals_local_device.argtypes = [vp, vp, f32p, sz, C.POINTER(NormalConfig), f32p, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.tc_debug_counter.argtypes = [vp, i]
+    L.tc_debug_counter.restype = C.c_ulonglong
     L.tc_multiscale_icp_point_to_point.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(MultiScaleConfigC), resp]
     L.tc_gicp.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(GicpConfigC), resp]
     L.tc_gicp_device.argtypes = [vp, f32p, sz, f32p, sz, f32p, C.POINTER(GicpConfigC), resp]

@@ -213,6 +213,11 @@ class GpuContext:
     def profile_reset(self):
         self._L.tc_profile_reset(self._h)
 
+    def debug_counter(self, which="indexed_points"):
+        """work counters since the context was created (tc_debug_counter): "indexed_points" = points that went through an index
+        build, "index_builds" = the builds"""
+        return int(self._L.tc_debug_counter(self._h, {"indexed_points": _lib.TC_COUNTER_INDEXED_POINTS, "index_builds": _lib.TC_COUNTER_INDEX_BUILDS}[which]))
+
     def profile_read(self, minmax=False):
         """{kernel name: (launches, total ms)}; minmax=True: (launches, total ms, shortest launch ms, longest launch ms)"""
         buf = (_lib.KernelStatC * 64)()

@@ -476,7 +476,7 @@ tc_status tc_sharded_icp_point_to_plane_device(tc_context *ctx, tc_comm *comm, i
                                                tc_icp_result *result) {
     if (!ctx || !comm || !result) return TC_INVALID_DATA;
     if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
-    if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
+    if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL && shard_mode != TC_SHARD_INDEX) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
     // a rank of a TC_SHARD_LOCAL run may own no source points (the other ranks do)
     const size_t ns_check = (shard_mode == TC_SHARD_LOCAL && comm->nranks > 1 && n_source == 0) ? 1 : n_source;
     if (tc_status s = p2plane_validate(ctx, ns_check, n_target, n_normals, stride, max_iters, result)) return s;
@@ -490,12 +490,21 @@ tc_status tc_sharded_icp_detailed_device(tc_context *ctx, tc_comm *comm, int sha
                                          float conv_thr, tc_icp_result *result) {
     if (!ctx || !comm || !result) return TC_INVALID_DATA;
     if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
-    if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
+    if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL && shard_mode != TC_SHARD_INDEX) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
     const size_t ns_check = (shard_mode == TC_SHARD_LOCAL && comm->nranks > 1 && n_source == 0) ? 1 : n_source;
     if (tc_status s = icp_validate(ctx, ns_check, n_target, max_iters, result)) return s;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return icp_run_sharded(ctx, comm, shard_mode, false, d_source, n_source, d_target, n_target, nullptr, 0, init, max_iters, max_dist,
                            conv_thr, result);
+}
+
+// this rank's slot of ceil(n / W) cell-sorted positions -> slot_out (rows x 6); the fallible part of the sharded normals
+static tc_status sharded_normals_slot(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n, const tc_normal_config *cfg,
+                                      float *slot_out, size_t &lo, size_t &hi) {
+    const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank;
+    const size_t rows = (n + W - 1) / W;
+    lo = std::min(r * rows, n); hi = std::min((r + 1) * rows, n);
+    return normals_device(ctx, d_xyz, n, cfg, slot_out, lo, hi, true);
 }
 
 tc_status tc_sharded_estimate_normals_device(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n, const tc_normal_config *cfg,
@@ -509,15 +518,49 @@ tc_status tc_sharded_estimate_normals_device(tc_context *ctx, tc_comm *comm, con
     const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank;
     // equal slots of `rows` records (the last ranks' ranges may be shorter or empty): the all-gather runs in place
     const size_t rows = (n + W - 1) / W;
-    const size_t lo = std::min(r * rows, n), hi = std::min((r + 1) * rows, n);
-    if (tc_status s = ensure(ctx, ctx->out_a, W * rows * 6 * sizeof(float))) return s;
+    // everything that can fail on ONE rank (allocation, index build, launches) happens before the collective, and the ranks agree
+    // on it: a rank returning early would leave its peers waiting in the all-gather for ever (comm_agree)
+    tc_status local = ensure(ctx, ctx->out_a, W * rows * 6 * sizeof(float));
     float *sorted_all = (float *)ctx->out_a.p;
-    if (tc_status s = normals_device(ctx, d_xyz, n, cfg, sorted_all + r * rows * 6, lo, hi, true)) return s;
+    size_t lo = 0, hi = 0;
+    if (local == TC_OK) local = sharded_normals_slot(ctx, comm, d_xyz, n, cfg, sorted_all + r * rows * 6, lo, hi);
+    if (tc_status s = comm_agree(comm, local)) return s;
     if (tc_status s = comm_allgather(comm, sorted_all, rows * 6 * sizeof(float))) return s;
     // slot q holds the cell-sorted positions [q rows, min((q + 1) rows, n)): the slots are contiguous in position
     if (tc_status s = launch_normals_unsort(ctx, ctx->tgt_index, sorted_all, d_out)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
+}
+
+__global__ void __launch_bounds__(256) slice_orig_index_kernel(const float4 *__restrict__ pts, uint32_t lo, uint32_t count, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = __float_as_uint(pts[lo + i].w);
+}
+
+tc_status tc_sharded_estimate_normals_local_device(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n, const tc_normal_config *cfg,
+                                                   float *d_out_slice, uint32_t *d_orig_index, size_t *first, size_t *count) {
+    if (!comm || !first || !count) return TC_INVALID_DATA;
+    *first = 0; *count = 0;
+    bool empty;
+    if (tc_status s = normals_validate(ctx, n, cfg, &empty)) return s;
+    if (empty) return TC_OK;
+    if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
+    TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t lo = 0, hi = 0;
+    if (tc_status s = sharded_normals_slot(ctx, comm, d_xyz, n, cfg, d_out_slice, lo, hi)) return s;
+    if (d_orig_index && hi > lo) {
+        hipLaunchKernelGGL(slice_orig_index_kernel, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float4 *)ctx->tgt_index.pts.p, (uint32_t)lo, (uint32_t)(hi - lo), d_orig_index);
+        TC_HIP_TRY(ctx, hipGetLastError());
+    }
+    TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *first = lo; *count = hi - lo;
+    return TC_OK;
+}
+
+unsigned long long tc_debug_counter(const tc_context *ctx, int which) {
+    if (!ctx) return 0;
+    return which == TC_COUNTER_INDEXED_POINTS ? ctx->stat_indexed_points : which == TC_COUNTER_INDEX_BUILDS ? ctx->stat_index_builds : 0ull;
 }
 
 tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp_job *jobs, size_t n_jobs,

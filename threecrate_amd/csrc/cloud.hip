@@ -145,7 +145,7 @@ tc_status tc_cloud_sharded_icp(tc_comm *comm, int shard_mode, int point_to_plane
     if (!comm || !target || !result || !init) return TC_INVALID_DATA;
     tc_context *ctx = target->ctx;
     if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
-    if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
+    if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL && shard_mode != TC_SHARD_INDEX) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
     const bool may_be_empty = shard_mode == TC_SHARD_LOCAL && comm->nranks > 1;
     if ((n_source == 0 && !may_be_empty) || target->n == 0) return fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");
     if (point_to_plane && !target->has_normals && !target->has_normals6)

@@ -476,6 +476,8 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
                       const GridGeom *reuse_geom, const IcpState *d_state_transform, const TileGeom *tile_major,
                       float min_cell_edge, float target_ppo, bool strict_order) {
     if (n == 0 || n >= 0xFFFFFFF0ull) return fail(ctx, TC_INVALID_DATA, "build_index: bad point count");
+    ctx->stat_indexed_points += n;
+    ctx->stat_index_builds += 1;
     ix.vor_valid = false;
     ix.occ_host_valid = false;
     hipStream_t st = ctx->stream;

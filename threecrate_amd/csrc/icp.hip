@@ -217,7 +217,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *p) {
 #endif
 __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, float y, float z, float ub2,
                                                  float &best, uint32_t &bestj, bool &refine, float max_dist,
-                                                 uint2 (*spans)[kIcpBlock] TC_STAMP_ARGS) {
+                                                 uint2 (*spans)[kIcpBlock] TC_STAMP_ARGS
+#ifdef TC_ANCHOR_STATS
+                                                 , float &second_lb
+#endif
+                                                 ) {
     const GridGeom &g = gv.g;
     int cx, cy, cz;
     float mf, out2;
@@ -293,6 +297,9 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     const f32x2 qxy = {x, y};
     best = INFINITY;
     bestj = 0xFFFFFFFFu;
+#ifdef TC_ANCHOR_STATS
+    float m2 = INFINITY, m1s = INFINITY;
+#endif
     // The span change is a select inside ONE divergent loop -- a lane leaves when its last span ends; the next span is fetched
     // from LDS at the top of every step -- instead of two nested exec-mask regions per step (`if (j >= e) { if (!mask) break; .. }`):
     // the loop is a single basic block of 68 instructions, 40.1 -> 39.1 us per pass on average (moving 46.0 -> 44.9, aligned 15.6 -> 15.3).
@@ -324,6 +331,18 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         const float m = bb ? m23 : m01;
         const uint32_t im = bb ? i23 : i01;
         const bool upd = m < best;
+#ifdef TC_ANCHOR_STATS
+        {   // the two smallest squared distances seen so far (statistic only: a plain running pair beside the product's best)
+            const float vs[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v = (j + t < e) ? vs[t] : INFINITY;
+                const bool lt1 = v < m1s;
+                m2 = lt1 ? m1s : fminf(m2, v);
+                m1s = lt1 ? v : m1s;
+            }
+        }
+#endif
         best = upd ? m : best;
         bestj = upd ? im : bestj;
         j += 4;
@@ -337,6 +356,11 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
                         (cz - 1 <= 0) && (cz + 1 >= g.gz - 1);
     const float bound = (1.0f + mf - 2e-3f) * g.h;
     refine = !(covers || best <= bound * bound + out2 || (max_dist >= 0.0f && bound > max_dist));
+#ifdef TC_ANCHOR_STATS
+    // lower bound of the distance to every target point other than the best one: the runner-up scanned, what the pruning ball left
+    // out (farther than sqrt(ub2)), what ring 1 cannot see (farther than `bound`)
+    second_lb = fminf(fminf(sqrtf(m2), sqrtf(fmaxf(ub2, 0.0f))), covers ? INFINITY : sqrtf(bound * bound + out2));
+#endif
 }
 
 // per-pair terms -> per-lane f32 accumulators (shared by the main and the refine kernel)
@@ -580,7 +604,39 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             float best = INFINITY;
             uint32_t bestg = 0xFFFFFFFFu;
             bool refine = false;
+#ifdef TC_ANCHOR_STATS
+            // 2-NN anchor statistic: would |T s - p| < (runner-up bound of the last search) - (motion since then) have certified the match?
+            float4 *anc = const_cast<float4 *>(src_cov);
+            float4 a_prev = make_float4(0.f, 0.f, 0.f, -1.0f);
+            if (anc && j < end) a_prev = anc[j];
+            const float mot = sqrtf(d2_nc(a_prev.x, a_prev.y, a_prev.z, x, y, z));
+            const bool cert = in && warm && pj != 0xFFFFFFFFu && a_prev.w >= 0.0f && sqrtf(ub2p) < (a_prev.w - mot) * 0.9999f;
+            float second_lb = INFINITY;
+            {
+                IcpState *sw = const_cast<IcpState *>(st);
+                const unsigned long long act = __ballot(in && warm), kv = __ballot(in && warm && keep), kc = __ballot(in && warm && (keep || cert)), co = __ballot(cert);
+                if (lane == 0 && act) {
+                    atomicAdd(&sw->refine_ring_hist[0], (uint32_t)__popcll(act));
+                    atomicAdd(&sw->refine_ring_hist[1], (uint32_t)__popcll(kv));
+                    atomicAdd(&sw->refine_ring_hist[2], (uint32_t)__popcll(co));
+                    atomicAdd(&sw->refine_ring_hist[3], (uint32_t)__popcll(kc));
+                    atomicAdd(&sw->refine_ring_hist[4], 1u);
+                    if (kv == act) atomicAdd(&sw->refine_ring_hist[5], 1u);
+                    if (kc == act) atomicAdd(&sw->refine_ring_hist[6], 1u);
+                }
+            }
+            // (the statistic scans a ball HALF A CELL wider than the warm-start ball: the previous match's own distance bounds nothing
+            // beyond itself -- a runner-up bound worth having needs the wider scan, which is what a real 2-NN pass would pay for)
+            const float ub2w = (sqrtf(ub2) + 0.5f * g.h) * (sqrtf(ub2) + 0.5f * g.h);
+            if (__ballot(in && !keep) != 0ull) nn_search_pruned(tgt, x, y, z, (keep || !in) ? -1.0f : ub2w, best, bestg, refine, max_dist, spans TC_STAMP_PASS, second_lb);
+            if (anc && j < end) {
+                // a searched lane gets a fresh bound; a kept one carries the old bound minus what it moved
+                const float nb = (in && !keep) ? (refine ? -1.0f : second_lb) : (a_prev.w >= 0.0f ? a_prev.w - mot : -1.0f);
+                anc[j] = make_float4(x, y, z, nb);
+            }
+#else
             if (__ballot(in && !keep) != 0ull) nn_search_pruned(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans TC_STAMP_PASS);
+#endif
             if (keep) { best = ub2p; bestg = pj; }
             refine = refine && in && !keep;
             if ((dbg & 8) && lane == 0) {          // statistics: wave trips / trips without a search
@@ -1707,6 +1763,13 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
         src_cov = (const float4 *)ctx->gicp_src_cov.p;
     }
     const float4 *nrm = (const float4 *)(*su.tix).normals.p;
+#ifdef TC_ANCHOR_STATS
+    if (mode != 2) {
+        if (tc_status s = ensure(ctx, ctx->gicp_src_cov, ns * sizeof(float4))) return s;
+        TC_HIP_TRY(ctx, hipMemsetAsync(ctx->gicp_src_cov.p, 0xFF, ns * sizeof(float4), st));      // w = NaN pattern -> "no anchor" (w >= 0 fails)
+        src_cov = (const float4 *)ctx->gicp_src_cov.p;
+    }
+#endif
 
     size_t enq = 0;
     // bounds that already exist (a cloud handle whose normals were estimated here, or that has been a target before) serve from
@@ -1765,6 +1828,12 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
         }
         fprintf(stderr, "\n");
     }
+#ifdef TC_ANCHOR_STATS
+    fprintf(stderr, "[tc] anchor stats over %u iterations: warm lanes %u | kept by the inscribed ball %.2f %% | certified by the 2-NN anchor %.2f %% | either %.2f %% || wave trips %u | all lanes kept (ball) %.2f %% | all lanes kept (ball or anchor) %.2f %%\n",
+            hs->iterations, hs->refine_ring_hist[0], 100.0 * hs->refine_ring_hist[1] / std::max(hs->refine_ring_hist[0], 1u),
+            100.0 * hs->refine_ring_hist[2] / std::max(hs->refine_ring_hist[0], 1u), 100.0 * hs->refine_ring_hist[3] / std::max(hs->refine_ring_hist[0], 1u),
+            hs->refine_ring_hist[4], 100.0 * hs->refine_ring_hist[5] / std::max(hs->refine_ring_hist[4], 1u), 100.0 * hs->refine_ring_hist[6] / std::max(hs->refine_ring_hist[4], 1u));
+#endif
     if (debug_flags() & 64)
         fprintf(stderr, "[tc] icp: %u iterations, refine queries total %u max %u  exit ring hist %u %u %u %u %u %u %u %u\n", hs->iterations,
                 hs->refine_total, hs->refine_max, hs->refine_ring_hist[0], hs->refine_ring_hist[1], hs->refine_ring_hist[2], hs->refine_ring_hist[3],
@@ -1804,24 +1873,33 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     const int mode = p2plane ? 1 : 0;
     const int W = comm ? comm->nranks : 1, rank = comm ? comm->rank : 0;
     IcpSetup su;
+    // TC_SHARD_INDEX: this rank's ORIGINAL-index range of the replicated source -- only those points are ordered by target cell
+    // (the per-call set-up shrinks with 1 / W; TC_SHARD_SPATIAL orders the whole source on every rank and takes a range of the order)
+    const size_t rows = (ns + (size_t)W - 1) / (size_t)W;
+    size_t ilo = 0, ihi = ns;
+    if (shard_mode == TC_SHARD_INDEX) { ilo = std::min((size_t)rank * rows, ns); ihi = std::min(ilo + rows, ns); }
+    const size_t n_setup = ihi - ilo;              // source points this rank's set-up sees
     // (TC_SHARD_SPATIAL over several ranks: every rank sorts the replicated source and takes a range of positions -- the ranks must
     // agree on the order, also inside a cell too populous for the deterministic re-rank: build_index(strict_order))
-    tc_status setup_rc = icp_setup(ctx, p2plane, d_src, ns, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, 0, tgt_prebuilt, nullptr,
+    tc_status setup_rc = icp_setup(ctx, p2plane, d_src + 3 * ilo, n_setup, d_tgt, nt, d_nrm, nstride, init, max_dist, conv_thr, su, 0, tgt_prebuilt, nullptr,
                                    shard_mode == TC_SHARD_SPATIAL && W > 1);
     // Everything that can fail on ONE rank happens before the first collective, and the ranks agree on it: the inscribed-ball
-    // bounds' buffer (the loop computes them at iteration 6) is allocated here, so that no fallible host path sits between two
-    // all-reduces -- a rank returning early from inside the loop would leave its peers waiting in ncclAllReduce for ever.
+    // bounds' buffer (the loop computes them at iteration 6) and the gathered correspondence array are allocated here, so that no
+    // fallible host path sits between two collectives -- a rank returning early from inside the loop would leave its peers waiting
+    // in ncclAllReduce for ever.
     if (setup_rc == TC_OK && !su.tix->vor_valid) setup_rc = ensure(ctx, su.tix->vor, (size_t)su.tix->geom.n * sizeof(float4));
+    const bool gather_index = shard_mode == TC_SHARD_INDEX && res->corr_target && ns > 0 && (W > 1 || (comm && comm->nccl));
+    if (setup_rc == TC_OK && gather_index) setup_rc = ensure(ctx, ctx->out_a, (size_t)W * rows * sizeof(uint32_t));
     if (tc_status s = comm_agree(comm, setup_rc)) return s;
     hipStream_t st = ctx->stream;
     IcpState *dstate = (IcpState *)ctx->state.p;
-    // this rank's range of the tile-major sorted source: a spatially compact shard (TC_SHARD_SPATIAL), or everything it was given
-    size_t lo = 0, hi = ns;
+    // this rank's range of the tile-major sorted source: a spatially compact shard (TC_SHARD_SPATIAL), or everything it set up
+    size_t lo = 0, hi = n_setup;
     if (shard_mode == TC_SHARD_SPATIAL) { lo = ns * (size_t)rank / (size_t)W; hi = ns * ((size_t)rank + 1) / (size_t)W; }
     const size_t nl = hi - lo;
     const IcpLaunch l = plan_launch(nl);
-    // corr (ns) | corr_pos (nl) | refine counts + entries -- inside the buffer icp_setup sized for the whole source
-    uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns, *rlist = corr + 2 * ns;
+    // corr (n_setup) | corr_pos (nl) | refine counts + entries -- inside the buffer icp_setup sized for the points it was given
+    uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + n_setup, *rlist = corr + 2 * n_setup;
     double *partials = (double *)ctx->partials.p;
     const float4 *src = su.src + lo;
     const float4 *nrm = (const float4 *)(*su.tix).normals.p;
@@ -1847,15 +1925,27 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
     TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
     if (res->corr_target && ns > 0) {
-        const bool gather = shard_mode == TC_SHARD_SPATIAL && (W > 1 || (comm && comm->nccl));
-        // the write-out kernel scatters by ORIGINAL source index: with the source sharded spatially every rank fills its own
-        // entries of a zeroed array and one all-reduce(sum) of n_source words completes it everywhere
-        if (gather) hipLaunchKernelGGL(icp_zero_u32_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, corr, (uint32_t)ns);
-        if (nl > 0)
-            hipLaunchKernelGGL(icp_write_corr_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, su.tv, src, (uint32_t)nl, corr_pos, corr);
-        if (gather)
-            if (tc_status s = comm_allreduce_u32(comm, corr, ns)) return s;
-        TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        if (gather_index) {
+            // every rank writes the matches of ITS index range (the write-out kernel scatters by the index inside the slice) into its
+            // slot of `rows` entries; one in-place all-gather of the slots completes the dense array everywhere: 4 ns bytes in total
+            // (the spatial mode's all-reduce moves ns words per rank through a reduction)
+            uint32_t *all = (uint32_t *)ctx->out_a.p;
+            if (nl > 0)
+                hipLaunchKernelGGL(icp_write_corr_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, su.tv, src, (uint32_t)nl, corr_pos,
+                                   all + (size_t)rank * rows);
+            if (tc_status s = comm_allgather(comm, all, rows * sizeof(uint32_t))) return s;
+            TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, all, ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        } else {
+            const bool gather = shard_mode == TC_SHARD_SPATIAL && (W > 1 || (comm && comm->nccl));
+            // the write-out kernel scatters by ORIGINAL source index: with the source sharded spatially every rank fills its own
+            // entries of a zeroed array and one all-reduce(sum) of n_source words completes it everywhere
+            if (gather) hipLaunchKernelGGL(icp_zero_u32_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, corr, (uint32_t)ns);
+            if (nl > 0)
+                hipLaunchKernelGGL(icp_write_corr_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, su.tv, src, (uint32_t)nl, corr_pos, corr);
+            if (gather)
+                if (tc_status s = comm_allreduce_u32(comm, corr, ns)) return s;
+            TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, n_setup * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        }
     }
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
     TC_HIP_TRY(ctx, hipGetLastError());

@@ -1244,11 +1244,75 @@ __device__ __forceinline__ uint32_t coop_nearest(const GridView &gv, float qx, f
     return total;
 }
 
+// Radius mode beyond the register list (k_neighbors > 128 with a radius; the reference has no cap on either, normals.rs:17-26,
+// :141-146): the block enumerates the ball of `radius` clipped to the grid -- rows dealt to the threads, closed-form x windows,
+// like coop_nearest -- and folds count + first and second moments (about the query, f64) of every record within it except the
+// query: mom[0] = count, mom[1..3] = sum d, mom[4..9] = sum d d^T (xx xy xz yy yz zz).  Fixed order (a thread's rows in ascending
+// order, wave shuffle tree, waves in order): deterministic.  A set of >= k members IS the neighbourhood (order-free f64 moments +
+// closed-form eigenvector, exactly what the lane-per-point kernel does with a radius set too large for its list); fewer: the k-NN
+// path (normals.rs:315-323).
+__device__ __forceinline__ void coop_radius_moments(const GridView &gv, float qx, float qy, float qz, uint32_t p, float radius, double (*red)[10],
+                                                    double (&mom)[10]) {
+    const GridGeom &g = gv.g;
+    const int tid = threadIdx.x;
+    const float r2 = radius * radius;
+    double a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float ry = radius * 1.0001f + 4e-3f * g.h;
+    const int y0 = cell_coord(fminf(fmaxf(qy - ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy), y1 = cell_coord(fminf(fmaxf(qy + ry, g.miny), g.maxy), g.miny, g.inv_h, g.gy);
+    const int z0 = cell_coord(fminf(fmaxf(qz - ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz), z1 = cell_coord(fminf(fmaxf(qz + ry, g.minz), g.maxz), g.minz, g.inv_h, g.gz);
+    const int ny = y1 - y0 + 1;
+    const uint32_t nrows = (uint32_t)ny * (uint32_t)(z1 - z0 + 1);
+    for (uint32_t ri = (uint32_t)tid; ri < nrows; ri += kCoopThreads) {
+        const int zz = z0 + (int)(ri / (uint32_t)ny), yy = y0 + (int)(ri % (uint32_t)ny);
+        const float gy = g.clamped ? axis_gap_n<true>(qy, g.miny, g.h, yy, g.gy - 1) : axis_gap_n<false>(qy, g.miny, g.h, yy, g.gy - 1);
+        const float gz = g.clamped ? axis_gap_n<true>(qz, g.minz, g.h, zz, g.gz - 1) : axis_gap_n<false>(qz, g.minz, g.h, zz, g.gz - 1);
+        const float rg = gy * gy + gz * gz;
+        if (rg > r2) continue;
+        const float rx = sqrtf(fmaxf(r2 - rg, 0.0f)) * 1.0001f + 4e-3f * g.h;
+        const int xa = (int)fminf(fmaxf((qx - rx - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
+        const int xb = (int)fmaxf(fminf((qx + rx - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
+        if (xa > xb) continue;
+        const uint32_t row = ((uint32_t)zz * g.gy + yy) * g.gx;
+        const uint32_t s = gv.cell_start[row + xa], e = gv.cell_start[row + xb + 1];
+        for (uint32_t j = s; j < e; ++j) {
+            const float4 c = gv.pts[j];
+            const float v = d2_nc(c.x, c.y, c.z, qx, qy, qz);
+            if (j == p || !(v <= r2)) continue;                      // nearest_neighbor.rs:254-298: d2 <= r2; the query itself is dropped
+            const double dx = (double)c.x - (double)qx, dy = (double)c.y - (double)qy, dz = (double)c.z - (double)qz;
+            a[0] += 1.0;
+            a[1] += dx; a[2] += dy; a[3] += dz;
+            a[4] = fma(dx, dx, a[4]); a[5] = fma(dx, dy, a[5]); a[6] = fma(dx, dz, a[6]);
+            a[7] = fma(dy, dy, a[7]); a[8] = fma(dy, dz, a[8]); a[9] = fma(dz, dz, a[9]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        double v = a[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        a[i] = v;
+    }
+    __syncthreads();                                  // (red may still be read by the previous point's consumers)
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) red[tid >> 6][i] = a[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kCoopThreads / 64; ++w) v += red[w][i];
+        mom[i] = v;
+    }
+}
+
 template <int CAPB>
 __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv, NormalParams prm, float *__restrict__ out6, uint32_t *__restrict__ hard) {
     __shared__ CoopShared<CAPB> sh;
     __shared__ float nbx[CAPB / 2], nby[CAPB / 2], nbz[CAPB / 2];
     __shared__ int self_s;
+    __shared__ double rmom[kCoopThreads / 64][10];
     const GridGeom &g = gv.g;
     const int tid = threadIdx.x;
     const uint32_t count = hard ? hard[0] : prm.p_end - prm.p_begin;
@@ -1263,6 +1327,29 @@ __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv,
         if (p >= nfin) {            // a non-finite point: the default normal (see normals_point)
             if (tid == 0) { px = prm.xyz[3 * (size_t)orig]; py = prm.xyz[3 * (size_t)orig + 1]; pz = prm.xyz[3 * (size_t)orig + 2]; }
         } else {
+            bool by_radius = false;
+            if (prm.has_radius && !hard) {
+                double mom[10];
+                coop_radius_moments(gv, q.x, q.y, q.z, p, prm.radius, rmom, mom);
+                by_radius = mom[0] >= (double)prm.k;                 // normals.rs:315: fewer than k members -> the k-NN fallback
+                if (by_radius && tid == 0) {
+                    const double nn = mom[0] + 1.0;                  // + the query itself (normals.rs:338-340), at offset 0
+                    const double mx = mom[1] / nn, my = mom[2] / nn, mz = mom[3] / nn;
+                    double ex, ey, ez;
+                    smallest_eigvec_sym3(mom[4] / nn - mx * mx, mom[5] / nn - mx * my, mom[6] / nn - mx * mz, mom[7] / nn - my * my,
+                                         mom[8] / nn - my * mz, mom[9] / nn - mz * mz, ex, ey, ez);
+                    const float vx = (float)ex, vy = (float)ey, vz = (float)ez;
+                    const float mag = sqrtf(vx * vx + vy * vy + vz * vz);
+                    if (mag > 1e-6f) { nrm_x = vx / mag; nrm_y = vy / mag; nrm_z = vz / mag; }
+                    if (prm.orient) {
+                        const float tx = prm.vx - q.x, ty = prm.vy - q.y, tz = prm.vz - q.z;
+                        const float tn = sqrtf(tx * tx + ty * ty + tz * tz);
+                        const float dp = nrm_x * (tx / tn) + nrm_y * (ty / tn) + nrm_z * (tz / tn);
+                        if (dp < 0.0f) { nrm_x = -nrm_x; nrm_y = -nrm_y; nrm_z = -nrm_z; }
+                    }
+                }
+            }
+            if (!by_radius) {
             const uint32_t K1 = min(prm.k + 1u, nfin);
             if (tid == 0) self_s = -1;
             const uint32_t total = coop_nearest<CAPB>(gv, q.x, q.y, q.z, K1, nfin, sh);
@@ -1317,6 +1404,7 @@ __global__ void __launch_bounds__(kCoopThreads) normals_coop_kernel(GridView gv,
                     if (dp < 0.0f) { nrm_x = -nrm_x; nrm_y = -nrm_y; nrm_z = -nrm_z; }
                 }
             }
+            }   // !by_radius
         }
         if (tid == 0) {
             if (prm.sorted_nrm) prm.sorted_nrm[p] = make_float4(nrm_x, nrm_y, nrm_z, 0.0f);
@@ -1637,7 +1725,7 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
     const bool radius_mode = cfg.has_radius && cfg.radius > 0.0f;
     // k_neighbors > 128: the wave-per-point kernel (the k + 1 nearest in an LDS buffer instead of a register list), up to 2047
     const bool big_k = cfg.k_neighbors + 1 > 129;
-    if (big_k && radius_mode) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 128 together with a radius is not supported by the HIP backend");
+    // (k_neighbors > 128 together with a radius: the wave-per-point kernel folds the radius ball's moments itself -- coop_radius_moments)
     if (cfg.k_neighbors + 1 > 2048) return fail(ctx, TC_UNSUPPORTED, "k_neighbors > 2047 is not supported by the HIP backend");
     NormalParams prm;
     prm.hard_list = nullptr;

@@ -169,6 +169,7 @@ struct tc_context {
     tc::DevBuf overflow;            // scratch (voxel filter: occupied-cell flags / output slots)
     tc::DevBuf build_tmp;           // index build: the records in arrival order, before the in-cell re-rank (float4 * n)
     tc::DevBuf normals_hard;        // normals: count + positions of the points handed to the wave-per-point kernel
+    unsigned long long stat_indexed_points = 0, stat_index_builds = 0;   // tc_debug_counter
     bool normals_hard_clean = false; // its header (count, exit ticket) is known to be zero: the last serving launch went through
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)

@@ -215,6 +215,20 @@ def _icp_args(ctx, source, target, init, max_correspondence_distance):
     return s, t, i7, md
 
 
+def _shard_mode(comm, source_is_local_slice, shard):
+    """TC_SHARD_LOCAL for a caller-partitioned source; otherwise the full source is replicated and the library takes this rank's
+    part: by ORIGINAL-index range (TC_SHARD_INDEX: each rank orders ns / W points -- the default for more than one rank, the
+    per-call set-up shrinks with the rank count) or as a spatially compact range of the source ordered by target cell
+    (TC_SHARD_SPATIAL: every rank orders the whole source)."""
+    if source_is_local_slice:
+        return _lib.TC_SHARD_LOCAL
+    if shard is None:
+        shard = "index" if comm.size > 1 else "spatial"
+    if shard not in ("index", "spatial"):
+        raise ValueError("shard: 'index' or 'spatial'")
+    return _lib.TC_SHARD_INDEX if shard == "index" else _lib.TC_SHARD_SPATIAL
+
+
 def _finish(ctx, r, corr, correspondences):
     import torch
     if corr is not None and correspondences != "device":      # "device": the dense per-source index stays as written (int32 bits, -1 = none)
@@ -224,7 +238,7 @@ def _finish(ctx, r, corr, correspondences):
 
 def sharded_icp_point_to_plane(ctx, source, target, target_normals, init=None, max_iters=50,
                                max_correspondence_distance=None, convergence_threshold=1e-6, group=None,
-                               source_is_local_slice=False, comm=None, correspondences=False):
+                               source_is_local_slice=False, comm=None, correspondences=False, shard=None):
     """icp_point_to_plane_detailed (registration.rs:508-602) over all ranks of `comm` (default: Comm.from_group(ctx,
     group)) through tc_sharded_icp_point_to_plane_device: `source` is the full source cloud, replicated (the library
     takes a spatially compact range of it per rank: TC_SHARD_SPATIAL), or -- source_is_local_slice=True -- this rank's
@@ -245,7 +259,7 @@ def sharded_icp_point_to_plane(ctx, source, target, target_normals, init=None, m
         r.corr_target = corr.data_ptr() if corr is not None else None
         ctx._order(t.device)
         ctx._check(_lib.load().tc_sharded_icp_point_to_plane_device(
-            ctx._h, comm._h, _lib.TC_SHARD_LOCAL if source_is_local_slice else _lib.TC_SHARD_SPATIAL, s.data_ptr(), s.shape[0],
+            ctx._h, comm._h, _shard_mode(comm, source_is_local_slice, shard), s.data_ptr(), s.shape[0],
             t.data_ptr(), t.shape[0], n.data_ptr() + (12 if stride == 6 else 0), nn, stride, i7.ctypes.data, max_iters, md,
             convergence_threshold, C.byref(r)))
         return _finish(ctx, r, None if corr is None else corr[: s.shape[0]], correspondences)
@@ -256,7 +270,7 @@ def sharded_icp_point_to_plane(ctx, source, target, target_normals, init=None, m
 
 def sharded_icp_against_cloud(ctx, source, target_cloud, init=None, max_iters=50, max_correspondence_distance=None,
                               convergence_threshold=1e-6, point_to_plane=True, group=None, source_is_local_slice=False, comm=None,
-                              correspondences=False):
+                              correspondences=False, shard=None):
     """The same registration against a TARGET HANDLE (tc.Cloud, the same cloud on every rank): tc_cloud_sharded_icp.  Index, normals
     and inscribed-ball bounds of the target are built once per handle instead of once per call."""
     import torch
@@ -273,7 +287,7 @@ def sharded_icp_against_cloud(ctx, source, target_cloud, init=None, max_iters=50
         corr = torch.empty(max(1, s.shape[0]), dtype=torch.int32, device=s.device) if correspondences else None
         r.corr_target = corr.data_ptr() if corr is not None else None
         ctx._order(s.device)
-        ctx._check(_lib.load().tc_cloud_sharded_icp(comm._h, _lib.TC_SHARD_LOCAL if source_is_local_slice else _lib.TC_SHARD_SPATIAL,
+        ctx._check(_lib.load().tc_cloud_sharded_icp(comm._h, _shard_mode(comm, source_is_local_slice, shard),
                                                     1 if point_to_plane else 0, s.data_ptr(), s.shape[0], target_cloud._h, i7.ctypes.data,
                                                     max_iters, md, convergence_threshold, C.byref(r)))
         return _finish(ctx, r, None if corr is None else corr[: s.shape[0]], correspondences)
@@ -283,7 +297,7 @@ def sharded_icp_against_cloud(ctx, source, target_cloud, init=None, max_iters=50
 
 
 def sharded_icp_detailed(ctx, source, target, init=None, max_iters=50, max_correspondence_distance=None,
-                         convergence_threshold=1e-6, group=None, source_is_local_slice=False, comm=None, correspondences=False):
+                         convergence_threshold=1e-6, group=None, source_is_local_slice=False, comm=None, correspondences=False, shard=None):
     """icp_detailed (registration.rs:258-370, point-to-point) over all ranks: tc_sharded_icp_detailed_device."""
     import torch
     own = comm is None
@@ -297,7 +311,7 @@ def sharded_icp_detailed(ctx, source, target, init=None, max_iters=50, max_corre
         r.corr_target = corr.data_ptr() if corr is not None else None
         ctx._order(t.device)
         ctx._check(_lib.load().tc_sharded_icp_detailed_device(
-            ctx._h, comm._h, _lib.TC_SHARD_LOCAL if source_is_local_slice else _lib.TC_SHARD_SPATIAL, s.data_ptr(), s.shape[0],
+            ctx._h, comm._h, _shard_mode(comm, source_is_local_slice, shard), s.data_ptr(), s.shape[0],
             t.data_ptr(), t.shape[0], i7.ctypes.data, max_iters, md, convergence_threshold, C.byref(r)))
         return _finish(ctx, r, None if corr is None else corr[: s.shape[0]], correspondences)
     finally:
@@ -320,6 +334,30 @@ def sharded_estimate_normals(ctx, cloud, k=10, config=None, group=None, comm=Non
         ctx._order(x.device)
         ctx._check(_lib.load().tc_sharded_estimate_normals_device(ctx._h, comm._h, x.data_ptr(), x.shape[0], C.byref(c), out.data_ptr()))
         return out
+    finally:
+        if own:
+            comm.close()
+
+
+def sharded_estimate_normals_local(ctx, cloud, k=10, config=None, group=None, comm=None):
+    """This rank's part of the normals of a replicated cloud WITHOUT the all-gather (tc_sharded_estimate_normals_local_device): the
+    records (count, 6) of the cell-sorted positions [first, first + count) and the input index of each.  -> (records, orig_index,
+    first).  For callers that keep the normals sharded (240 MB at 10 M points is what bounds the gathered call on 8 GPUs)."""
+    import torch
+    from .api import NormalEstimationConfig
+    own = comm is None
+    comm = comm or Comm.from_group(ctx, group)
+    try:
+        c = ctx._cfg(config or NormalEstimationConfig(k_neighbors=k))
+        x = cloud.detach().to(torch.float32).contiguous().reshape(-1, 3)
+        rows = -(-x.shape[0] // comm.size) if x.shape[0] else 0
+        out = torch.empty((max(rows, 1), 6), dtype=torch.float32, device=x.device)
+        idx = torch.empty(max(rows, 1), dtype=torch.int32, device=x.device)
+        first, count = C.c_size_t(0), C.c_size_t(0)
+        ctx._order(x.device)
+        ctx._check(_lib.load().tc_sharded_estimate_normals_local_device(ctx._h, comm._h, x.data_ptr(), x.shape[0], C.byref(c), out.data_ptr(),
+                                                                        idx.data_ptr(), C.byref(first), C.byref(count)))
+        return out[: count.value], idx[: count.value], int(first.value)
     finally:
         if own:
             comm.close()
