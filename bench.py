@@ -541,7 +541,7 @@ def main():
         src_h, tgt_h, _ = synth.registration_pair(n, seed=1 + rank, transform=T_true, noise_sigma=NOISE_REL)
     src, tgt = torch.from_numpy(src_h).to(dev), torch.from_numpy(tgt_h).to(dev)
     ctx = tc.GpuContext(local_rank)
-    # sampled hipEvents around the dominant kernel only (every 4th launch): ~1 % overhead in the timed region
+    # sampled hipEvents around the dominant kernel only (every 17th launch: an event is a ~6 us bubble on the stream): ~1 % overhead in the timed region
     ctx.profile_enable(2)
 
     def step():
@@ -747,10 +747,11 @@ def main():
             # The other BASELINE configs, measured by the same run (outside the timed region, a few seconds each): configs[3] the
             # 10 M-point cloud through the sharded entry points with a REAL one-rank RCCL communicator, configs[4] the LiDAR frame
             # stream, configs[2]'s cloud shape as one pair.  Each with its own algorithmic bytes and fractions.
-            for key, fn in (("sharded_10m", lambda: measure_sharded(ctx, dev, 10_000_000, 3, 1)),
-                            ("frame_stream", lambda: measure_stream(ctx, 20, 1)),
-                            ("tum_pair", lambda: measure_tum_pair(ctx, dev, 3, 1))):
+            for key, fn in (("frame_stream", lambda: measure_stream(ctx, 50, 2)),
+                            ("tum_pair", lambda: measure_tum_pair(ctx, dev, 3, 1)),
+                            ("sharded_10m", lambda: measure_sharded(ctx, dev, 10_000_000, 3, 1))):
                 try:
+                    ctx.trim()            # (the blocks the previous workload parked in the context's pool: each line starts from a clean pool)
                     line = fn()
                     for drop in ("collective", "ranks", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
                         line.pop(drop, None)

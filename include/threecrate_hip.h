@@ -515,8 +515,8 @@ void      tc_frame_stream_destroy(tc_frame_stream *s);
 tc_status tc_read_kitti_bin(const char *path, float *out_xyz, size_t capacity_points, size_t *n_points);
 
 /* ---- profiling ---- */
-/* on: 0 = off, 1 = hipEvents around every kernel, 2 = only around every 4th launch of the dominant
-   kernel (icp_correspond_reduce): ~1 % overhead, used inside bench.py's timed region */
+/* on: 0 = off, 1 = hipEvents around every kernel, 2 = only around every 17th launch of the dominant
+   kernel (icp_correspond_reduce): ~1 % overhead (an event is a ~6 us bubble on the stream), used inside bench.py's timed region */
 void   tc_profile_enable(tc_context *ctx, int on);
 void   tc_profile_reset(tc_context *ctx);
 size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap);

@@ -2,6 +2,7 @@
 // order and precedence, host<->device staging, error mapping.  No CPU fallback exists: every
 // compute entry point needs a HIP device and returns TC_GPU otherwise.
 #include "tc_internal.h"
+#include <sched.h>
 
 #include <algorithm>
 #include <cmath>
@@ -78,7 +79,10 @@ tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes) {
 
 ProfScope::ProfScope(tc_context *c, const char *name, bool dominant) : ctx(c) {
     if (!ctx->profiling) return;
-    if (ctx->profiling == 2 && (!dominant || (ctx->prof_tick++ & 3u) != 0)) return;
+    // (mode 2: every 17th launch of the dominant kernel -- a stride coprime to the usual 50 iterations per call, so that the sampled
+    // iteration indices walk through all of 0 .. 49 over the calls and the cold first pass is sampled as often as any other.  An event on the stream is a ~5.7 us bubble on either side of the kernel --
+    // every 4th launch, as until round 4, was 2.9 us per ICP iteration = 5 % of the timed region, not the 1 % once estimated.)
+    if (ctx->profiling == 2 && (!dominant || (ctx->prof_tick++ % 17u) != 0)) return;
     for (size_t i = 0; i < ctx->timers.size(); ++i)
         if (ctx->timers[i].name == name) { idx = (int)i; break; }
     if (idx < 0) { ctx->timers.push_back(KernelTimer{name, {}, 0, 0.0, 1e300, 0.0}); idx = (int)ctx->timers.size() - 1; }
@@ -95,6 +99,33 @@ ProfScope::~ProfScope() {
     if (idx < 0) return;
     (void)hipEventRecord(e1, ctx->stream);
     ctx->timers[idx].pending.emplace_back(e0, e1);
+}
+
+bool pinned_poll_enabled() {
+    static const bool on = [] { const char *e = getenv("TC_NO_PINNED_POLL"); return !(e && atoi(e) != 0); }();
+    return on;
+}
+
+void *pinned_dev_ptr(tc_context *ctx, const void *host_addr) {
+    if (!ctx->pinned_dev) {
+        void *d = nullptr;
+        if (hipHostGetDevicePointer(&d, ctx->pinned, 0) != hipSuccess) return nullptr;
+        ctx->pinned_dev = d;
+    }
+    return (char *)ctx->pinned_dev + ((const char *)host_addr - (const char *)ctx->pinned);
+}
+
+tc_status wait_pinned_word(tc_context *ctx, volatile uint32_t *word, const char *what) {
+    for (unsigned spins = 0; *word == 0u; ++spins) {
+        if ((spins & 1023u) == 1023u) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) { if (*word == 0u) return fail(ctx, TC_GPU, std::string("internal error: ") + what + ": the stream drained without the word being written"); break; }
+            if (q != hipErrorNotReady) return fail(ctx, TC_GPU, std::string(what) + ": " + hipGetErrorString(q));
+        }
+        if (spins > 4096u) sched_yield(); else __builtin_ia32_pause();       // (a long wait gives the core away: ranks share the host's quota)
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return TC_OK;
 }
 
 static void free_buf(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }

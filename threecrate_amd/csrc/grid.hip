@@ -42,8 +42,10 @@ constexpr int kBboxBlocks = 256;
 // falls into one sixteenth of its range: ~n/64 points each, pseudo-random in the index (NOT every 64th point: organised
 // scans are periodic in 64 -- beams, image columns -- and a sample must not be one beam).  A handful of far outliers
 // shows up in the exact box but almost never in more than two of the four samples: the host compares them (cloud_bbox_impl).
+// box / sbox may live in the context's pinned HOST block (cloud_bbox_impl): every block fences its partials to system scope and
+// takes a ticket; the last one raises *done (also pinned): the host polls that word -- no copy kernels, no stream synchronisation.
 __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, float *__restrict__ box,
-                                                  float *__restrict__ sbox) {
+                                                  float *__restrict__ sbox, uint32_t *__restrict__ ticket, uint32_t *__restrict__ done) {
     __shared__ float sm[4][6];
     __shared__ float ss[4][4][6];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -98,6 +100,17 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
         float v = ss[0][sidx][c];
         for (int w = 1; w < 4; ++w) v = (c < 3) ? fminf(v, ss[w][sidx][c]) : fmaxf(v, ss[w][sidx][c]);
         sbox[blockIdx.x * 24 + threadIdx.x] = v;
+    }
+    if (done) {
+        if (threadIdx.x < 24) __threadfence_system();                 // the storing lanes' partials are out before the ticket
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1u) {
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (clean for the next launch)
+                __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -204,7 +217,8 @@ __global__ void __launch_bounds__(1024) scan_top_kernel(uint32_t *__restrict__ b
 
 __global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t n,
                                                                 uint32_t *__restrict__ blocksum,
-                                                                uint32_t *__restrict__ out /* n+1 */, uint32_t *__restrict__ occ_out, int prefixed) {
+                                                                uint32_t *__restrict__ out /* n+1 */, uint32_t *__restrict__ occ_out, int prefixed,
+                                                                unsigned long long *__restrict__ occ_host) {
     __shared__ uint32_t wtot[kScanBlock / 64];
     __shared__ uint32_t wpre[kScanBlock / 64], wnz[kScanBlock / 64];
     uint32_t pre = 0, nzt = 0;
@@ -241,6 +255,9 @@ __global__ void __launch_bounds__(kScanBlock) scan_apply_kernel(const uint32_t *
         for (int w = 0; w < kScanBlock / 64; ++w) t += wnz[w];
         blocksum[2 * gridDim.x] = t;
         if (occ_out) *occ_out = t;          // (build_index: kept in front of the prefix sums -- the normals kernel picks its path by it)
+        // (build_index's edge adaptation: count + flag in ONE 8-byte word of the pinned host block, which the host polls while the
+        // rest of the build runs -- no copy kernel, no stream synchronisation behind the build)
+        if (occ_host) __hip_atomic_store(occ_host, (1ull << 32) | (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     uint32_t run = block_pre + woff + inc - s;
 #pragma unroll
@@ -405,7 +422,8 @@ TileGeom make_tiles(const GridGeom &g, int tx, int ty, int tz) {
     return t;
 }
 
-tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out, DevBuf &blocksum, uint32_t *occ_out) {
+tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out, DevBuf &blocksum, uint32_t *occ_out,
+                             unsigned long long *occ_host) {
     hipStream_t st = ctx->stream;
     const uint32_t nscan = (n + kScanTile - 1) / kScanTile;
     if (tc_status s = ensure(ctx, blocksum, ((size_t)2 * nscan + 1) * sizeof(uint32_t))) return s;   // sums | non-zero counts | their total
@@ -414,7 +432,7 @@ tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, 
     const char *fm = getenv("TC_SCAN_FUSED_MAX");
     const bool prefixed = nscan > (fm ? (uint32_t)atoi(fm) : kScanFusedMax);
     if (prefixed) hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, (uint32_t *)blocksum.p, nscan);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p, d_out, occ_out, prefixed ? 1 : 0);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nscan), dim3(kScanBlock), 0, st, d_in, n, (uint32_t *)blocksum.p, d_out, occ_out, prefixed ? 1 : 0, occ_host);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
 }
@@ -428,16 +446,35 @@ static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, 
     const int nb = (int)((n + 255) / 256);
     const int bb = std::min(nb, kBboxBlocks);
     const bool robust = rmn != nullptr && n >= 4096;
-    if (tc_status s = ensure(ctx, ctx->bbox, (size_t)kBboxBlocks * 30 * sizeof(float))) return s;
-    float *d_box = (float *)ctx->bbox.p, *d_sbox = d_box + (size_t)kBboxBlocks * 6;
+    // The per-block partials go straight into the pinned host block and the host polls the word the last block raises: no
+    // device-to-host copy kernels, no stream synchronisation (TC_NO_PINNED_POLL=1: the copies + synchronisation of rounds 1-3).
+    // ctx->bbox: ticket word (zero between launches: the last block resets it) | the partials when they are copied.
+    const bool poll = pinned_poll_enabled();
+    const bool fresh = ctx->bbox.p == nullptr;
+    if (tc_status s = ensure(ctx, ctx->bbox, 256 + (size_t)kBboxBlocks * 30 * sizeof(float))) return s;
+    if (fresh) TC_HIP_TRY(ctx, hipMemsetAsync(ctx->bbox.p, 0, 256, st));
+    float *hb = (float *)((char *)ctx->pinned + 2048), *hs = (float *)((char *)ctx->pinned + 16384);
+    volatile uint32_t *h_done = (volatile uint32_t *)((char *)ctx->pinned + 2048 + 8192 + 192);
+    float *d_box = (float *)((char *)ctx->bbox.p + 256), *d_sbox = d_box + (size_t)kBboxBlocks * 6;
+    uint32_t *d_done = nullptr;
+    if (poll) {
+        d_box = (float *)pinned_dev_ptr(ctx, hb); d_sbox = (float *)pinned_dev_ptr(ctx, hs);
+        d_done = (uint32_t *)pinned_dev_ptr(ctx, (const void *)h_done);
+        if (!d_box || !d_sbox || !d_done) return fail(ctx, TC_GPU, "bbox: the pinned block has no device address");
+        *h_done = 0u;
+    }
     {
         ProfScope ps(ctx, "bbox");
-        hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, d_box, robust ? d_sbox : nullptr);
+        hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, d_box, robust ? d_sbox : nullptr, (uint32_t *)ctx->bbox.p, d_done);
     }
-    float *hb = (float *)((char *)ctx->pinned + 2048), *hs = (float *)((char *)ctx->pinned + 16384);
-    TC_HIP_TRY(ctx, hipMemcpyAsync(hb, d_box, (size_t)bb * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
-    if (robust) TC_HIP_TRY(ctx, hipMemcpyAsync(hs, d_sbox, (size_t)bb * 24 * sizeof(float), hipMemcpyDeviceToHost, st));
-    TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+    TC_HIP_TRY(ctx, hipGetLastError());
+    if (poll) {
+        if (tc_status s = wait_pinned_word(ctx, h_done, "bounding box")) { (void)hipMemsetAsync(ctx->bbox.p, 0, 256, st); return s; }
+    } else {
+        TC_HIP_TRY(ctx, hipMemcpyAsync(hb, d_box, (size_t)bb * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (robust) TC_HIP_TRY(ctx, hipMemcpyAsync(hs, d_sbox, (size_t)bb * 24 * sizeof(float), hipMemcpyDeviceToHost, st));
+        TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
     for (int c = 0; c < 3; ++c) { mn[c] = INFINITY; mx[c] = -INFINITY; }
     for (int b = 0; b < bb; ++b)
         for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hb[6 * b + c]); mx[c] = std::fmax(mx[c], hb[6 * b + 3 + c]); }
@@ -531,12 +568,17 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         if (tc_status s = ensure(ctx, ix.slot, n * sizeof(uint32_t))) return s;
         if (tc_status s = ensure(ctx, ix.arrival, n * sizeof(uint32_t))) return s;
         // nkeys cells + the bucket of the non-finite points behind them
-        if (tc_status s = ensure(ctx, ix.fill, ((size_t)nkeys + 2) * sizeof(uint32_t))) return s;       // (+ the oversized-cell flag)
+        // (+ the oversized-cell flag; rounded up to 256 bytes: a memset whose size is not a multiple of its fill kernel's vector width is
+        // TWO fill kernels on the stream, 3.6 + 4.4 us instead of one)
+        const size_t fill_bytes = (((size_t)nkeys + 2) * sizeof(uint32_t) + 255) & ~(size_t)255;
+        if (tc_status s = ensure(ctx, ix.fill, fill_bytes)) return s;
         if (tc_status s = ensure(ctx, ix.cell_start, (kCellStartFront + (size_t)nkeys + 2 + kCellStartPad) * sizeof(uint32_t))) return s;
         uint32_t *const cs = (uint32_t *)ix.cell_start.p + kCellStartFront;       // zeros in front (the ICP window of cell 0 starts at -1)
         nkeys_final = nkeys; cs_final = cs;
+        const bool check = adapt && attempt < 3;
+        volatile uint32_t *h_occ = (volatile uint32_t *)((char *)ctx->pinned + 2048 + 8192);      // [0] = occupied cells, [1] = written
 
-        TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, ((size_t)nkeys + 2) * sizeof(uint32_t), st));
+        TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, fill_bytes, st));
         // records past the end: huge finite coordinates -> d2 = +inf, never a match (kernels may read, never select them)
         {
             ProfScope ps(ctx, "cell_hist");
@@ -547,13 +589,11 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         {
             ProfScope ps(ctx, "cell_scan");
             // (the number of occupied cells also goes to the first word in front of the prefix sums: view.cell_start[-kCellStartFront])
-            if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, nkeys + 1, cs, ix.blocksum, (uint32_t *)ix.cell_start.p)) return s;
-        }
-        const bool check = adapt && attempt < 3;
-        uint32_t *h_occ = (uint32_t *)((char *)ctx->pinned + 2048 + 8192);
-        if (check) {
-            const uint32_t nscan = (nkeys + 1 + kScanTile - 1) / kScanTile;
-            TC_HIP_TRY(ctx, hipMemcpyAsync(h_occ, (const uint32_t *)ix.blocksum.p + 2 * nscan, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            // (with the edge adaptation on, the count also goes to the pinned host block: polled below while place / rerank run)
+            if (check) { h_occ[0] = 0u; h_occ[1] = 0u; }
+            unsigned long long *d_occ_host = (check && pinned_poll_enabled()) ? (unsigned long long *)pinned_dev_ptr(ctx, (const void *)h_occ) : nullptr;
+            if (check && pinned_poll_enabled() && !d_occ_host) return fail(ctx, TC_GPU, "index build: the pinned block has no device address");
+            if (tc_status s = exclusive_scan_u32(ctx, (const uint32_t *)ix.fill.p, nkeys + 1, cs, ix.blocksum, (uint32_t *)ix.cell_start.p, d_occ_host)) return s;
         }
         if (tc_status s = ensure(ctx, ctx->build_tmp, (n + kPtsPad) * sizeof(float4))) return s;       // (shared by every build of the context)
         {
@@ -568,13 +608,21 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         }
         TC_HIP_TRY(ctx, hipGetLastError());
         if (!check) break;
-        // the rest of the build is already enqueued (the usual outcome is to keep it)
-        TC_HIP_TRY(ctx, hipStreamSynchronize(st));
-        const double ppo = (double)n / (double)std::max<uint32_t>(*h_occ, 1u);
-        ix.occ_host = *h_occ; ix.occ_host_valid = true;        // (of THIS attempt's grid: reset below when another attempt follows)
+        // the rest of the build is already enqueued (the usual outcome is to keep it) and keeps running while the host waits for
+        // the scan's word only: the caller's next kernel is enqueued under place / rerank, not behind a drained stream
+        if (pinned_poll_enabled()) {
+            if (tc_status s = wait_pinned_word(ctx, h_occ + 1, "index build (occupied cells)")) return s;
+        } else {
+            const uint32_t nscan = (nkeys + 1 + kScanTile - 1) / kScanTile;
+            TC_HIP_TRY(ctx, hipMemcpyAsync((void *)h_occ, (const uint32_t *)ix.blocksum.p + 2 * nscan, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+        }
+        const uint32_t occ_now = h_occ[0];
+        const double ppo = (double)n / (double)std::max<uint32_t>(occ_now, 1u);
+        ix.occ_host = occ_now; ix.occ_host_valid = true;        // (of THIS attempt's grid: reset below when another attempt follows)
         if (dbg & 256)
             fprintf(stderr, "[tc] index: n %zu h %.5f grid %d x %d x %d = %u cells (%.2f n), %u occupied, %.2f points each (want %.1f)\n", n,
-                    g.h, g.gx, g.gy, g.gz, g.ncell, (double)g.ncell / (double)n, *h_occ, ppo, target_ppo);
+                    g.h, g.gx, g.gy, g.gz, g.ncell, (double)g.ncell / (double)n, occ_now, ppo, target_ppo);
         if (!(ppo > 2.0 * target_ppo)) break;
         double h = (double)g.h * std::min(0.8, std::max(0.35, std::sqrt((double)target_ppo / ppo)));
         if (min_cell_edge > 0.0f) h = std::max(h, (double)min_cell_edge);

@@ -1490,8 +1490,26 @@ __global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const do
 // after the last iteration: not-converged epilogue (registration.rs:343-369 / :595-601)
 // from_sums: the post-loop (sum |T s - q|^2, count) of a sharded point-to-point run sit in st->sums[0..1], already
 // reduced over the ranks (icp_final_mse_fold_kernel + all-reduce); otherwise the per-block rows are folded here
-__global__ void icp_finish_kernel(IcpState *__restrict__ st, const double *__restrict__ partials, uint32_t nblocks, int p2plane, int from_sums) {
-    if (threadIdx.x != 0 || st->done) return;
+// host_out (optional): the pinned host block's copy of the state -- everything in front of `sums` is stored there directly (system
+// scope; the host reads it after the call's final stream synchronisation): no device-to-host copy kernel between this launch and
+// the correspondence write-out
+constexpr int kStateWords = (int)(offsetof(IcpState, sums) / sizeof(uint32_t));
+static_assert(kStateWords <= 64, "one lane per word");
+// called by the whole (one-wave) block: lane 0, which wrote the state, parks its words in LDS (a lane reads its OWN stores back in
+// order), the lanes store one word each
+__device__ __forceinline__ void publish_state(const IcpState *st, IcpState *host_out, uint32_t *lds) {
+    if (threadIdx.x == 0) {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(st);
+        for (int i = 0; i < kStateWords; ++i) lds[i] = s[i];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kStateWords)
+        __hip_atomic_store(reinterpret_cast<uint32_t *>(host_out) + threadIdx.x, lds[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void icp_finish_kernel(IcpState *__restrict__ st, const double *__restrict__ partials, uint32_t nblocks, int p2plane, int from_sums,
+                                  IcpState *__restrict__ host_out) {
+    __shared__ uint32_t lds[64];
+    if (threadIdx.x == 0 && !st->done) {
     st->converged = 0;
     if (p2plane || st->kiss) {         // point-to-plane :595-601 and kiss_icp.rs:292-299 return the last measured mse
         st->mse = st->prev_mse;
@@ -1502,6 +1520,8 @@ __global__ void icp_finish_kernel(IcpState *__restrict__ st, const double *__res
         st->mse = (c > 0.0) ? (float)(s / c) : st->prev_mse;
     }
     st->done = 1;
+    }
+    if (host_out) publish_state(st, host_out, lds);
 }
 
 // sharded point-to-point: this rank's post-loop (sum, count) -> st->sums[0..1] (rest zero), same order as icp_finish_kernel
@@ -1788,9 +1808,14 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
         hipLaunchKernelGGL(icp_final_mse_kernel, dim3(su.l.mse_blocks), dim3(kIcpBlock), 0, st, su.tv, src, (uint32_t)ns,
                            su.l.mse_chunk, dstate, corr_pos, partials);
     }
-    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, su.l.mse_blocks, mode != 0 ? 1 : 0, 0);
-    IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
-    TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
+    // (the RESULT block: pinned bytes 640 .. 1008 -- not the block at 256 the initial state was staged in, whose asynchronous upload
+    // may still be pending when a short run has been enqueued in one go)
+    IcpState *hs = (IcpState *)((char *)ctx->pinned + 640);
+    IcpState *hs_dev = (IcpState *)pinned_dev_ptr(ctx, hs);
+    if (!hs_dev) return fail(ctx, TC_GPU, "ICP: the pinned block has no device address");
+    hs->status = TC_GPU; hs->iterations = 0;          // (overwritten by the finish kernel; a launch that never ran must not read as a result)
+    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, su.l.mse_blocks, mode != 0 ? 1 : 0, 0, pinned_poll_enabled() ? hs_dev : nullptr);
+    if (!pinned_poll_enabled()) TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
     if (res->corr_target) {
         // (a caller's device array is written directly, a host array through the context's buffer)
         hipLaunchKernelGGL(icp_write_corr_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, su.tv, src, (uint32_t)ns,
@@ -1921,9 +1946,12 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
         hipLaunchKernelGGL(icp_final_mse_fold_kernel, dim3(1), dim3(64), 0, st, dstate, partials, l.mse_blocks);
         if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;
     }
-    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, 0u, mode != 0 ? 1 : 0, 1);
-    IcpState *hs = (IcpState *)((char *)ctx->pinned + 256);
-    TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
+    IcpState *hs = (IcpState *)((char *)ctx->pinned + 640);        // (the result block, see icp_run_mode)
+    IcpState *hs_dev = (IcpState *)pinned_dev_ptr(ctx, hs);
+    if (!hs_dev) return fail(ctx, TC_GPU, "ICP: the pinned block has no device address");
+    hs->status = TC_GPU; hs->iterations = 0;
+    hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, partials, 0u, mode != 0 ? 1 : 0, 1, pinned_poll_enabled() ? hs_dev : nullptr);
+    if (!pinned_poll_enabled()) TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(IcpState), hipMemcpyDeviceToHost, st));
     if (res->corr_target && ns > 0) {
         if (gather_index) {
             // every rank writes the matches of ITS index range (the write-out kernel scatters by the index inside the slice) into its
@@ -2042,7 +2070,7 @@ tc_status tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *
     tc::IcpState *dstate = (tc::IcpState *)ctx->state.p;
     // point-to-point's post-loop mse recompute needs a cross-rank sum: the host driver does it
     // (threecrate_amd.distributed); here the p2plane rule (mse = previous_mse) is applied.
-    hipLaunchKernelGGL(tc::icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, (const double *)ctx->partials.p, 0u, 1, 0);
+    hipLaunchKernelGGL(tc::icp_finish_kernel, dim3(1), dim3(64), 0, st, dstate, (const double *)ctx->partials.p, 0u, 1, 0, (tc::IcpState *)nullptr);
     tc::IcpState *hs = (tc::IcpState *)((char *)ctx->pinned + 256);
     TC_HIP_TRY(ctx, hipMemcpyAsync(hs, dstate, sizeof(tc::IcpState), hipMemcpyDeviceToHost, st));
     if (res->corr_target) {

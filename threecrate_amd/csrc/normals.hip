@@ -511,6 +511,11 @@ __device__ __forceinline__ void list_insert_u(uint32_t (&d)[L], uint32_t v) {
 // walks them -- a lane moves to its next span when its current one ends, so a group costs the wave the longest SUM of spans
 // (simulated on the uniform cloud: ~155 slots).  The loop body is branch-free: a slot beyond its span inserts the key
 // 0xFFFFFFFF (a no-op for the list), the next span is prefetched from LDS at the top of every step.
+// records per step of the flattened walk: 2 since round 4 (4 before: 304 -> 291 us at 1 M points / k = 16, 227 -> 218 at k = 10;
+// 3: 292 / 223).  Build with -DTC_FLAT_W=<n> for an A/B (tools/dev/build_variant.sh).
+#ifndef TC_FLAT_W
+#define TC_FLAT_W 2
+#endif
 struct FlatRows { int8_t dz[9], dy[9]; int n; };
 __device__ constexpr FlatRows kFlatRows[3] = {
     {{0, 0, 0, -1, 1, -1, -1, 1, 1}, {0, -1, 1, 0, 0, -1, 1, -1, 1}, 9},
@@ -593,16 +598,16 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
                 const uint32_t kn = min(k + 1u, (uint32_t)(NR - 1));
                 const uint32_t n1 = ldsA[(2u * kn) * BLOCK], n2 = ldsA[(2u * kn + 1u) * BLOCK];
                 const uint32_t o = j << 4;
-                const nf32x3 c0 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o, 0, 0));
-                const nf32x3 c1 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u, 0, 0));
-                const nf32x3 c2 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 32u, 0, 0));
-                const nf32x3 c3 = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 48u, 0, 0));
-                const uint32_t k0 = tag_key(c0, q, tag, j), k1 = tag_key(c1, q, tag, j + 1u), k2 = tag_key(c2, q, tag, j + 2u), k3 = tag_key(c3, q, tag, j + 3u);
-                list_insert_u<L>(d, j < e ? k0 : 0xFFFFFFFFu);
-                list_insert_u<L>(d, j + 1u < e ? k1 : 0xFFFFFFFFu);
-                list_insert_u<L>(d, j + 2u < e ? k2 : 0xFFFFFFFFu);
-                list_insert_u<L>(d, j + 3u < e ? k3 : 0xFFFFFFFFu);
-                j += 4u;
+                // TC_FLAT_W records per step.  A span of len records costs ceil(len / W) * W slots: with ~5 records per span (five cells
+                // of ~1 point) W = 4 wastes a third of the slots, W = 2 a tenth -- against ~15 instructions of step overhead (87 per step
+                // of two slots: 36 v_med3 for the list, 12 for the distances, 8 for keys and validity)
+#pragma unroll
+                for (int w = 0; w < TC_FLAT_W; ++w) {
+                    const nf32x3 cw = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u * (uint32_t)w, 0, 0));
+                    const uint32_t kw = tag_key(cw, q, tag, j + (uint32_t)w);
+                    list_insert_u<L>(d, j + (uint32_t)w < e ? kw : 0xFFFFFFFFu);
+                }
+                j += (uint32_t)TC_FLAT_W;
                 const bool adv = j >= e;
                 k += adv ? 1u : 0u;
                 const bool more = k < ns;

@@ -136,7 +136,7 @@ struct tc_context {
     hipStream_t stream = nullptr;
     bool own_stream = true;
     std::string last_error;
-    int profiling = 0;          // 0 off, 1 every kernel, 2 only the dominant kernel, every 4th launch
+    int profiling = 0;          // 0 off, 1 every kernel, 2 only the dominant kernel, every 17th launch
     uint32_t prof_tick = 0;
     std::vector<tc::KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
@@ -173,6 +173,7 @@ struct tc_context {
     bool normals_hard_clean = false; // its header (count, exit ticket) is known to be zero: the last serving launch went through
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
+    void *pinned_dev = nullptr;     // the device's address of the same block
     size_t pinned_cap = 0;
 };
 
@@ -203,6 +204,12 @@ tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes);
 tc_status upload_async(tc_context *ctx, void *d_dst, const void *h_src, size_t bytes);
 tc_status uploads_issued(tc_context *ctx);
 tc_status wait_uploads(tc_context *ctx);
+// Device -> host words without a copy kernel or a stream synchronisation: a kernel stores into the context's pinned (host-coherent)
+// block through its device address and raises a flag word there last (system scope); the host spins on the flag -- with a
+// hipStreamQuery now and then, never on a dead device.  dev_ptr: the device's view of a host address inside ctx->pinned.
+void *pinned_dev_ptr(tc_context *ctx, const void *host_addr);
+bool pinned_poll_enabled();       // TC_NO_PINNED_POLL=1: copies + stream synchronisations as before round 4 (A/B)
+tc_status wait_pinned_word(tc_context *ctx, volatile uint32_t *word, const char *what);
 // hand a block back to the context's pool (the caller has made sure no work in flight uses it)
 void recycle(tc_context *ctx, DevBuf &b);
 
@@ -222,7 +229,8 @@ tc_status gather_normals(tc_context *ctx, DeviceIndex &ix, const float *d_normal
 GridView view_of(const DeviceIndex &ix);
 
 // grid.hip (shared with voxel.hip)
-tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out /* n+1 */, DevBuf &blocksum, uint32_t *occ_out = nullptr);
+tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, uint32_t *d_out /* n+1 */, DevBuf &blocksum, uint32_t *occ_out = nullptr,
+                             unsigned long long *occ_host = nullptr);
 tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3]);
 
 // voxel.hip
