@@ -399,8 +399,9 @@ impl<'a> HipComm<'a> {
     pub fn size(&self) -> i32 { unsafe { ffi::tc_comm_size(self.raw) } }
 
     /// `icp_point_to_plane_detailed` of ONE cloud pair over all ranks: every rank passes the same device-resident clouds
-    /// (pointers to n x 3 floats in HBM), the library shards the source spatially and runs one ncclAllReduce of the packed
-    /// 6x6 system per iteration on the compute stream.  Every rank returns the same result.
+    /// (pointers to n x 3 floats in HBM), the library takes this rank's index range of the source (TC_SHARD_INDEX: each rank
+    /// orders n / W points by target cell) and runs one ncclAllReduce of the packed 6x6 system per iteration on the compute
+    /// stream.  Every rank returns the same result.
     #[allow(clippy::too_many_arguments)]
     pub unsafe fn icp_point_to_plane_device(&self, d_source: *const f32, n_source: usize, d_target: *const f32, n_target: usize,
                                             d_target_normals: *const f32, normal_stride: usize, init: Isometry3<f32>, max_iters: usize,
@@ -409,7 +410,7 @@ impl<'a> HipComm<'a> {
         let mut r = empty_result(&mut none);
         r.corr_target = std::ptr::null_mut();
         let i7 = iso_to7(&init);
-        self.ctx.check(ffi::tc_sharded_icp_point_to_plane_device(self.ctx.0, self.raw, ffi::TC_SHARD_SPATIAL, d_source, n_source, d_target,
+        self.ctx.check(ffi::tc_sharded_icp_point_to_plane_device(self.ctx.0, self.raw, ffi::TC_SHARD_INDEX, d_source, n_source, d_target,
                                                                   n_target, d_target_normals, n_target, normal_stride, i7.as_ptr(), max_iters,
                                                                   encode_max_dist(max_correspondence_distance, n_source, n_target, max_iters, None)?,
                                                                   convergence_threshold, &mut r))?;

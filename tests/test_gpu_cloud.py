@@ -188,3 +188,48 @@ def test_context_trim_releases_the_parked_blocks(ctx):
     h = tc.Cloud(ctx, d)
     assert torch.equal(h.estimate_normals(16), ref)
     h.close()
+
+
+def test_superseded_handle_normals_are_never_recovered(ctx):
+    """a handle whose normals were estimated WITHOUT an input-order copy (k = 64: its own cell edge), then
+    replaced by the caller's (tc_cloud_set_normals_device re-indexes at the ICP edge): the rebuild must not "recover" the OLD
+    normals into the input-order copy.  tc_cloud_normals_device returns the caller's, and so does a registration after one more
+    forced rebuild (another estimate with another k, then the caller's normals again)."""
+    src, tgt, T = synth.registration_pair(30000, seed=12)
+    theirs = O.estimate_normals(tgt, 12)                      # "computed elsewhere"
+    t, s = tc.Cloud(ctx, tgt), tc.Cloud(ctx, src)
+    assert t.normals() is None
+    t.estimate_normals(64, out=False)                          # cell-sorted normals only, on the k = 64 grid
+    own = t.normals()                                          # (made on demand from the cell-sorted ones)
+    assert own is not None and np.array_equal(own[:, :3], tgt)
+    assert np.abs(np.abs((own[:, 3:] * O.estimate_normals(tgt, 64)[:, 3:]).sum(1)) - 1).max() < 1e-4
+    t.estimate_normals(64, out=False)                          # again: the input-order copy above is stale now and must not be kept
+    t.set_normals(theirs[:, 3:])                               # forces the rebuild at the ICP edge
+    got = t.normals()
+    assert got is not None and np.array_equal(got[:, 3:], theirs[:, 3:]) and np.array_equal(got[:, :3], tgt)
+    a = s.icp_point_to_plane(t, None, 10, None, 0.0)
+    b = ctx.icp_point_to_plane_detailed(src, tgt, theirs[:, 3:], None, 10, None, 0.0)
+    assert _frob(a.transformation, b.transformation) <= 1e-6
+    t.estimate_normals(64, out=False)                          # rebuild again (k = 64 edge) ...
+    t.set_normals(theirs)                                      # ... and back: (n, 6) layout this time
+    assert np.array_equal(t.normals()[:, 3:], theirs[:, 3:])
+    c = s.icp_point_to_plane(t, None, 10, None, 0.0)
+    assert _frob(c.transformation, b.transformation) <= 1e-6
+    t.close(); s.close()
+
+
+def test_two_level_cell_scan_gives_the_same_index(ctx, monkeypatch):
+    """the fused block-sum scan is quadratic in its block count; beyond 2048 blocks (grids of tens of millions of cells) a
+    one-block kernel prefixes the block sums first.  Forced here on a small grid (TC_SCAN_FUSED_MAX is read per call): normals, k-NN
+    and a registration must come out bit for bit as with the fused scan."""
+    src, tgt, T = synth.registration_pair(60000, seed=3)
+    a_n = ctx.estimate_normals(tgt, 16)
+    a_i = ctx.icp_point_to_plane_detailed(src, tgt, a_n, None, 6, None, 0.0)
+    a_v = ctx.voxel_grid_filter(tgt, 0.05)
+    monkeypatch.setenv("TC_SCAN_FUSED_MAX", "1")
+    b_n = ctx.estimate_normals(tgt, 16)
+    b_i = ctx.icp_point_to_plane_detailed(src, tgt, b_n, None, 6, None, 0.0)
+    b_v = ctx.voxel_grid_filter(tgt, 0.05)
+    monkeypatch.delenv("TC_SCAN_FUSED_MAX")
+    assert np.array_equal(a_n, b_n) and np.array_equal(a_v, b_v)
+    assert np.array_equal(a_i.transformation, b_i.transformation) and a_i.mse == b_i.mse and np.array_equal(a_i.correspondences, b_i.correspondences)

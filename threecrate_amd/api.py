@@ -520,6 +520,19 @@ class GpuContext:
         return self.icp_point_to_plane_detailed(source, target, target_normals, init, max_iters, None, 1e-6)
 
 
+def _hip_memcpy_dtoh(dst, src, nbytes):
+    """hipMemcpy(dst, src, nbytes, hipMemcpyDeviceToHost) through the HIP runtime the library is bound to (already in the process'
+    global namespace: _lib._preload_hip_runtime / the library's own NEEDED entry) -- never a second copy of the runtime"""
+    rt = C.CDLL(None)
+    try:
+        fn = rt.hipMemcpy
+    except AttributeError:
+        return -1
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    fn.restype = C.c_int
+    return fn(dst, src, nbytes, 2)
+
+
 class Cloud:
     """Device-resident cloud handle (tc_cloud_*): owns a copy of the points in HBM, is indexed once, keeps its
     normals in the layout the ICP kernels read.  `points`: numpy (uploaded) or a torch CUDA tensor (copied on the device).
@@ -568,6 +581,20 @@ class Cloud:
         o = np.empty((n, 6), np.float32)
         self._ctx._check(self._L.tc_cloud_estimate_normals(self._h, C.byref(c), o.ctypes.data))
         return o
+
+    def normals(self):
+        """the handle's (n, 6) NormalPoint3f array in input order (tc_cloud_normals_device; made from the cell-sorted normals on
+        demand), as a numpy copy; None when the handle has no normals"""
+        p = self._L.tc_cloud_normals_device(self._h)
+        if not p:
+            return None
+        n = len(self)
+        self._ctx._check(self._L.tc_synchronize(self._ctx._h))
+        host = np.empty((n, 6), np.float32)
+        rc = _hip_memcpy_dtoh(host.ctypes.data, p, n * 24)
+        if rc != 0:
+            raise GpuError(f"hipMemcpy failed ({rc})")
+        return host
 
     def set_normals(self, normals):
         """normals computed elsewhere: (n, 3), or the (n, 6) NormalPoint3f array of an estimate_normals call"""

@@ -1189,8 +1189,14 @@ __device__ __forceinline__ bool chol6_solve(const double *Su, const double *b, d
         }
         const double d = L[tri(j, j)];
         ok = ok && (d > 0.0);             // Cholesky::new -> None on a non-positive pivot
-        const double sd = sqrt(d > 0.0 ? d : 1.0);
-        const double inv = 1.0 / sd;
+        // 1 / sqrt(d) from the hardware estimate + two Newton steps (error ~1e-16 relative), sqrt(d) = d / sqrt(d): the correctly
+        // rounded sqrt + division this replaces were ~27 dependent f64 instructions per pivot on the ONE lane the whole GPU waits
+        // for (round 4: the solve was 2.6 of this launch's 4.7 us)
+        const double dp = d > 0.0 ? d : 1.0;
+        double inv = __builtin_amdgcn_rsq(dp);
+        inv = inv * fma(-0.5 * dp * inv, inv, 1.5);
+        inv = inv * fma(-0.5 * dp * inv, inv, 1.5);
+        const double sd = dp * inv;
         rinv[j] = inv;
         L[tri(j, j)] = sd;
 #pragma unroll
@@ -1418,9 +1424,11 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
         }
         // Rz(x2) * Ry(x1) * Rx(x0) as axis-angle quaternions (:441-444), f32 like the reference
         const float hx = (float)x[0] / 2.0f, hy = (float)x[1] / 2.0f, hz = (float)x[2] / 2.0f;
-        const float qx[4] = {sinf(hx), 0.0f, 0.0f, cosf(hx)};
-        const float qy[4] = {0.0f, sinf(hy), 0.0f, cosf(hy)};
-        const float qz[4] = {0.0f, 0.0f, sinf(hz), cosf(hz)};
+        float sx, cx, sy, cy, sz, cz;          // (one argument reduction per angle)
+        sincosf(hx, &sx, &cx); sincosf(hy, &sy, &cy); sincosf(hz, &sz, &cz);
+        const float qx[4] = {sx, 0.0f, 0.0f, cx};
+        const float qy[4] = {0.0f, sy, 0.0f, cy};
+        const float qz[4] = {0.0f, 0.0f, sz, cz};
         float zy[4], rot[4];
         quat_mul_f(qz, qy, zy);
         quat_mul_f(zy, qx, rot);
@@ -1737,16 +1745,8 @@ static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate
     size_t it = 0;
     for (size_t c = 0; c < nchunks; ++c) {
         if (c >= 2 && c - 2 < max_flags) {
-            // wait for chunk c - 2 (chunk c - 1 keeps the device busy meanwhile)
-            for (unsigned spins = 0; flags[c - 2] == 0; ++spins) {
-                if ((spins & 1023u) == 1023u) {
-                    // (a stream that has drained without writing the word, or an error: never spin on a dead device)
-                    const hipError_t q = hipStreamQuery(st);
-                    if (q == hipSuccess) { if (flags[c - 2] == 0) return fail(ctx, TC_GPU, "internal error: an ICP chunk finished without reporting"); break; }
-                    if (q != hipErrorNotReady) return fail(ctx, TC_GPU, std::string("ICP loop: ") + hipGetErrorString(q));
-                }
-                __builtin_ia32_pause();
-            }
+            // wait for chunk c - 2 (chunk c - 1 keeps the device busy meanwhile); spins, then yields the core (wait_pinned_word)
+            if (tc_status s = wait_pinned_word(ctx, (volatile uint32_t *)&flags[c - 2], "ICP loop")) return s;
             if (flags[c - 2] == 1) break;
         }
         if (c < max_flags) flags[c] = 0;
