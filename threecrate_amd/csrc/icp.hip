@@ -47,18 +47,21 @@ __device__ __forceinline__ void iso_apply(const float q[4], const float t[3], fl
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 struct IcpHeader {
     float q[4], t[3];
-    float max_dist;
+    float prev_mse, conv_thr, max_dist;
     uint32_t iterations;
     int32_t done;
 };
-static_assert(offsetof(IcpState, done) == 48 && offsetof(IcpState, max_dist) == 60 && offsetof(IcpState, iterations) == 36, "IcpState header layout");
+static_assert(offsetof(IcpState, done) == 48 && offsetof(IcpState, max_dist) == 60 && offsetof(IcpState, iterations) == 36 &&
+              offsetof(IcpState, prev_mse) == 28 && offsetof(IcpState, conv_thr) == 56, "IcpState header layout");
 __device__ __forceinline__ IcpHeader load_header(const IcpState *st) {
     const u32x16 h = *reinterpret_cast<const u32x16 *>(st);
     IcpHeader o;
     o.q[0] = __uint_as_float(h[0]); o.q[1] = __uint_as_float(h[1]); o.q[2] = __uint_as_float(h[2]); o.q[3] = __uint_as_float(h[3]);
     o.t[0] = __uint_as_float(h[4]); o.t[1] = __uint_as_float(h[5]); o.t[2] = __uint_as_float(h[6]);
+    o.prev_mse = __uint_as_float(h[7]);
     o.iterations = h[9];
     o.done = (int32_t)h[12];
+    o.conv_thr = __uint_as_float(h[14]);
     o.max_dist = __uint_as_float(h[15]);
     return o;
 }
@@ -1193,10 +1196,15 @@ __device__ __forceinline__ bool chol6_solve(const double *Su, const double *b, d
         // rounded sqrt + division this replaces were ~27 dependent f64 instructions per pivot on the ONE lane the whole GPU waits
         // for (round 4: the solve was 2.6 of this launch's 4.7 us)
         const double dp = d > 0.0 ? d : 1.0;
+#ifdef TC_OLD_SOLVE          // (A/B: the correctly rounded sqrt + division of rounds 1-3)
+        const double sd = sqrt(dp);
+        const double inv = 1.0 / sd;
+#else
         double inv = __builtin_amdgcn_rsq(dp);
         inv = inv * fma(-0.5 * dp * inv, inv, 1.5);
         inv = inv * fma(-0.5 * dp * inv, inv, 1.5);
         const double sd = dp * inv;
+#endif
         rinv[j] = inv;
         L[tri(j, j)] = sd;
 #pragma unroll
@@ -1255,10 +1263,11 @@ __device__ __forceinline__ void quat_mul_f(const float a[4], const float b[4], f
     o[0] = i; o[1] = j; o[2] = k; o[3] = w;
 }
 
-// current = delta * current  (Isometry3 product, registration.rs:321 / :576)
-__device__ void compose(IcpState *st, const float dq[4], const float dt[3]) {
-    const float cq[4] = {st->q[0], st->q[1], st->q[2], st->q[3]};
-    const float ct[3] = {st->t[0], st->t[1], st->t[2]};
+// current = delta * current  (Isometry3 product, registration.rs:321 / :576); the current transform comes from the header the
+// kernel loaded at its start -- reading it again through `st` would be one more round trip to memory on the lane everything waits for
+__device__ void compose(const IcpHeader &hd, IcpState *st, const float dq[4], const float dt[3]) {
+    const float cq[4] = {hd.q[0], hd.q[1], hd.q[2], hd.q[3]};
+    const float ct[3] = {hd.t[0], hd.t[1], hd.t[2]};
     const float zero[3] = {0.0f, 0.0f, 0.0f};
     float rx, ry, rz;
     iso_apply(dq, zero, ct[0], ct[1], ct[2], rx, ry, rz);    // R_delta * t_current
@@ -1350,12 +1359,12 @@ __device__ void rotmat_to_quat(const double m[3][3], float q[4]) {
 }
 
 // convergence bookkeeping shared by both variants (registration.rs:324-339 / :578-592)
-__device__ void finish_iteration(IcpState *st, float mse, uint32_t n) {
-    st->iterations += 1;
+__device__ void finish_iteration(const IcpHeader &hd, IcpState *st, float mse, uint32_t n) {
+    st->iterations = hd.iterations + 1u;
     st->mse = mse;
     st->n_corr = n;
-    const float change = fabsf(st->prev_mse - mse);
-    if (change < st->conv_thr) { st->converged = 1; st->done = 1; return; }
+    const float change = fabsf(hd.prev_mse - mse);
+    if (change < hd.conv_thr) { st->converged = 1; st->done = 1; return; }
     st->prev_mse = mse;
 }
 
@@ -1363,7 +1372,8 @@ constexpr int kFinalizeThreads = 512;
 // the calling block (kFinalizeThreads threads): fixed-order sum of the rows, solve, compose, bookkeeping
 template <int MODE>
 __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
-                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE], bool done = false) {
+                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE], const IcpHeader &hd) {
+    const bool done = hd.done != 0;
     constexpr bool P2PLANE = MODE != 0;        // GICP solves the same 6x6 system from the same 29 words (gicp.rs:258-281)
     if (do_sum) {
         // 16 row groups x 32 columns (512 threads): every group folds its rows in a fixed order, then column t folds the 16
@@ -1433,8 +1443,8 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
         quat_mul_f(qz, qy, zy);
         quat_mul_f(zy, qx, rot);
         const float dt[3] = {(float)x[3], (float)x[4], (float)x[5]};
-        compose(st, rot, dt);
-        finish_iteration(st, (float)(S[27] / cnt), (uint32_t)cnt);
+        compose(hd, st, rot, dt);
+        finish_iteration(hd, st, (float)(S[27] / cnt), (uint32_t)cnt);
     } else {
         const double cnt = S[16];
         if (cnt < 3.0) { st->status = TC_ALGORITHM; st->done = 1; return; }     // registration.rs:311-315
@@ -1453,7 +1463,7 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
         rotmat_to_quat(R, dq);
         float dt[3];
         for (int r = 0; r < 3; ++r) dt[r] = (float)(cq[r] - (R[r][0] * cs[0] + R[r][1] * cs[1] + R[r][2] * cs[2]));
-        compose(st, dq, dt);
+        compose(hd, st, dq, dt);
         double nmse = S[15];                               // sum |s - q|^2 before the update (registration.rs:214)
         if (st->kiss) {
             // KISS-ICP measures AFTER applying delta (kiss_icp.rs:270-276).  With the optimal translation the
@@ -1464,7 +1474,7 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
             nmse = S[15] - cnt * (d0 * d0 + d1 * d1 + d2 * d2) + 2.0 * (H[0][0] + H[1][1] + H[2][2]) - 2.0 * rh;
             nmse = fmax(nmse, 0.0);
         }
-        finish_iteration(st, (float)(nmse / cnt), (uint32_t)cnt);
+        finish_iteration(hd, st, (float)(nmse / cnt), (uint32_t)cnt);
     }
 }
 
@@ -1483,13 +1493,13 @@ __global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const do
     if (hd.done && !do_sum) { if (done_out && threadIdx.x == 0) __hip_atomic_store(done_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
 #ifdef TC_PHASE_STAMPS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    finalize_body<MODE>(partials, nblocks, st, g, do_sum, 0, sm);
+    finalize_body<MODE>(partials, nblocks, st, g, do_sum, 0, sm, hd);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    finalize_body<MODE>(partials, nblocks, st, g, 0, do_apply, sm);
+    finalize_body<MODE>(partials, nblocks, st, g, 0, do_apply, sm, hd);
     const unsigned long long t2 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) { st->refine_ring_hist[0] += (uint32_t)(t1 - t0); st->refine_ring_hist[1] += (uint32_t)(t2 - t1); }
 #else
-    finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm, hd.done != 0);
+    finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm, hd);
 #endif
     if (done_out && threadIdx.x == 0)      // (thread 0 wrote st->done itself)
         __hip_atomic_store(done_out, (hd.done || st->done) ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

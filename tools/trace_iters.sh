@@ -20,7 +20,7 @@ for pat in ("icp_correspond", "icp_refine", "icp_finalize"):
     d = d[-50:]
     if not d: continue
     print(pat, "last call, us per launch:")
-    print("  " + " ".join(f"{x:.0f}" for x in d))
+    print("  " + " ".join(f"{x:.1f}" if pat == "icp_finalize" else f"{x:.0f}" for x in d))
     print(f"  mean {sum(d)/len(d):.1f}   launches 2-37 {sum(d[1:37])/36:.1f}   launches 12-37 {sum(d[11:37])/26:.1f}   last 8 {sum(d[-8:])/8:.1f}")
 starts = [s for s, e, k in rows if "icp_correspond" in k][-50:]
 if len(starts) == 50:
