@@ -747,17 +747,27 @@ def main():
             # The other BASELINE configs, measured by the same run (outside the timed region, a few seconds each): configs[3] the
             # 10 M-point cloud through the sharded entry points with a REAL one-rank RCCL communicator, configs[4] the LiDAR frame
             # stream, configs[2]'s cloud shape as one pair.  Each with its own algorithmic bytes and fractions.
-            for key, fn in (("frame_stream", lambda: measure_stream(ctx, 50, 2)),
-                            ("tum_pair", lambda: measure_tum_pair(ctx, dev, 3, 1)),
-                            ("sharded_10m", lambda: measure_sharded(ctx, dev, 10_000_000, 3, 1))):
-                try:
-                    ctx.trim()            # (the blocks the previous workload parked in the context's pool: each line starts from a clean pool)
-                    line = fn()
-                    for drop in ("collective", "ranks", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
-                        line.pop(drop, None)
-                    out[key] = line
-                except Exception as e:          # an auxiliary line must never take the judged one down
-                    out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # (native libraries print to C stdout -- RCCL's version banner when the sharded line creates its communicator: while the
+            # extras run, file descriptor 1 points at stderr, so that this process' stdout stays the ONE JSON line)
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                for key, fn in (("frame_stream", lambda: measure_stream(ctx, 50, 2)),
+                                ("tum_pair", lambda: measure_tum_pair(ctx, dev, 3, 1)),
+                                ("sharded_10m", lambda: measure_sharded(ctx, dev, 10_000_000, 3, 1))):
+                    try:
+                        ctx.trim()            # (the blocks the previous workload parked in the context's pool: each line starts from a clean pool)
+                        line = fn()
+                        for drop in ("collective", "ranks", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+                            line.pop(drop, None)
+                        out[key] = line
+                    except Exception as e:          # an auxiliary line must never take the judged one down
+                        out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                flush_native_stdio()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(n, tgt_h, src_h, nrm_last.cpu().numpy())
             out["parity"] = cb.pop("parity")
