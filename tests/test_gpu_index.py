@@ -1,0 +1,54 @@
+"""-m gpu: the two placements of the index build give the SAME layout.
+
+Round 4 added a binned placement (grid.hip: bin_count / bin_scatter / bin_place -- LDS stages instead of one global atomic per point)
+for large clouds on dense-ish grids; the atomic counting sort of rounds 1-3 stays for everything else and as the fallback when a
+bin overflows a block's LDS.  Both must produce the cell-sorted order with ascending original index inside a cell, bit for bit:
+every search result, tie-break and sum order downstream depends on it.  TC_INDEX_BINNED is read per call."""
+import numpy as np
+import pytest
+
+import threecrate_amd as tc
+from threecrate_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _clouds():
+    rng = np.random.default_rng(11)
+    u = synth.uniform_cloud(400_000, seed=3)
+    yield "uniform 400k", u
+    # a lattice with exact duplicates: distance ties everywhere, cells with several points -> the in-cell order decides tie-breaks
+    g = np.stack(np.meshgrid(np.arange(70), np.arange(70), np.arange(60), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * np.float32(0.01)
+    lat = np.concatenate([g, g[rng.integers(0, len(g), 40_000)]]).astype(np.float32)
+    yield "lattice + duplicates 334k", lat[rng.permutation(len(lat))]
+    nf = u.copy()
+    nf[rng.integers(0, len(nf), 50)] = np.nan
+    nf[rng.integers(0, len(nf), 20), 1] = np.inf
+    yield "uniform with non-finite points", nf
+    # strongly non-uniform: most bins nearly empty, a few far beyond a block's LDS -> the build must fall back, same answers
+    clu = np.concatenate([synth.uniform_cloud(200_000, seed=5), (0.5 + 0.002 * rng.standard_normal((120_000, 3))).astype(np.float32)])
+    yield "uniform + dense cluster", clu.astype(np.float32)
+
+
+@pytest.mark.parametrize("name,pts", list(_clouds()), ids=lambda v: v if isinstance(v, str) else "")
+def test_binned_and_atomic_index_builds_agree_bit_for_bit(ctx, monkeypatch, name, pts):
+    d = torch.from_numpy(pts).cuda()
+    qh = np.ascontiguousarray(pts[::97][:3000])
+    qh = qh[np.isfinite(qh).all(1)]
+    src = torch.from_numpy((pts[::3] + np.float32(0.003)).astype(np.float32)).cuda()          # (the ICP source: ordered by tile-major target cell)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TC_INDEX_BINNED", mode)
+        nrm = ctx.estimate_normals(d, 12)
+        idx, dist, cnt = ctx.find_k_nearest_batch(pts, qh, 9)
+        fin = torch.isfinite(d).all(1)
+        r = ctx.icp_point_to_plane_detailed(src[torch.isfinite(src).all(1)], d[fin], nrm[fin], None, 4, None, 0.0, correspondences=True)
+        h = tc.Cloud(ctx, d)
+        hn = h.estimate_normals(12)
+        h.close()
+        out[mode] = (nrm.cpu().numpy(), np.asarray(idx), np.asarray(dist), np.asarray(cnt), r.transformation, r.mse, r.correspondences, hn.cpu().numpy())
+    monkeypatch.delenv("TC_INDEX_BINNED")
+    a, b = out["1"], out["0"]
+    for x, y, what in zip(a, b, ("normals", "knn idx", "knn dist", "knn count", "icp T", "icp mse", "icp pairs", "handle normals")):
+        assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True), (name, what)

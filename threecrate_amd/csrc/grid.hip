@@ -42,10 +42,19 @@ constexpr int kBboxBlocks = 256;
 // falls into one sixteenth of its range: ~n/64 points each, pseudo-random in the index (NOT every 64th point: organised
 // scans are periodic in 64 -- beams, image columns -- and a sample must not be one beam).  A handful of far outliers
 // shows up in the exact box but almost never in more than two of the four samples: the host compares them (cloud_bbox_impl).
-// box / sbox may live in the context's pinned HOST block (cloud_bbox_impl): every block fences its partials to system scope and
-// takes a ticket; the last one raises *done (also pinned): the host polls that word -- no copy kernels, no stream synchronisation.
-__global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, float *__restrict__ box,
-                                                  float *__restrict__ sbox, uint32_t *__restrict__ ticket, uint32_t *__restrict__ done) {
+// float <-> unsigned with the same order (atomicMin / atomicMax on floats of either sign)
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); }
+constexpr uint32_t kOrdPlusInf = 0xFF800000u, kOrdMinusInf = 0x007FFFFFu;       // f2ord(+inf), f2ord(-inf): the empty box
+
+// The blocks fold their boxes into 30 accumulators in device memory with integer atomics (acc: [0..6) the exact box, [6..30) four
+// sample boxes; `state`: ticket | 7 pad | acc[30]), drain them (s_waitcnt vmcnt(0)) and take a ticket; the LAST block reads the
+// accumulators back (atomic loads: served where the atomics ran), stores the 30 floats to `out` -- the context's pinned HOST block,
+// or device memory -- raises *done and resets the state for the next launch.  No per-block fence, no partials over PCIe (the first
+// version of round 4 did both: 20.6 us instead of 10.9), no copy kernels, no stream synchronisation: the host polls *done.
+__global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, uint32_t *__restrict__ state, int robust,
+                                                  float *__restrict__ out, uint32_t *__restrict__ done) {
+    const bool sbox = robust != 0;
     __shared__ float sm[4][6];
     __shared__ float ss[4][4][6];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -90,29 +99,44 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
         for (int c = 0; c < 3; ++c) { sm[threadIdx.x >> 6][c] = mn[c]; sm[threadIdx.x >> 6][3 + c] = mx[c]; }
     }
     __syncthreads();
+    uint32_t *acc = state + 8;
     if (threadIdx.x < 6) {
         float v = sm[0][threadIdx.x];
         for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
-        box[blockIdx.x * 6 + threadIdx.x] = v;
+        if (threadIdx.x < 3) atomicMin(&acc[threadIdx.x], f2ord(v)); else atomicMax(&acc[threadIdx.x], f2ord(v));
     }
     if (sbox && threadIdx.x < 24) {
         const int sidx = threadIdx.x / 6, c = threadIdx.x % 6;
         float v = ss[0][sidx][c];
         for (int w = 1; w < 4; ++w) v = (c < 3) ? fminf(v, ss[w][sidx][c]) : fmaxf(v, ss[w][sidx][c]);
-        sbox[blockIdx.x * 24 + threadIdx.x] = v;
+        if (c < 3) atomicMin(&acc[6 + threadIdx.x], f2ord(v)); else atomicMax(&acc[6 + threadIdx.x], f2ord(v));
     }
+    __shared__ uint32_t s_last;
+    if (threadIdx.x < 64) {                       // the lanes that issued atomics are in wave 0: its atomics are done before its ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 30) {
+        const uint32_t u = __hip_atomic_load(&acc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out[threadIdx.x], ord2f(u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&acc[threadIdx.x], (threadIdx.x % 6 < 3) ? kOrdPlusInf : kOrdMinusInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(state, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done) {
-        if (threadIdx.x < 24) __threadfence_system();                 // the storing lanes' partials are out before the ticket
+        if (threadIdx.x < 30) __threadfence_system();            // (one block, once: the 30 stores are out before the flag)
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == gridDim.x - 1u) {
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (clean for the next launch)
-                __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+        if (threadIdx.x == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
+__global__ void bbox_state_init_kernel(uint32_t *__restrict__ state) {
+    const uint32_t t = threadIdx.x;
+    if (t < 8) state[t] = 0u;
+    else if (t < 38) state[t] = ((t - 8) % 6 < 3) ? kOrdPlusInf : kOrdMinusInf;
+}
+
 
 // cell id per point (+ histogram).  With `st` != null the point is first moved by the
 // isometry in *st (ICP source ordering by target cell); the stored record keeps the raw point.
@@ -446,38 +470,38 @@ static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, 
     const int nb = (int)((n + 255) / 256);
     const int bb = std::min(nb, kBboxBlocks);
     const bool robust = rmn != nullptr && n >= 4096;
-    // The per-block partials go straight into the pinned host block and the host polls the word the last block raises: no
-    // device-to-host copy kernels, no stream synchronisation (TC_NO_PINNED_POLL=1: the copies + synchronisation of rounds 1-3).
-    // ctx->bbox: ticket word (zero between launches: the last block resets it) | the partials when they are copied.
+    // The blocks fold into device accumulators, the last one stores the 30 floats (exact box + four sample boxes) into the pinned
+    // host block and raises a word there; the host polls it: no copy kernels, no stream synchronisation (TC_NO_PINNED_POLL=1: the
+    // result stays on the device and comes back through a copy + synchronisation, as in rounds 1-3).
     const bool poll = pinned_poll_enabled();
     const bool fresh = ctx->bbox.p == nullptr;
-    if (tc_status s = ensure(ctx, ctx->bbox, 256 + (size_t)kBboxBlocks * 30 * sizeof(float))) return s;
-    if (fresh) TC_HIP_TRY(ctx, hipMemsetAsync(ctx->bbox.p, 0, 256, st));
-    float *hb = (float *)((char *)ctx->pinned + 2048), *hs = (float *)((char *)ctx->pinned + 16384);
+    if (tc_status s = ensure(ctx, ctx->bbox, 512)) return s;
+    uint32_t *d_state = (uint32_t *)ctx->bbox.p;                       // ticket | pad | 30 accumulators | (no-poll: 30 results at +256)
+    if (fresh) hipLaunchKernelGGL(bbox_state_init_kernel, dim3(1), dim3(64), 0, st, d_state);
+    float *hb = (float *)((char *)ctx->pinned + 2048);                  // [0..6) exact box, [6..30) sample boxes
     volatile uint32_t *h_done = (volatile uint32_t *)((char *)ctx->pinned + 2048 + 8192 + 192);
-    float *d_box = (float *)((char *)ctx->bbox.p + 256), *d_sbox = d_box + (size_t)kBboxBlocks * 6;
+    float *d_out = (float *)((char *)ctx->bbox.p + 256);
     uint32_t *d_done = nullptr;
     if (poll) {
-        d_box = (float *)pinned_dev_ptr(ctx, hb); d_sbox = (float *)pinned_dev_ptr(ctx, hs);
+        d_out = (float *)pinned_dev_ptr(ctx, hb);
         d_done = (uint32_t *)pinned_dev_ptr(ctx, (const void *)h_done);
-        if (!d_box || !d_sbox || !d_done) return fail(ctx, TC_GPU, "bbox: the pinned block has no device address");
+        if (!d_out || !d_done) return fail(ctx, TC_GPU, "bbox: the pinned block has no device address");
         *h_done = 0u;
     }
     {
         ProfScope ps(ctx, "bbox");
-        hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, d_box, robust ? d_sbox : nullptr, (uint32_t *)ctx->bbox.p, d_done);
+        hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, d_state, robust ? 1 : 0, d_out, d_done);
     }
     TC_HIP_TRY(ctx, hipGetLastError());
     if (poll) {
-        if (tc_status s = wait_pinned_word(ctx, h_done, "bounding box")) { (void)hipMemsetAsync(ctx->bbox.p, 0, 256, st); return s; }
+        if (tc_status s = wait_pinned_word(ctx, h_done, "bounding box")) { hipLaunchKernelGGL(bbox_state_init_kernel, dim3(1), dim3(64), 0, st, d_state); return s; }
     } else {
-        TC_HIP_TRY(ctx, hipMemcpyAsync(hb, d_box, (size_t)bb * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
-        if (robust) TC_HIP_TRY(ctx, hipMemcpyAsync(hs, d_sbox, (size_t)bb * 24 * sizeof(float), hipMemcpyDeviceToHost, st));
+        TC_HIP_TRY(ctx, hipMemcpyAsync(hb, d_out, 30 * sizeof(float), hipMemcpyDeviceToHost, st));
         TC_HIP_TRY(ctx, hipStreamSynchronize(st));
     }
+    const float *hs = hb + 6;
     for (int c = 0; c < 3; ++c) { mn[c] = INFINITY; mx[c] = -INFINITY; }
-    for (int b = 0; b < bb; ++b)
-        for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hb[6 * b + c]); mx[c] = std::fmax(mx[c], hb[6 * b + 3 + c]); }
+    for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hb[c]); mx[c] = std::fmax(mx[c], hb[3 + c]); }
     if (rmn) {
         for (int c = 0; c < 3; ++c) { rmn[c] = mn[c]; rmx[c] = mx[c]; }
         *clamped = false;
@@ -485,10 +509,7 @@ static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, 
     if (!robust) return TC_OK;
     float acc[24];                                   // [sample][min xyz | max xyz], folded over the blocks (plain compares: no NaNs in here)
     for (int i = 0; i < 24; ++i) acc[i] = (i % 6 < 3) ? INFINITY : -INFINITY;
-    for (int b = 0; b < bb; ++b) {
-        const float *r = hs + 24 * b;
-        for (int i = 0; i < 24; ++i) acc[i] = (i % 6 < 3) ? (r[i] < acc[i] ? r[i] : acc[i]) : (r[i] > acc[i] ? r[i] : acc[i]);
-    }
+    for (int i = 0; i < 24; ++i) acc[i] = (i % 6 < 3) ? (hs[i] < acc[i] ? hs[i] : acc[i]) : (hs[i] > acc[i] ? hs[i] : acc[i]);
     for (int c = 0; c < 3; ++c) {
         float lo[4], hi[4];
         for (int k = 0; k < 4; ++k) { lo[k] = acc[6 * k + c]; hi[k] = acc[6 * k + 3 + c]; }
@@ -507,6 +528,241 @@ static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, 
 
 tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3]) {
     return cloud_bbox_impl(ctx, d_xyz, n, mn, mx, nullptr, nullptr, nullptr);
+}
+
+
+// ---- binned placement (round 4) ------------------------------------------------------------------------------------------------
+// The counting sort above pays 1 M scattered returning atomics for 1 M points (cell_hist_kernel: 42 us, the memory side's rate
+// for 64 lanes in 64 different rows), a scattered 16-byte placement (23 us) and a re-rank pass (10 us).  On a grid that is dense in
+// the cloud's sense -- at most ~8 cells per point -- the same layout (cell-sorted, ascending original index inside a cell: bit for
+// bit the layout of the passes above) comes out of two LDS stages without a global atomic per point:
+//   bin_count / bin_offsets / bin_scan : 256 blocks walk contiguous shares of the input and count, in LDS, how many of their points
+//        fall into each BIN (a run of consecutive keys holding ~2048 points); per-(block, bin) offsets + the bins' starts;
+//   bin_scatter  : the same walk again, each record goes to its block's run inside its bin (LDS cursor: one returning LDS atomic);
+//   bin_place    : one block per bin -- its records' keys counted in LDS, scanned (-> cell_start of the bin's keys), every record
+//        ranked inside its cell by original index (LDS), the bin written out in final order with coalesced stores.
+// A bin that does not fit a block's LDS (kBinCap records: a cloud far denser in one place than on average) sends the whole build
+// back to the atomic passes: the host reads the largest bin's population after bin_scan (one polled word).
+constexpr int kBinBlocks = 256;               // blocks of the count / scatter passes
+constexpr int kBinWalkThreads = 1024;         // their threads (the walks are latency bound: 65 k threads left 15 dependent rounds each)
+#ifndef TC_BIN_TARGET
+#define TC_BIN_TARGET 2048
+#endif
+#ifndef TC_BIN_PLACE_THREADS
+#define TC_BIN_PLACE_THREADS 512
+#endif
+constexpr uint32_t kBinTarget = TC_BIN_TARGET;          // points per bin aimed at
+constexpr uint32_t kBinCap = 2 * kBinTarget;            // records one bin_place block holds in LDS
+constexpr uint32_t kBinKeysMax = 2 * kBinTarget;        // keys (cells) per bin: one LDS counter each
+constexpr uint32_t kBinMaxBins = 8192;                  // LDS counters of the count / scatter passes
+constexpr int kBinPlaceThreads = TC_BIN_PLACE_THREADS;
+
+__device__ __forceinline__ uint32_t point_key(float x, float y, float z, const GridGeom &g, const IcpState *__restrict__ st, const TileGeom &tg,
+                                              int tile_major, uint32_t nkeys) {
+    // (the same expressions on the same bits as cell_hist_kernel / rerank_kernel)
+    if (st) {
+        float q[4] = {st->q[0], st->q[1], st->q[2], st->q[3]}, t[3] = {st->t[0], st->t[1], st->t[2]};
+        float ox, oy, oz;
+        isometry_apply(q, t, x, y, z, ox, oy, oz);
+        x = ox; y = oy; z = oz;
+    }
+    const int ix = cell_coord(x, g.minx, g.inv_h, g.gx), iy = cell_coord(y, g.miny, g.inv_h, g.gy), iz = cell_coord(z, g.minz, g.inv_h, g.gz);
+    uint32_t c = tile_major ? tile_major_id(tg, ix, iy, iz) : ((uint32_t)iz * g.gy + iy) * g.gx + ix;
+    if (!(fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f)) c = nkeys;
+    return c;
+}
+
+__global__ void __launch_bounds__(kBinWalkThreads) bin_count_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g, const IcpState *__restrict__ st,
+                                                       TileGeom tg, int tile_major, uint32_t nkeys, uint32_t kpb, uint32_t nbins,
+                                                       uint32_t *__restrict__ cnt /* [nbins][kBinBlocks] */, uint32_t *__restrict__ pts_pad,
+                                                       uint32_t *__restrict__ cs_front, uint32_t *__restrict__ cs_tail) {
+    __shared__ uint32_t c[kBinMaxBins];
+    if (blockIdx.x == 0 && threadIdx.x < 4 * kPtsPad + kCellStartFront + kCellStartPad) {     // the paddings (see cell_hist_kernel)
+        const uint32_t t = threadIdx.x;
+        if (t < 4 * kPtsPad) pts_pad[t] = 0x7F7F7F7Fu;
+        else if (t < 4 * kPtsPad + kCellStartFront) cs_front[t - 4 * kPtsPad] = 0u;
+        else cs_tail[t - 4 * kPtsPad - kCellStartFront] = 0u;
+    }
+    for (uint32_t b = threadIdx.x; b < nbins; b += kBinWalkThreads) c[b] = 0u;
+    __syncthreads();
+    const uint32_t per = (n + kBinBlocks - 1) / kBinBlocks;
+    const uint32_t i0 = blockIdx.x * per, i1 = min(i0 + per, n);
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += kBinWalkThreads) {
+        const uint32_t k = point_key(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], g, st, tg, tile_major, nkeys);
+        atomicAdd(&c[k / kpb], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += kBinWalkThreads) cnt[(size_t)b * kBinBlocks + blockIdx.x] = c[b];        // [bin][block]
+}
+
+// per bin: exclusive prefix over the blocks (in place) + the bin's total.  One wave per bin: a lane takes four consecutive blocks
+// (one 16-byte read), in-lane prefix + wave scan.  cnt is [bin][kBinBlocks].
+static_assert(kBinBlocks == 256, "one wave x four entries per lane");
+__global__ void __launch_bounds__(256) bin_offsets_kernel(uint32_t *__restrict__ cnt, uint32_t nbins, uint32_t *__restrict__ tot) {
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (b >= nbins) return;
+    uint4 *row = reinterpret_cast<uint4 *>(cnt + (size_t)b * kBinBlocks);
+    const uint4 v = row[lane];
+    const uint32_t s = v.x + v.y + v.z + v.w;
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= (unsigned)o) inc += t;
+    }
+    const uint32_t ex = inc - s;
+    row[lane] = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+    if (lane == 63u) tot[b] = inc;
+}
+
+// bin starts (exclusive scan of the totals, nbins + 1 entries), the largest bin -> the pinned host word (flag << 32 | population),
+// and the zeroed {occupied cells, ticket} pair of bin_place
+__global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *__restrict__ tot, uint32_t nbins, uint32_t *__restrict__ binstart,
+                                                       uint32_t *__restrict__ occ_ticket, unsigned long long *__restrict__ host_word) {
+    __shared__ uint32_t wtot[16], wmax[16];
+    uint32_t carry = 0, mx = 0;
+    for (uint32_t base = 0; base < nbins; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nbins ? tot[i] : 0u;
+        mx = max(mx, v);
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if ((threadIdx.x & 63) >= (unsigned)o) inc += t;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < (int)(threadIdx.x >> 6)) woff += wtot[w]; total += wtot[w]; }
+        if (i < nbins) binstart[i] = carry + woff + inc - v;
+        carry += total;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        binstart[nbins] = carry;
+        uint32_t m = 0;
+        for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
+        occ_ticket[0] = 0u; occ_ticket[1] = 0u;
+        __hip_atomic_store(host_word, (1ull << 32) | (unsigned long long)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ void __launch_bounds__(kBinWalkThreads) bin_scatter_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g, const IcpState *__restrict__ st,
+                                                         TileGeom tg, int tile_major, uint32_t nkeys, uint32_t kpb, uint32_t nbins,
+                                                         const uint32_t *__restrict__ off /* [nbins][kBinBlocks] */,
+                                                         const uint32_t *__restrict__ binstart, float4 *__restrict__ tmp) {
+    __shared__ uint32_t cur[kBinMaxBins];
+    for (uint32_t b = threadIdx.x; b < nbins; b += kBinWalkThreads) cur[b] = binstart[b] + off[(size_t)b * kBinBlocks + blockIdx.x];
+    __syncthreads();
+    const uint32_t per = (n + kBinBlocks - 1) / kBinBlocks;
+    const uint32_t i0 = blockIdx.x * per, i1 = min(i0 + per, n);
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += kBinWalkThreads) {
+        float4 r;
+        r.x = xyz[3 * (size_t)i]; r.y = xyz[3 * (size_t)i + 1]; r.z = xyz[3 * (size_t)i + 2];
+        const uint32_t k = point_key(r.x, r.y, r.z, g, st, tg, tile_major, nkeys);
+        if (k == nkeys) r.x = r.y = r.z = __uint_as_float(0x7F7F7F7Fu);     // the non-finite bucket (see place_kernel)
+        r.w = __uint_as_float(i);
+        tmp[atomicAdd(&cur[k / kpb], 1u)] = r;
+    }
+}
+
+__global__ void __launch_bounds__(kBinPlaceThreads) bin_place_kernel(const float4 *__restrict__ tmp, const uint32_t *__restrict__ binstart,
+                                                                     uint32_t nbins, uint32_t kpb, uint32_t nkeys, GridGeom g,
+                                                                     const IcpState *__restrict__ st, TileGeom tg, int tile_major,
+                                                                     uint32_t *__restrict__ cs, float4 *__restrict__ pts,
+                                                                     uint32_t *__restrict__ occ_ticket, uint32_t *__restrict__ occ_out,
+                                                                     unsigned long long *__restrict__ occ_host) {
+    __shared__ uint32_t cnt[kBinKeysMax];            // per key of the bin: count, then exclusive start
+    __shared__ uint32_t rkey[kBinCap];               // record i: local key | arrival rank << 16, later its final slot
+    __shared__ uint32_t ridx[kBinCap];               // record i: original index
+    __shared__ uint32_t slot[kBinCap];               // by (start + arrival): original index; later by final slot: record
+    __shared__ uint32_t wsum[kBinPlaceThreads / 64];
+    __shared__ uint32_t s_occ;
+    const uint32_t bin = blockIdx.x, tid = threadIdx.x;
+    const uint32_t bs = binstart[bin], P = binstart[bin + 1] - bs;
+    const uint32_t k0 = bin * kpb, K = min(kpb, nkeys + 1u - k0);          // this bin's keys: k0 .. k0 + K
+    for (uint32_t k = tid; k < K; k += kBinPlaceThreads) cnt[k] = 0u;
+    if (tid == 0) s_occ = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < P; i += kBinPlaceThreads) {
+        const float4 r = tmp[bs + i];
+        // (the record's key is computed again from its coordinates: the placeholder of a non-finite point fails the finiteness test)
+        const uint32_t k = point_key(r.x, r.y, r.z, g, st, tg, tile_major, nkeys) - k0;
+        const uint32_t a = atomicAdd(&cnt[k], 1u);
+        rkey[i] = k | (a << 16);
+        ridx[i] = __float_as_uint(r.w);
+    }
+    __syncthreads();
+    // exclusive scan of the K counts (kBinKeysMax / kBinPlaceThreads consecutive keys per thread), occupied keys counted on the way
+    constexpr uint32_t kPer = kBinKeysMax / kBinPlaceThreads;
+    uint32_t v[kPer], sum = 0, nz = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < kPer; ++t) {
+        const uint32_t k = tid * kPer + t;
+        v[t] = k < K ? cnt[k] : 0u;
+        sum += v[t];
+        nz += v[t] != 0u;
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t2 = __shfl_up(inc, o);
+        if ((tid & 63) >= (unsigned)o) inc += t2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nz += __shfl_xor(nz, o);
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    if ((tid & 63) == 0 && nz) atomicAdd(&s_occ, nz);
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) run += wsum[w];
+#pragma unroll
+    for (uint32_t t = 0; t < kPer; ++t) {
+        const uint32_t k = tid * kPer + t;
+        if (k < K) { cnt[k] = run; cs[k0 + k] = bs + run; }
+        run += v[t];
+    }
+    if (bin == nbins - 1 && tid == 0) cs[nkeys + 1] = bs + P;              // the total behind the last key
+    __syncthreads();
+    // records by (start of their key + arrival): the members of a key sit together, in arrival order
+    for (uint32_t i = tid; i < P; i += kBinPlaceThreads) slot[cnt[rkey[i] & 0xFFFFu] + (rkey[i] >> 16)] = ridx[i];
+    __syncthreads();
+    // rank inside the key = members with a smaller original index (keys hold a handful of points: a cell; P <= kBinCap bounds it)
+    for (uint32_t i = tid; i < P; i += kBinPlaceThreads) {
+        const uint32_t k = rkey[i] & 0xFFFFu, me = ridx[i];
+        const uint32_t s0 = cnt[k], e0 = (k + 1 < K) ? cnt[k + 1] : P;
+        uint32_t rank = 0;
+        for (uint32_t j = s0; j < e0; ++j) rank += slot[j] < me ? 1u : 0u;
+        rkey[i] = s0 + rank;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < P; i += kBinPlaceThreads) slot[rkey[i]] = i;
+    __syncthreads();
+    for (uint32_t t = tid; t < P; t += kBinPlaceThreads) pts[bs + t] = tmp[bs + slot[t]];        // final order, coalesced stores
+    // occupied keys of the whole index: the last bin to arrive publishes the count (in front of the prefix sums: the normals kernel
+    // picks its path by it; and, for the edge adaptation, to the pinned host block)
+    // (count and ticket travel in ONE 64-bit atomic -- occupied keys in the high word, arrived bins in the low one: no ordering
+    // between two atomics to enforce, no fence: an agent-scope fence per block, with the bin's 32 KB of fresh stores behind it, made
+    // this kernel 34 us instead of 10)
+    if (tid == 0) {
+        const unsigned long long mine = ((unsigned long long)s_occ << 32) | 1ull;
+        const unsigned long long old = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(occ_ticket), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)old == nbins - 1u) {
+            const uint32_t occ = (uint32_t)(old >> 32) + s_occ;
+            if (occ_out) __hip_atomic_store(occ_out, occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (occ_host) __hip_atomic_store(occ_host, (1ull << 32) | (unsigned long long)occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+static bool binned_build_enabled() {          // TC_INDEX_BINNED=0: the atomic counting sort only (A/B; read per call: the tests flip it)
+    const char *e = getenv("TC_INDEX_BINNED");
+    return !(e && atoi(e) == 0);
 }
 
 tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size_t n, float cell_factor,
@@ -578,6 +834,59 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         const bool check = adapt && attempt < 3;
         volatile uint32_t *h_occ = (volatile uint32_t *)((char *)ctx->pinned + 2048 + 8192);      // [0] = occupied cells, [1] = written
 
+        // ---- binned placement (see bin_count_kernel): dense-ish grids of large clouds, no global atomic per point ----
+        bool binned_done = false;
+        if (binned_build_enabled() && pinned_poll_enabled() && !strict_order && n >= kAdaptMinPoints && n <= (1u << 24) && nkeys < 0x7FFFFFF0u) {
+            const uint32_t keys = nkeys + 1u;               // + the bucket of the non-finite points
+            uint32_t nbins = std::max<uint32_t>((n32 + kBinTarget - 1) / kBinTarget, (keys + kBinKeysMax - 1) / kBinKeysMax);
+            const uint32_t kpb = (keys + nbins - 1) / nbins;           // keys per bin
+            nbins = (keys + kpb - 1) / kpb;
+            if (nbins <= kBinMaxBins && kpb <= kBinKeysMax) {
+                // scratch in ix.fill: {occupied cells, arrived bins} as one 8-byte word (+ 8 bytes: the rows below are read 16 bytes at a time)
+                // | [nbins][kBinBlocks] counts / offsets | nbins totals | nbins + 1 starts
+                const size_t words = 4 + (size_t)kBinBlocks * nbins + nbins + (nbins + 1);
+                if (tc_status s = ensure(ctx, ix.fill, std::max(fill_bytes, words * sizeof(uint32_t)))) return s;
+                uint32_t *occ_ticket = (uint32_t *)ix.fill.p, *cnt = occ_ticket + 4, *tot = cnt + (size_t)kBinBlocks * nbins, *binstart = tot + nbins;
+                volatile uint32_t *h_max = (volatile uint32_t *)((char *)ctx->pinned + 2048 + 8192 + 256);      // [0] = largest bin, [1] = written
+                unsigned long long *d_max = (unsigned long long *)pinned_dev_ptr(ctx, (const void *)h_max);
+                if (!d_max) return fail(ctx, TC_GPU, "index build: the pinned block has no device address");
+                h_max[0] = 0u; h_max[1] = 0u;
+                {
+                    ProfScope ps(ctx, "cell_bin_count");
+                    hipLaunchKernelGGL(bin_count_kernel, dim3(kBinBlocks), dim3(kBinWalkThreads), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0, nkeys, kpb,
+                                       nbins, cnt, reinterpret_cast<uint32_t *>((float4 *)ix.pts.p + n), (uint32_t *)ix.cell_start.p, cs + nkeys + 2);
+                }
+                {
+                    ProfScope ps(ctx, "cell_bin_scan");
+                    hipLaunchKernelGGL(bin_offsets_kernel, dim3((nbins + 3) / 4), dim3(256), 0, st, cnt, nbins, tot);
+                    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)tot, nbins, binstart, occ_ticket, d_max);
+                }
+                if (tc_status s = ensure(ctx, ctx->build_tmp, (n + kPtsPad) * sizeof(float4))) return s;
+                // the scatter is valid whatever the bins' populations are: it runs while the host waits for the largest one (no bubble
+                // on the stream for the decision; a build that falls back has wasted these 10 us)
+                {
+                    ProfScope ps(ctx, "cell_bin_scatter");
+                    hipLaunchKernelGGL(bin_scatter_kernel, dim3(kBinBlocks), dim3(kBinWalkThreads), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0, nkeys,
+                                       kpb, nbins, (const uint32_t *)cnt, (const uint32_t *)binstart, (float4 *)ctx->build_tmp.p);
+                }
+                TC_HIP_TRY(ctx, hipGetLastError());
+                if (tc_status s = wait_pinned_word(ctx, h_max + 1, "index build (bin populations)")) return s;
+                if (h_max[0] <= kBinCap) {
+                    if (check) { h_occ[0] = 0u; h_occ[1] = 0u; }
+                    unsigned long long *d_occ_host = check ? (unsigned long long *)pinned_dev_ptr(ctx, (const void *)h_occ) : nullptr;
+                    {
+                        ProfScope ps(ctx, "cell_bin_place");
+                        hipLaunchKernelGGL(bin_place_kernel, dim3(nbins), dim3(kBinPlaceThreads), 0, st, (const float4 *)ctx->build_tmp.p, (const uint32_t *)binstart,
+                                           nbins, kpb, nkeys, g, d_state_transform, tg, tile_major ? 1 : 0, cs, (float4 *)ix.pts.p, occ_ticket,
+                                           (uint32_t *)ix.cell_start.p, d_occ_host);
+                    }
+                    binned_done = true;
+                } else if (dbg & 256) {
+                    fprintf(stderr, "[tc] index: largest bin holds %u points (> %u): atomic counting sort\n", h_max[0], kBinCap);
+                }
+            }
+        }
+        if (!binned_done) {
         TC_HIP_TRY(ctx, hipMemsetAsync(ix.fill.p, 0, fill_bytes, st));
         // records past the end: huge finite coordinates -> d2 = +inf, never a match (kernels may read, never select them)
         {
@@ -605,6 +914,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
             ProfScope ps(ctx, "cell_rerank");
             hipLaunchKernelGGL(rerank_kernel, dim3(nb), dim3(256), 0, st, n32, g, d_state_transform, tg, tile_major ? 1 : 0, nkeys, (const uint32_t *)cs,
                                (const float4 *)ctx->build_tmp.p, (float4 *)ix.pts.p);
+        }
         }
         TC_HIP_TRY(ctx, hipGetLastError());
         if (!check) break;

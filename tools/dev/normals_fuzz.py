@@ -71,7 +71,7 @@ def run(budget, seed, ctx, log=print, only_case=None):
         spacing = float(np.linalg.norm(p.max(0) - p.min(0))) / max(n, 2) ** (1.0 / 3.0) + 1e-12
         k = int(rng.choice([1, 2, 3, 5, 10, 16, 17, 31, 32, 33, 64, 100, 127, 128, int(rng.integers(1, 129)), 129, 200, int(rng.integers(129, 600))]))      # (> 128: the wave-per-point kernel)
         radius = None if rng.random() < 0.6 else float(spacing * rng.choice([0.05, 0.5, 1.5, 4.0, 50.0]))
-        if k > 128: radius = None                # (k > 128 together with a radius: TC_UNSUPPORTED, a documented limit)
+        # (k > 128 together with a radius: the wave-per-point kernel folds the radius ball itself since round 4)
         orient = bool(rng.random() < 0.7)
         vp = None if rng.random() < 0.6 else tuple((p.mean(0) + (p.std(0) + 1e-3) * rng.normal(0, 3, 3)).tolist())
         mode = int(rng.integers(0, 3))           # 0 plain host call, 1 device tensor, 2 cloud handle
