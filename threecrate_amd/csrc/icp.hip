@@ -1741,7 +1741,6 @@ static tc_status check_iteration_count(tc_context *ctx, const IcpState *hs, size
 // The events live in the context (created once, reused by every call).
 template <typename F>
 static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate, F &&enqueue_iteration) {
-    hipStream_t st = ctx->stream;
     auto chunk_len = [](size_t c) -> size_t { return c == 0 ? 6 : c == 1 ? 2 : c == 2 ? 4 : 8; };
     size_t nchunks = 0;
     for (size_t covered = 0; covered < max_iters; ++nchunks) covered += chunk_len(nchunks);

@@ -17,65 +17,82 @@ def frob(a, b):
     return float(np.linalg.norm(O.isometry_to_matrix(a).astype(np.float64) - O.isometry_to_matrix(b).astype(np.float64)))
 
 
+def build_case(seed, cases, ctx):
+    """inputs + the two runners of case `cases` of campaign `seed` (also used by variants_debug.py)"""
+    kiss_seeded = None; params = {}
+    rng = np.random.default_rng([seed, cases])
+    n = int(rng.choice([600, 2500, 8000]))
+    kind = int(rng.integers(0, 3))
+    if kind == 0: tgt = rng.random((n, 3))
+    elif kind == 1: u = rng.random((n, 2)); tgt = np.stack([u[:, 0], u[:, 1], 0.15 * np.sin(5 * u[:, 0]) * np.cos(4 * u[:, 1])], 1)
+    else: tgt = rng.random((n, 3)) * np.array([4.0, 1.0, 0.3])
+    scale = float(rng.choice([1.0, 10.0, 40.0]))
+    tgt = (tgt * scale).astype(np.float32)
+    ext = float(np.linalg.norm(tgt.max(0) - tgt.min(0)))
+    spacing = ext / n ** (1.0 / 3.0)
+    T = synth.yaw_isometry(tuple((rng.normal(0, 0.01, 3) * ext).tolist()), float(rng.normal(0, 0.02)))
+    src = synth.apply_isometry(T, tgt[rng.permutation(n)[: int(n * rng.choice([0.5, 1.0]))]])
+    if rng.random() < 0.5: src = (src + rng.normal(0, 1e-3 * ext, src.shape)).astype(np.float32)
+    init = None if rng.random() < 0.6 else synth.yaw_isometry(tuple((rng.normal(0, 0.004, 3) * ext).tolist()), float(rng.normal(0, 0.005)))
+    which = int(rng.integers(0, 3))
+    if which == 1:
+        f_ = 0.3 / spacing
+        tgt = (tgt * f_).astype(np.float32); src = (src * f_).astype(np.float32)
+        if init is not None: init = np.concatenate([init[:4], init[4:] * f_]).astype(np.float32)
+        ext *= f_; spacing *= f_
+    if which == 0:
+        nl = int(rng.integers(1, 4))
+        levels = [(float(spacing * f), int(rng.integers(1, 25)), None if rng.random() < 0.4 else float(spacing * f * rng.choice([2.0, 6.0])))
+                  for f in sorted(rng.choice([0.7, 1.5, 3.0, 6.0], nl, replace=False), reverse=True)]
+        fin_it = int(rng.integers(1, 25)); fin_md = None if rng.random() < 0.4 else float(spacing * rng.choice([1.5, 5.0]))
+        # thresholds far above the f32 resolution of the mse (~1e-7 * spacing^2): a stop decided by the last bits of the
+        # reference's sequential sums is loop_fuzz.py's subject, not this one's
+        thr = float(rng.choice([1e-4, 1e-3, 1e-2])) * spacing * spacing
+        name = f"multiscale levels {levels} final {fin_it}/{fin_md} thr {thr:.3g}"
+        cfg = tc.MultiScaleIcpConfig(levels=[tc.IcpScaleLevel(*l) for l in levels], final_refinement_iterations=fin_it,
+                                     final_max_correspondence_distance=fin_md, convergence_threshold=thr)
+        grun = lambda s_: ctx.multiscale_icp_point_to_point(s_, tgt, init, cfg)
+        orun = lambda s_: O.multiscale_icp_point_to_point(s_, tgt, init, levels, fin_it, fin_md, thr)
+        def oexact(s_):
+            O.lib().tco_set_exact_sums(1)
+            try: return O.multiscale_icp_point_to_point(s_, tgt, init, levels, fin_it, fin_md, thr)
+            finally: O.lib().tco_set_exact_sums(0)
+    elif which == 1:
+        # (kiss_icp.rs:277 stops at |prev_mse - mse| < 1e-6 ABSOLUTE: metric clouds; here the cloud is rescaled so that the
+        # mse is ~1e-2, i.e. the threshold sits 100x above the f32 resolution of the mse as on a LiDAR frame)
+        vs = float(spacing * rng.choice([0.8, 1.5, 3.0])); mx = float(ext * rng.choice([0.5, 2.0])); mn = float(ext * rng.choice([0.0, 0.05]))
+        it = int(rng.integers(1, 61))
+        name = f"kiss voxel {vs:.3g} range {mn:.3g}..{mx:.3g} iters {it}"
+        cfg = tc.KissIcpConfig(voxel_size=vs, max_range=mx, min_range=mn, max_iterations=it)
+        grun = lambda s_: ctx.kiss_icp(s_, tgt, init, cfg)
+        orun = lambda s_: O.kiss_icp(s_, tgt, init, vs, mx, mn, it)[0]
+        oexact = lambda s_: O.kiss_icp(s_, tgt, init, vs, mx, mn, it, exact_sums=True)[0]
+        kiss_seeded = lambda sd: O.kiss_icp(src, tgt, init, vs, mx, mn, it, voxel_order_seed=sd)[0]
+    else:
+        it = int(rng.integers(1, 41)); md = float(spacing * rng.choice([1.5, 4.0, 50.0])); thr = float(rng.choice([1e-4, 1e-3, 1e-2]))
+        kc = int(rng.choice([5, 10, 20]))
+        name = f"gicp iters {it} md {md:.3g} thr {thr:.3g} k {kc}"
+        cfg = tc.GicpConfig(max_iterations=it, max_correspondence_distance=md, convergence_threshold=thr, k_correspondences=kc)
+        grun = lambda s_: ctx.gicp(s_, tgt, init, cfg)
+        orun = lambda s_: O.gicp(s_, tgt, init, it, md, thr, kc)
+        oexact = lambda s_: O.gicp(s_, tgt, init, it, md, thr, kc, exact_sums=True)
+    tag = f"case {cases}: n {n} m {len(src)} kind {kind} scale {scale} init {init is not None} | {name}"
+    if which == 0: params = dict(levels=levels, fin_it=fin_it, fin_md=fin_md, thr=thr)
+    elif which == 1: params = dict(vs=vs, mx=mx, mn=mn, it=it)
+    else: params = dict(it=it, md=md, thr=thr, kc=kc)
+    return dict(tag=tag, src=src, tgt=tgt, init=init, which=which, ext=ext, spacing=spacing, grun=grun, orun=orun, oexact=oexact, kiss_seeded=kiss_seeded, params=params, cfg=cfg)
+
+
 def run(budget, seed, ctx, log=print, only_case=None):
     t_end = time.time() + budget
-    cases = bad = noisy = 0
+    cases = bad = noisy = exact = 0
     while time.time() < t_end:
         cases += 1
         if only_case is not None:
             if cases > 1: break
             cases = only_case
-        rng = np.random.default_rng([seed, cases])
-        n = int(rng.choice([600, 2500, 8000]))
-        kind = int(rng.integers(0, 3))
-        if kind == 0: tgt = rng.random((n, 3))
-        elif kind == 1: u = rng.random((n, 2)); tgt = np.stack([u[:, 0], u[:, 1], 0.15 * np.sin(5 * u[:, 0]) * np.cos(4 * u[:, 1])], 1)
-        else: tgt = rng.random((n, 3)) * np.array([4.0, 1.0, 0.3])
-        scale = float(rng.choice([1.0, 10.0, 40.0]))
-        tgt = (tgt * scale).astype(np.float32)
-        ext = float(np.linalg.norm(tgt.max(0) - tgt.min(0)))
-        spacing = ext / n ** (1.0 / 3.0)
-        T = synth.yaw_isometry(tuple((rng.normal(0, 0.01, 3) * ext).tolist()), float(rng.normal(0, 0.02)))
-        src = synth.apply_isometry(T, tgt[rng.permutation(n)[: int(n * rng.choice([0.5, 1.0]))]])
-        if rng.random() < 0.5: src = (src + rng.normal(0, 1e-3 * ext, src.shape)).astype(np.float32)
-        init = None if rng.random() < 0.6 else synth.yaw_isometry(tuple((rng.normal(0, 0.004, 3) * ext).tolist()), float(rng.normal(0, 0.005)))
-        which = int(rng.integers(0, 3))
-        if which == 1:
-            f_ = 0.3 / spacing
-            tgt = (tgt * f_).astype(np.float32); src = (src * f_).astype(np.float32)
-            if init is not None: init = np.concatenate([init[:4], init[4:] * f_]).astype(np.float32)
-            ext *= f_; spacing *= f_
-        if which == 0:
-            nl = int(rng.integers(1, 4))
-            levels = [(float(spacing * f), int(rng.integers(1, 25)), None if rng.random() < 0.4 else float(spacing * f * rng.choice([2.0, 6.0])))
-                      for f in sorted(rng.choice([0.7, 1.5, 3.0, 6.0], nl, replace=False), reverse=True)]
-            fin_it = int(rng.integers(1, 25)); fin_md = None if rng.random() < 0.4 else float(spacing * rng.choice([1.5, 5.0]))
-            # thresholds far above the f32 resolution of the mse (~1e-7 * spacing^2): a stop decided by the last bits of the
-            # reference's sequential sums is loop_fuzz.py's subject, not this one's
-            thr = float(rng.choice([1e-4, 1e-3, 1e-2])) * spacing * spacing
-            name = f"multiscale levels {levels} final {fin_it}/{fin_md} thr {thr:.3g}"
-            cfg = tc.MultiScaleIcpConfig(levels=[tc.IcpScaleLevel(*l) for l in levels], final_refinement_iterations=fin_it,
-                                         final_max_correspondence_distance=fin_md, convergence_threshold=thr)
-            grun = lambda s_: ctx.multiscale_icp_point_to_point(s_, tgt, init, cfg)
-            orun = lambda s_: O.multiscale_icp_point_to_point(s_, tgt, init, levels, fin_it, fin_md, thr)
-        elif which == 1:
-            # (kiss_icp.rs:277 stops at |prev_mse - mse| < 1e-6 ABSOLUTE: metric clouds; here the cloud is rescaled so that the
-            # mse is ~1e-2, i.e. the threshold sits 100x above the f32 resolution of the mse as on a LiDAR frame)
-            vs = float(spacing * rng.choice([0.8, 1.5, 3.0])); mx = float(ext * rng.choice([0.5, 2.0])); mn = float(ext * rng.choice([0.0, 0.05]))
-            it = int(rng.integers(1, 61))
-            name = f"kiss voxel {vs:.3g} range {mn:.3g}..{mx:.3g} iters {it}"
-            cfg = tc.KissIcpConfig(voxel_size=vs, max_range=mx, min_range=mn, max_iterations=it)
-            grun = lambda s_: ctx.kiss_icp(s_, tgt, init, cfg)
-            orun = lambda s_: O.kiss_icp(s_, tgt, init, vs, mx, mn, it)[0]
-            kiss_seeded = lambda sd: O.kiss_icp(src, tgt, init, vs, mx, mn, it, voxel_order_seed=sd)[0]
-        else:
-            it = int(rng.integers(1, 41)); md = float(spacing * rng.choice([1.5, 4.0, 50.0])); thr = float(rng.choice([1e-4, 1e-3, 1e-2]))
-            kc = int(rng.choice([5, 10, 20]))
-            name = f"gicp iters {it} md {md:.3g} thr {thr:.3g} k {kc}"
-            cfg = tc.GicpConfig(max_iterations=it, max_correspondence_distance=md, convergence_threshold=thr, k_correspondences=kc)
-            grun = lambda s_: ctx.gicp(s_, tgt, init, cfg)
-            orun = lambda s_: O.gicp(s_, tgt, init, it, md, thr, kc)
-        tag = f"case {cases}: n {n} m {len(src)} kind {kind} scale {scale} init {init is not None} | {name}"
+        cs = build_case(seed, cases, ctx)
+        tag, src, tgt, init, which, ext, grun, orun, kiss_seeded = (cs[k] for k in ('tag', 'src', 'tgt', 'init', 'which', 'ext', 'grun', 'orun', 'kiss_seeded'))
         try:
             try: g, gerr = grun(src), None
             except tc.Error as e: g, gerr = None, type(e).__name__ + ": " + str(e)[:80]
@@ -104,12 +121,23 @@ def run(budget, seed, ctx, log=print, only_case=None):
             stops = {(f.converged, f.iterations) for f in fam} | {(r.converged, r.iterations)}
             if (stop_same or len(stops) > 1 or (g.converged, g.iterations) in stops) and fro <= 3.0 * spread + tol:
                 noisy += 1
+                continue
+            # the device adds the reference's f32 terms in f64: does it agree with the REFERENCE doing the same (exact_sums: the only
+            # change is the accumulator of the Kabsch / Gauss-Newton sums)?  Then the difference is the reference's own rounding of
+            # its sequential f32 sums, amplified by the case (a handful of points per level, a stop decided by the last digits)
+            try: rx = cs["oexact"](src)
+            except O.OracleError: rx = None
+            if rx is not None and (g.converged, g.iterations) == (rx.converged, rx.iterations) and frob(g.transformation, rx.transformation) <= tol:
+                exact += 1
             else:
                 bad += 1
-                log("MISMATCH", tag, f"| gpu {g.converged} {g.iterations} oracle {r.converged} {r.iterations} frob {fro:.3e} oracle's own spread {spread:.3e} stops {sorted(stops)}")
+                fx = -1.0 if rx is None else frob(g.transformation, rx.transformation)
+                log("MISMATCH", tag, f"| gpu {g.converged} {g.iterations} oracle {r.converged} {r.iterations} frob {fro:.3e} oracle's own spread {spread:.3e} stops {sorted(stops)}"
+                    f" | exact-sums oracle {None if rx is None else (rx.converged, rx.iterations)} frob to it {fx:.3e}")
         except Exception as e:
             bad += 1; log("EXCEPTION", tag, type(e).__name__, str(e)[:200])
-    log(f"variants fuzz: {cases} cases, {bad} to look at, {noisy} within the oracle's own sensitivity to the order of its input")
+    log(f"variants fuzz: {cases} cases, {bad} to look at, {noisy} within the oracle's own sensitivity to the order of its input, "
+        f"{exact} equal to the oracle with its f32 sums kept in f64")
     return cases, bad
 
 

@@ -10,8 +10,8 @@ dst = os.path.join(ROOT, "profiles")
 out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_profiles.py"), src], capture_output=True, text=True).stdout
 open(os.path.join(dst, f"{name}_summary.txt"), "w").write(out)
 shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, f"{name}_summary.json"))
-ks = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
-if ks: shutil.copy(ks[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
+if ks: shutil.copy(ks[-1], os.path.join(dst, f"{name}_kernel_stats.csv"))
 summ = json.load(open(os.path.join(src, "summary.json")))
 kernels = {k: {kk: vv for kk, vv in v.items() if "SIZE" in kk or "traffic" in kk} for k, v in summ.items() if "traffic_bytes_raw" in v}
 json.dump({"source": f"profiles/{name}_summary.json (tools/collect_profiles.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "

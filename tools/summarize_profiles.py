@@ -6,7 +6,7 @@ gfx950 corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE is reported in
 16-B-per-lane stores.  Both raw and the x2-corrected read figure are reported; our kernels mix
 4/16-B gathers with streams, so the truth lies between them.
 """
-import collections
+import os, re, collections
 import csv
 import glob
 import json
@@ -17,12 +17,17 @@ res = {}
 
 
 def load(sub, pat):
-    fs = glob.glob(f"{out}/{sub}/*/*{pat}.csv")
-    return list(csv.DictReader(open(fs[0]))) if fs else []
+    # (gpurun merges every call's files into the same local directory: take the newest run)
+    fs = sorted(glob.glob(f"{out}/{sub}/*/*{pat}.csv"), key=os.path.getmtime)
+    return list(csv.DictReader(open(fs[-1]))) if fs else []
 
 
 def short(name):
-    # template argument = ICP mode: 0 point-to-point, 1 point-to-plane, 2 GICP
+    # template arguments = ICP mode (0 point-to-point, 1 point-to-plane, 2 GICP) and, for the main pass, whether the launch also
+    # runs the previous iteration's finalize step in its solver block ("fused": DESIGN 4.3)
+    m = re.search(r"icp_correspond_reduce_kernel<(\d)(?:, ?(true|false|1|0))?>", name)
+    if m:
+        return f"icp_correspond_reduce_kernel<{m.group(1)}>" + (" fused" if m.group(2) in ("true", "1") else "")
     for k in ["icp_correspond_reduce_kernel<1>", "icp_correspond_reduce_kernel<0>", "icp_correspond_reduce_kernel<2>",
               "icp_refine_kernel<1>", "icp_refine_kernel<0>", "icp_refine_kernel<2>", "icp_finalize_kernel", "knn_kernel",
               "bin_count_kernel", "bin_offsets_kernel", "bin_scan_kernel", "bin_scatter_kernel", "bin_place_kernel", "bbox_state_init_kernel", "vox_hist_kernel", "vox_scatter_kernel",
