@@ -52,3 +52,31 @@ def test_binned_and_atomic_index_builds_agree_bit_for_bit(ctx, monkeypatch, name
     a, b = out["1"], out["0"]
     for x, y, what in zip(a, b, ("normals", "knn idx", "knn dist", "knn count", "icp T", "icp mse", "icp pairs", "handle normals")):
         assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True), (name, what)
+
+
+def test_a_cell_of_a_hundred_thousand_points_is_ordered_deterministically(ctx, monkeypatch):
+    """A cluster far below the cell edge: ~120 k points of a 400 k cloud in ONE cell.  Until round 4 a cell of more than 65 536
+    points kept the atomic arrival order of its records (the only documented source of run-to-run differences): about one run in
+    ten matched a different member of an equidistant neighbour pair somewhere in the cluster (tools/dev/index_stress.py).  The
+    cut-off is 2^20 now: four builds -- both placements, twice each -- give the same bits; with the cut-off lowered below the
+    cell's population the build still works (arrival order inside that cell: results valid, not compared)."""
+    rng = np.random.default_rng(3)
+    u = synth.uniform_cloud(280_000, seed=8)
+    pts = np.concatenate([u, (np.float32(0.4137) + 0.002 * rng.standard_normal((120_000, 3))).astype(np.float32)]).astype(np.float32)
+    d = torch.from_numpy(pts).cuda()
+    src = torch.from_numpy((pts[::3] + np.float32(0.003)).astype(np.float32)).cuda()
+    runs = []
+    for mode in ("1", "0", "1", "0"):
+        monkeypatch.setenv("TC_INDEX_BINNED", mode)
+        nrm = ctx.estimate_normals(d, 12)
+        r = ctx.icp_point_to_plane_detailed(src, d, nrm, None, 3, None, 0.0, correspondences=True)
+        runs.append((nrm.cpu().numpy(), r.transformation, np.float32(r.mse), np.asarray(r.correspondences)))
+    monkeypatch.delenv("TC_INDEX_BINNED")
+    for other in runs[1:]:
+        for x, y, what in zip(runs[0], other, ("normals", "icp T", "icp mse", "icp pairs")):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), what
+    monkeypatch.setenv("TC_RANK_QUADRATIC_MAX", "4096")
+    nrm = ctx.estimate_normals(d, 12)
+    monkeypatch.delenv("TC_RANK_QUADRATIC_MAX")
+    dev = 1.0 - np.abs((nrm.cpu().numpy()[:, 3:] * runs[0][0][:, 3:]).sum(1))
+    assert (dev > 1e-4).mean() < 1e-4          # (an equidistant pair here and there may be resolved the other way)

@@ -158,9 +158,14 @@ def _rank_main(rank, world, port, q):
         mine = ds[:0] if rank == 0 else ds[(rank - 1) * per: rank * per]
         a = D.sharded_icp_point_to_plane(ctx, mine, dt, nrm, None, 8, None, 0.0, comm=comm, source_is_local_slice=True)
         out["local_empty"] = (a.transformation, a.mse, a.iterations)
-        # a source cell far beyond the deterministic re-rank's reach (80 k points inside one target cell): the ranks' shard
-        # boundaries fall INSIDE it, so they must agree on the order of its records (build_index(strict_order))
-        a = D.sharded_icp_point_to_plane(ctx, _big_cell_source(ds), dt, nrm, None, 4, None, 0.0, comm=comm, correspondences=True)
+        # a source cell beyond the deterministic re-rank's reach (80 k points inside one target cell; the reach is 2^20 since round
+        # 4 -- lowered here to the 65 536 of rounds 2-3, read per call): the ranks' shard boundaries fall INSIDE it, so they must
+        # agree on the order of its records (build_index(strict_order) -> stable radix re-sort)
+        os.environ["TC_RANK_QUADRATIC_MAX"] = "65536"
+        try:
+            a = D.sharded_icp_point_to_plane(ctx, _big_cell_source(ds), dt, nrm, None, 4, None, 0.0, comm=comm, correspondences=True)
+        finally:
+            os.environ.pop("TC_RANK_QUADRATIC_MAX", None)
         out["bigcell"] = (a.transformation, a.mse, a.iterations, a.converged, a.correspondences)
         comm.close()
         ctx.close()

@@ -1,7 +1,7 @@
 // grid.hip -- device-built uniform-grid index (replaces KdTree::new, nearest_neighbor.rs:37-159).
 //
 // Pipeline (all on ctx->stream):
-//   bbox_kernel      : per-block min/max partials, folded on the host (order independent)
+//   bbox_kernel      : min/max box (+ four sample boxes) folded into device accumulators with ordered-integer atomics
 //   cell_hist_kernel : cell id per point + histogram
 //   scan_*           : exclusive prefix sum of the histogram -> cell_start
 //   place_kernel     : the record goes straight to cell_start[cell] + the arrival rank the histogram atomics returned
@@ -46,70 +46,96 @@ constexpr int kBboxBlocks = 256;
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); }
 constexpr uint32_t kOrdPlusInf = 0xFF800000u, kOrdMinusInf = 0x007FFFFFu;       // f2ord(+inf), f2ord(-inf): the empty box
+constexpr uint32_t kBboxAccStride = 32;        // words between two accumulators of the state block (ticket at word 0, accumulator k at (k + 1) * 32)
+constexpr size_t kBboxStateBytes = 31 * kBboxAccStride * sizeof(uint32_t), kBboxBufBytes = kBboxStateBytes + 128 + 256;   // + the no-poll results
 
 // The blocks fold their boxes into 30 accumulators in device memory with integer atomics (acc: [0..6) the exact box, [6..30) four
-// sample boxes; `state`: ticket | 7 pad | acc[30]), drain them (s_waitcnt vmcnt(0)) and take a ticket; the LAST block reads the
+// sample boxes; `state`: ticket, then one accumulator per 128-byte line), drain them (s_waitcnt vmcnt(0)) and take a ticket; the LAST block reads the
 // accumulators back (atomic loads: served where the atomics ran), stores the 30 floats to `out` -- the context's pinned HOST block,
 // or device memory -- raises *done and resets the state for the next launch.  No per-block fence, no partials over PCIe (the first
 // version of round 4 did both: 20.6 us instead of 10.9), no copy kernels, no stream synchronisation: the host polls *done.
+// VEC (the cloud starts on a 16-byte boundary: every hipMalloc'd or torch-allocated tensor): a thread takes FOUR consecutive points
+// per step as three 16-byte reads (perfectly coalesced; the 12-byte records read one float at a time cost three gathers per
+// point), four steps in flight -- 1 M points are one round trip per thread instead of 16 dependent ones: 22 -> ~8 us.
+template <bool VEC>
 __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, uint32_t *__restrict__ state, int robust,
                                                   float *__restrict__ out, uint32_t *__restrict__ done) {
     const bool sbox = robust != 0;
-    __shared__ float sm[4][6];
-    __shared__ float ss[4][4][6];
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    float smn[3] = {INFINITY, INFINITY, INFINITY}, smx[3] = {-INFINITY, -INFINITY, -INFINITY};     // this thread's share of sample (lane & 3)
-    // each thread reads whole points; consecutive lanes read consecutive 12-B records
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    __shared__ float sm[4][30];
+    // v[0..6): the exact box (min xyz | max xyz); v[6 + 6 s ..): sample box s (points with index = s mod 4 whose hash is drawn)
+    float v[30];
+#pragma unroll
+    for (int k = 0; k < 30; ++k) v[k] = (k % 6 < 3) ? INFINITY : -INFINITY;
+    auto take = [&](float x, float y, float z, uint32_t i, int s) {
         // a point with a NaN or infinite coordinate takes no part in the box (it is indexed in the bucket behind the last cell)
-        if (!(fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f)) continue;
-        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
-        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+        if (!(fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f)) return;
+        v[0] = fminf(v[0], x); v[1] = fminf(v[1], y); v[2] = fminf(v[2], z);
+        v[3] = fmaxf(v[3], x); v[4] = fmaxf(v[4], y); v[5] = fmaxf(v[5], z);
         if (sbox && ((i * 2654435761u) >> 28) == 0u) {
-            smn[0] = fminf(smn[0], x); smn[1] = fminf(smn[1], y); smn[2] = fminf(smn[2], z);
-            smx[0] = fmaxf(smx[0], x); smx[1] = fmaxf(smx[1], y); smx[2] = fmaxf(smx[2], z);
+            float *b = v + 6 + 6 * s;
+            b[0] = fminf(b[0], x); b[1] = fminf(b[1], y); b[2] = fminf(b[2], z);
+            b[3] = fmaxf(b[3], x); b[4] = fmaxf(b[4], y); b[5] = fmaxf(b[5], z);
         }
-    }
-    if (sbox) {
-        // fold the lanes of equal (lane & 3): i = lane mod 4 for every point of the thread (the stride is a multiple of 64)
+    };
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if constexpr (VEC) {
+        const float4 *__restrict__ q = reinterpret_cast<const float4 *>(xyz);
+        const uint32_t nq = n >> 2;                 // whole groups of four points
+        constexpr int U = 4;
+        for (uint32_t c0 = gt; c0 < nq; c0 += U * stride) {
+            float4 a[U], b[U], c[U];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+            for (int u = 0; u < U; ++u) {
+                const uint32_t cc = min(c0 + (uint32_t)u * stride, nq - 1u);       // (clamped: a repeated group changes no box)
+                a[u] = q[3 * (size_t)cc]; b[u] = q[3 * (size_t)cc + 1]; c[u] = q[3 * (size_t)cc + 2];
+            }
 #pragma unroll
-            for (int o = 32; o >= 4; o >>= 1) {
-                smn[c] = fminf(smn[c], __shfl_xor(smn[c], o));
-                smx[c] = fmaxf(smx[c], __shfl_xor(smx[c], o));
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = 4u * min(c0 + (uint32_t)u * stride, nq - 1u);
+                take(a[u].x, a[u].y, a[u].z, i, 0);
+                take(a[u].w, b[u].x, b[u].y, i + 1u, 1);
+                take(b[u].z, b[u].w, c[u].x, i + 2u, 2);
+                take(c[u].y, c[u].z, c[u].w, i + 3u, 3);
             }
         }
-        if ((threadIdx.x & 63) < 4) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { ss[threadIdx.x >> 6][threadIdx.x & 63][c] = smn[c]; ss[threadIdx.x >> 6][threadIdx.x & 63][3 + c] = smx[c]; }
+        if (gt < (n & 3u)) {                         // the last n mod 4 points
+            const uint32_t i = (nq << 2) + gt;
+            const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+            if ((i & 3u) == 0u) take(x, y, z, i, 0); else if ((i & 3u) == 1u) take(x, y, z, i, 1); else take(x, y, z, i, 2);
+        }
+    } else {
+        // each thread reads whole points; consecutive lanes read consecutive 12-B records; i = lane mod 4 for every point of a
+        // thread (the stride is a multiple of 64)
+        for (uint32_t i = gt; i < n; i += stride) {
+            const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+            const uint32_t sidx = threadIdx.x & 3u;
+            if (sidx == 0u) take(x, y, z, i, 0); else if (sidx == 1u) take(x, y, z, i, 1); else if (sidx == 2u) take(x, y, z, i, 2); else take(x, y, z, i, 3);
         }
     }
+    // fold over the wave (min / max: order independent), the four waves through LDS, then the block's 30 values into the accumulators
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int k = 0; k < 30; ++k) {
+        if (k < 6 || sbox) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
-            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+            for (int o = 32; o > 0; o >>= 1) {
+                const float w = __shfl_xor(v[k], o);
+                v[k] = (k % 6 < 3) ? fminf(v[k], w) : fmaxf(v[k], w);
+            }
         }
     }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { sm[threadIdx.x >> 6][c] = mn[c]; sm[threadIdx.x >> 6][3 + c] = mx[c]; }
+        for (int k = 0; k < 30; ++k) sm[threadIdx.x >> 6][k] = v[k];
     }
     __syncthreads();
-    uint32_t *acc = state + 8;
-    if (threadIdx.x < 6) {
-        float v = sm[0][threadIdx.x];
-        for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
-        if (threadIdx.x < 3) atomicMin(&acc[threadIdx.x], f2ord(v)); else atomicMax(&acc[threadIdx.x], f2ord(v));
-    }
-    if (sbox && threadIdx.x < 24) {
-        const int sidx = threadIdx.x / 6, c = threadIdx.x % 6;
-        float v = ss[0][sidx][c];
-        for (int w = 1; w < 4; ++w) v = (c < 3) ? fminf(v, ss[w][sidx][c]) : fmaxf(v, ss[w][sidx][c]);
-        if (c < 3) atomicMin(&acc[6 + threadIdx.x], f2ord(v)); else atomicMax(&acc[6 + threadIdx.x], f2ord(v));
+    // (one accumulator per 128-byte line: 256 blocks x 30 atomics on ONE line serialise at the memory side -- the kernel took 21 us
+    // whatever the reads cost; on 30 lines they run side by side)
+    uint32_t *acc = state + kBboxAccStride;
+    if (threadIdx.x < (sbox ? 30 : 6)) {
+        const bool is_min = threadIdx.x % 6 < 3;
+        float r = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) r = is_min ? fminf(r, sm[w][threadIdx.x]) : fmaxf(r, sm[w][threadIdx.x]);
+        if (is_min) atomicMin(&acc[threadIdx.x * kBboxAccStride], f2ord(r)); else atomicMax(&acc[threadIdx.x * kBboxAccStride], f2ord(r));
     }
     __shared__ uint32_t s_last;
     if (threadIdx.x < 64) {                       // the lanes that issued atomics are in wave 0: its atomics are done before its ticket
@@ -119,9 +145,9 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x < 30) {
-        const uint32_t u = __hip_atomic_load(&acc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t u = __hip_atomic_load(&acc[threadIdx.x * kBboxAccStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&out[threadIdx.x], ord2f(u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&acc[threadIdx.x], (threadIdx.x % 6 < 3) ? kOrdPlusInf : kOrdMinusInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&acc[threadIdx.x * kBboxAccStride], (threadIdx.x % 6 < 3) ? kOrdPlusInf : kOrdMinusInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 0) __hip_atomic_store(state, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done) {
@@ -133,8 +159,8 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz
 
 __global__ void bbox_state_init_kernel(uint32_t *__restrict__ state) {
     const uint32_t t = threadIdx.x;
-    if (t < 8) state[t] = 0u;
-    else if (t < 38) state[t] = ((t - 8) % 6 < 3) ? kOrdPlusInf : kOrdMinusInf;
+    if (t == 0) state[0] = 0u;
+    if (t < 30) state[(t + 1) * kBboxAccStride] = (t % 6 < 3) ? kOrdPlusInf : kOrdMinusInf;
 }
 
 
@@ -144,7 +170,7 @@ __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict_
                                                        const IcpState *__restrict__ st, TileGeom tg, int tile_major, uint32_t nkeys,
                                                        uint32_t *__restrict__ cell_of, uint32_t *__restrict__ hist,
                                                        uint32_t *__restrict__ arrival, uint32_t *__restrict__ pts_pad,
-                                                       uint32_t *__restrict__ cs_front, uint32_t *__restrict__ cs_tail) {
+                                                       uint32_t *__restrict__ cs_front, uint32_t *__restrict__ cs_tail, uint32_t rank_max) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // the paddings the ICP search over-reads (three tiny memsets = three launches otherwise): huge coordinates behind the
     // sorted records, zeros around the prefix sums
@@ -177,7 +203,7 @@ __global__ void __launch_bounds__(256) cell_hist_kernel(const float *__restrict_
     arrival[i] = a;
     // a cell too populous for the quadratic re-rank (rank_gather_kernel): the word behind the histogram says so
     // (build_index(strict_order): callers whose RANKS must agree on the order re-sort then)
-    if (a == kRankQuadraticMax) hist[nkeys + 1] = 1u;
+    if (a == rank_max) hist[nkeys + 1] = 1u;
 }
 
 __global__ void __launch_bounds__(256) iota_kernel(uint32_t *__restrict__ p, uint32_t n) {
@@ -299,20 +325,22 @@ __global__ void __launch_bounds__(256) rank_gather_kernel(const float *__restric
                                                          const uint32_t *__restrict__ cell_of,
                                                          const uint32_t *__restrict__ cell_start,
                                                          const uint32_t *__restrict__ slot,
-                                                         float4 *__restrict__ pts, int slot_is_ordered) {
+                                                         float4 *__restrict__ pts, int slot_is_ordered, uint32_t rank_max) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     uint32_t i = slot[p];
     uint32_t c = cell_of[i];
     uint32_t s = cell_start[c], e = cell_start[c + 1];
     // rank = the number of points of the cell with a smaller original index: quadratic in the cell's population, which is ~1.5 on
-    // the clouds this index is sized for.  65536 points in ONE cell (a block of exact duplicates, a cluster far below the cell
-    // edge) still rank in ~0.3 ms; beyond that the atomic arrival order is kept -- the only place where two runs may differ
-    // (DESIGN.md section 3), on inputs whose every neighbour search is quadratic anyway.
+    // the clouds this index is sized for.  A cluster far below the cell edge or a block of exact duplicates pays for it -- 120 k
+    // points in ONE cell rank in ~1.5 ms, 2^20 in ~0.1 s -- which is what ONE neighbour-search pass over such a cell costs as
+    // well (every query scans the whole cell).  Beyond 2^20 points in a cell the atomic arrival order is kept -- the only place
+    // where two runs may differ.  (The cut-off was 65 536 until round 4: a 120 k-point cluster of sigma =
+    // 0.002 in a unit cloud made one normal in ~10 runs differ, by an equidistant neighbour pair -- tools/dev/index_stress.py.)
     uint32_t rank;
     if (slot_is_ordered) {            // `slot` comes from a stable sort by cell: already in ascending original index
         rank = p - s;
-    } else if (e - s <= kRankQuadraticMax) {
+    } else if (e - s <= rank_max) {
         rank = 0;
         for (uint32_t j = s; j < e; ++j) rank += (slot[j] < i) ? 1u : 0u;
     } else {
@@ -346,7 +374,7 @@ __global__ void __launch_bounds__(256) place_kernel(const float *__restrict__ xy
 // than carried in a second scattered array: scattered 4-byte writes cost as much as the 16-byte ones)
 __global__ void __launch_bounds__(256) rerank_kernel(uint32_t n, GridGeom g, const IcpState *__restrict__ st, TileGeom tg, int tile_major,
                                                     uint32_t nkeys, const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tmp,
-                                                    float4 *__restrict__ pts) {
+                                                    float4 *__restrict__ pts, uint32_t rank_max) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const float4 r = tmp[p];
@@ -369,8 +397,9 @@ __global__ void __launch_bounds__(256) rerank_kernel(uint32_t n, GridGeom g, con
     const uint32_t i = __float_as_uint(r.w);
     // rank = the number of records of the cell with a smaller original index (see rank_gather_kernel for the population cut-off)
     uint32_t rank;
-    if (e - s <= kRankQuadraticMax) {
+    if (e - s <= rank_max) {
         rank = 0;
+#pragma unroll 4
         for (uint32_t j = s; j < e; ++j) rank += (__float_as_uint(tmp[j].w) < i) ? 1u : 0u;
     } else {
         rank = p - s;
@@ -475,12 +504,12 @@ static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, 
     // result stays on the device and comes back through a copy + synchronisation, as in rounds 1-3).
     const bool poll = pinned_poll_enabled();
     const bool fresh = ctx->bbox.p == nullptr;
-    if (tc_status s = ensure(ctx, ctx->bbox, 512)) return s;
-    uint32_t *d_state = (uint32_t *)ctx->bbox.p;                       // ticket | pad | 30 accumulators | (no-poll: 30 results at +256)
+    if (tc_status s = ensure(ctx, ctx->bbox, kBboxBufBytes)) return s;
+    uint32_t *d_state = (uint32_t *)ctx->bbox.p;                       // ticket | 30 accumulators, a 128-byte line each | (no-poll: 30 results behind them)
     if (fresh) hipLaunchKernelGGL(bbox_state_init_kernel, dim3(1), dim3(64), 0, st, d_state);
     float *hb = (float *)((char *)ctx->pinned + 2048);                  // [0..6) exact box, [6..30) sample boxes
     volatile uint32_t *h_done = (volatile uint32_t *)((char *)ctx->pinned + 2048 + 8192 + 192);
-    float *d_out = (float *)((char *)ctx->bbox.p + 256);
+    float *d_out = (float *)((char *)ctx->bbox.p + kBboxStateBytes + 128);
     uint32_t *d_done = nullptr;
     if (poll) {
         d_out = (float *)pinned_dev_ptr(ctx, hb);
@@ -490,7 +519,10 @@ static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, 
     }
     {
         ProfScope ps(ctx, "bbox");
-        hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, d_state, robust ? 1 : 0, d_out, d_done);
+        if (((uintptr_t)d_xyz & 15u) == 0u)
+            hipLaunchKernelGGL(bbox_kernel<true>, dim3(std::min((int)((n / 4 + 255) / 256) + 1, kBboxBlocks)), dim3(256), 0, st, d_xyz, (uint32_t)n, d_state, robust ? 1 : 0, d_out, d_done);
+        else
+            hipLaunchKernelGGL(bbox_kernel<false>, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, d_state, robust ? 1 : 0, d_out, d_done);
     }
     TC_HIP_TRY(ctx, hipGetLastError());
     if (poll) {
@@ -536,13 +568,14 @@ tc_status cloud_bbox(tc_context *ctx, const float *d_xyz, size_t n, float mn[3],
 // for 64 lanes in 64 different rows), a scattered 16-byte placement (23 us) and a re-rank pass (10 us).  On a grid that is dense in
 // the cloud's sense -- at most ~8 cells per point -- the same layout (cell-sorted, ascending original index inside a cell: bit for
 // bit the layout of the passes above) comes out of two LDS stages without a global atomic per point:
-//   bin_count / bin_offsets / bin_scan : 256 blocks walk contiguous shares of the input and count, in LDS, how many of their points
-//        fall into each BIN (a run of consecutive keys holding ~2048 points); per-(block, bin) offsets + the bins' starts;
-//   bin_scatter  : the same walk again, each record goes to its block's run inside its bin (LDS cursor: one returning LDS atomic);
+//   bin_count / bin_offsets : 256 blocks walk contiguous shares of the input and count, in LDS, how many of their points fall
+//        into each BIN (a run of consecutive keys holding ~2048 points); per-(block, bin) offsets + the bins' totals;
+//   bin_scatter  : every block scans the totals (the bins' starts), then the same walk again: each record goes to its block's run
+//        inside its bin (LDS cursor: one returning LDS atomic);
 //   bin_place    : one block per bin -- its records' keys counted in LDS, scanned (-> cell_start of the bin's keys), every record
 //        ranked inside its cell by original index (LDS), the bin written out in final order with coalesced stores.
 // A bin that does not fit a block's LDS (kBinCap records: a cloud far denser in one place than on average) sends the whole build
-// back to the atomic passes: the host reads the largest bin's population after bin_scan (one polled word).
+// back to the atomic passes: the host reads the largest bin's population (one polled word, written by block 0 of bin_scatter).
 constexpr int kBinBlocks = 256;               // blocks of the count / scatter passes
 constexpr int kBinWalkThreads = 1024;         // their threads (the walks are latency bound: 65 k threads left 15 dependent rounds each)
 #ifndef TC_BIN_TARGET
@@ -615,15 +648,24 @@ __global__ void __launch_bounds__(256) bin_offsets_kernel(uint32_t *__restrict__
     if (lane == 63u) tot[b] = inc;
 }
 
-// bin starts (exclusive scan of the totals, nbins + 1 entries), the largest bin -> the pinned host word (flag << 32 | population),
-// and the zeroed {occupied cells, ticket} pair of bin_place
-__global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *__restrict__ tot, uint32_t nbins, uint32_t *__restrict__ binstart,
-                                                       uint32_t *__restrict__ occ_ticket, unsigned long long *__restrict__ host_word) {
+// Every block first scans the bin totals itself (nbins <= 8192 words: cheaper than the 4.7 us floor of a one-block launch in
+// between, which this was until the end of round 4): bin starts = exclusive scan of the totals.  Block 0 also writes them out for
+// bin_place (nbins + 1 entries), zeroes its {occupied cells, ticket} pair and sends the largest bin to the pinned host word
+// (flag << 32 | population) -- the host decides with it whether bin_place may run (a bin must fit a block's LDS).
+__global__ void __launch_bounds__(kBinWalkThreads) bin_scatter_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g, const IcpState *__restrict__ st,
+                                                         TileGeom tg, int tile_major, uint32_t nkeys, uint32_t kpb, uint32_t nbins,
+                                                         const uint32_t *__restrict__ off /* [nbins][kBinBlocks] */,
+                                                         const uint32_t *__restrict__ tot, uint32_t *__restrict__ binstart,
+                                                         uint32_t *__restrict__ occ_ticket, unsigned long long *__restrict__ host_word,
+                                                         float4 *__restrict__ tmp) {
+    static_assert(kBinWalkThreads == 1024, "the scan below is written for 16 waves");
+    __shared__ uint32_t cur[kBinMaxBins];
     __shared__ uint32_t wtot[16], wmax[16];
     uint32_t carry = 0, mx = 0;
-    for (uint32_t base = 0; base < nbins; base += 1024) {
+    for (uint32_t base = 0; base < nbins; base += kBinWalkThreads) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < nbins ? tot[i] : 0u;
+        const uint32_t o_mine = i < nbins ? off[(size_t)i * kBinBlocks + blockIdx.x] : 0u;
         mx = max(mx, v);
         uint32_t inc = v;
 #pragma unroll
@@ -635,30 +677,27 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const uint32_t *__restri
         __syncthreads();
         uint32_t woff = 0, total = 0;
         for (int w = 0; w < 16; ++w) { if (w < (int)(threadIdx.x >> 6)) woff += wtot[w]; total += wtot[w]; }
-        if (i < nbins) binstart[i] = carry + woff + inc - v;
+        const uint32_t start = carry + woff + inc - v;
+        if (i < nbins) {
+            cur[i] = start + o_mine;
+            if (blockIdx.x == 0) binstart[i] = start;
+        }
         carry += total;
         __syncthreads();
     }
+    if (blockIdx.x == 0) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        binstart[nbins] = carry;
-        uint32_t m = 0;
-        for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
-        occ_ticket[0] = 0u; occ_ticket[1] = 0u;
-        __hip_atomic_store(host_word, (1ull << 32) | (unsigned long long)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            binstart[nbins] = carry;
+            uint32_t m = 0;
+            for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
+            occ_ticket[0] = 0u; occ_ticket[1] = 0u;
+            __hip_atomic_store(host_word, (1ull << 32) | (unsigned long long)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-}
-
-__global__ void __launch_bounds__(kBinWalkThreads) bin_scatter_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g, const IcpState *__restrict__ st,
-                                                         TileGeom tg, int tile_major, uint32_t nkeys, uint32_t kpb, uint32_t nbins,
-                                                         const uint32_t *__restrict__ off /* [nbins][kBinBlocks] */,
-                                                         const uint32_t *__restrict__ binstart, float4 *__restrict__ tmp) {
-    __shared__ uint32_t cur[kBinMaxBins];
-    for (uint32_t b = threadIdx.x; b < nbins; b += kBinWalkThreads) cur[b] = binstart[b] + off[(size_t)b * kBinBlocks + blockIdx.x];
-    __syncthreads();
     const uint32_t per = (n + kBinBlocks - 1) / kBinBlocks;
     const uint32_t i0 = blockIdx.x * per, i1 = min(i0 + per, n);
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += kBinWalkThreads) {
@@ -760,6 +799,13 @@ __global__ void __launch_bounds__(kBinPlaceThreads) bin_place_kernel(const float
     }
 }
 
+// cells up to this population are ranked by original index (quadratic in the population); TC_RANK_QUADRATIC_MAX overrides (read
+// per call: the tests lower it to reach the strict-order re-sort with a cell of a few thousand points)
+static uint32_t rank_quadratic_max() {
+    const char *e = getenv("TC_RANK_QUADRATIC_MAX");
+    return e ? (uint32_t)std::max(1, atoi(e)) : kRankQuadraticMax;
+}
+
 static bool binned_build_enabled() {          // TC_INDEX_BINNED=0: the atomic counting sort only (A/B; read per call: the tests flip it)
     const char *e = getenv("TC_INDEX_BINNED");
     return !(e && atoi(e) == 0);
@@ -777,6 +823,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     const uint32_t n32 = (uint32_t)n;
     const int nb = (int)((n + 255) / 256);
     const int dbg = debug_flags();
+    const uint32_t rank_max = rank_quadratic_max();
 
     if (reuse_geom) {
         ix.geom = *reuse_geom;
@@ -857,9 +904,8 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
                                        nbins, cnt, reinterpret_cast<uint32_t *>((float4 *)ix.pts.p + n), (uint32_t *)ix.cell_start.p, cs + nkeys + 2);
                 }
                 {
-                    ProfScope ps(ctx, "cell_bin_scan");
+                    ProfScope ps(ctx, "cell_bin_offsets");
                     hipLaunchKernelGGL(bin_offsets_kernel, dim3((nbins + 3) / 4), dim3(256), 0, st, cnt, nbins, tot);
-                    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)tot, nbins, binstart, occ_ticket, d_max);
                 }
                 if (tc_status s = ensure(ctx, ctx->build_tmp, (n + kPtsPad) * sizeof(float4))) return s;
                 // the scatter is valid whatever the bins' populations are: it runs while the host waits for the largest one (no bubble
@@ -867,7 +913,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
                 {
                     ProfScope ps(ctx, "cell_bin_scatter");
                     hipLaunchKernelGGL(bin_scatter_kernel, dim3(kBinBlocks), dim3(kBinWalkThreads), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0, nkeys,
-                                       kpb, nbins, (const uint32_t *)cnt, (const uint32_t *)binstart, (float4 *)ctx->build_tmp.p);
+                                       kpb, nbins, (const uint32_t *)cnt, (const uint32_t *)tot, binstart, occ_ticket, d_max, (float4 *)ctx->build_tmp.p);
                 }
                 TC_HIP_TRY(ctx, hipGetLastError());
                 if (tc_status s = wait_pinned_word(ctx, h_max + 1, "index build (bin populations)")) return s;
@@ -893,7 +939,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
             ProfScope ps(ctx, "cell_hist");
             hipLaunchKernelGGL(cell_hist_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0, nkeys,
                                (uint32_t *)ix.cell_of.p, (uint32_t *)ix.fill.p, (uint32_t *)ix.arrival.p,
-                               reinterpret_cast<uint32_t *>((float4 *)ix.pts.p + n), (uint32_t *)ix.cell_start.p, cs + nkeys + 2);
+                               reinterpret_cast<uint32_t *>((float4 *)ix.pts.p + n), (uint32_t *)ix.cell_start.p, cs + nkeys + 2, rank_max);
         }
         {
             ProfScope ps(ctx, "cell_scan");
@@ -913,7 +959,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
         {
             ProfScope ps(ctx, "cell_rerank");
             hipLaunchKernelGGL(rerank_kernel, dim3(nb), dim3(256), 0, st, n32, g, d_state_transform, tg, tile_major ? 1 : 0, nkeys, (const uint32_t *)cs,
-                               (const float4 *)ctx->build_tmp.p, (float4 *)ix.pts.p);
+                               (const float4 *)ctx->build_tmp.p, (float4 *)ix.pts.p, rank_max);
         }
         }
         TC_HIP_TRY(ctx, hipGetLastError());
@@ -944,7 +990,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     }
     if (strict_order) {
         // Ranks that split the cell-sorted order between them (TC_SHARD_SPATIAL, sharded normals) need the SAME order on every
-        // rank, also inside a cell of more than kRankQuadraticMax points, where rank_gather_kernel keeps the atomic arrival order:
+        // rank, also inside a cell of more than kRankQuadraticMax (2^20) points, where rerank_kernel keeps the atomic arrival order:
         // one host round trip for the flag, and -- only then -- a stable LSD radix sort of (cell, original index) replaces the
         // order (rocPRIM, the library primitive the voxel filter's sort path already uses), records gathered again.
         uint32_t *h_big = (uint32_t *)((char *)ctx->pinned + 2048 + 8192 + 64);
@@ -964,7 +1010,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
                                                       (uint32_t *)ix.slot.p, n, 0u, bits, st));
             ProfScope ps(ctx, "cell_rank_gather_strict");
             hipLaunchKernelGGL(rank_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n32, nkeys_final, (const uint32_t *)ix.cell_of.p,
-                               (const uint32_t *)cs_final, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p, 1);
+                               (const uint32_t *)cs_final, (const uint32_t *)ix.slot.p, (float4 *)ix.pts.p, 1, rank_max);
             TC_HIP_TRY(ctx, hipGetLastError());
         }
     }

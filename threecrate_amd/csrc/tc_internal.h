@@ -70,7 +70,7 @@ constexpr int kIcpBlock = 256;
 // span (4-wide steps) and 16-byte windows of cell_start without clamping
 constexpr size_t kPtsPad = 4, kCellStartPad = 4;
 constexpr size_t kCellStartFront = 4;            // zero entries in front of the prefix sums (16-byte aligned start)
-constexpr uint32_t kRankQuadraticMax = 65536u;  // cells up to this population are re-ranked by original index in O(m^2) (rank_gather_kernel)
+constexpr uint32_t kRankQuadraticMax = 1u << 20; // cells up to this population are re-ranked by original index in O(m^2) (rerank_kernel; 65536 until round 4)
 constexpr int kMaxPartialBlocks = 1024;         // plan_launch: one round of 4 blocks per CU
 // clouds from this size on get the occupancy-adapted cell edge (one host round trip + possibly a rebuild)
 constexpr uint32_t kAdaptMinPoints = 1u << 18;   // 2^17: a 230 k-point depth frame gets slower (normals 0.67 -> 0.71 ms, 10 ICP iterations 1.5 -> 2.8 ms)

@@ -30,7 +30,7 @@ def short(name):
         return f"icp_correspond_reduce_kernel<{m.group(1)}>" + (" fused" if m.group(2) in ("true", "1") else "")
     for k in ["icp_correspond_reduce_kernel<1>", "icp_correspond_reduce_kernel<0>", "icp_correspond_reduce_kernel<2>",
               "icp_refine_kernel<1>", "icp_refine_kernel<0>", "icp_refine_kernel<2>", "icp_finalize_kernel", "knn_kernel",
-              "bin_count_kernel", "bin_offsets_kernel", "bin_scan_kernel", "bin_scatter_kernel", "bin_place_kernel", "bbox_state_init_kernel", "vox_hist_kernel", "vox_scatter_kernel",
+              "bin_count_kernel", "bin_offsets_kernel", "bin_scatter_kernel", "bin_place_kernel", "bbox_state_init_kernel", "vox_hist_kernel", "vox_scatter_kernel",
               "vox_rank_kernel", "vox_flag_kernel", "vox_centroid_kernel",
               "normals_knn_pca_kernel", "normals_coop_kernel", "normals_overflow_kernel", "cell_hist_kernel", "place_kernel", "rerank_kernel", "scatter_kernel",
               "rank_gather_kernel", "scan_apply_kernel", "scan_top_kernel", "scan_reduce_kernel", "bbox_kernel",
