@@ -695,6 +695,7 @@ __global__ void __launch_bounds__(kBinWalkThreads) bin_scatter_kernel(const floa
             uint32_t m = 0;
             for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
             occ_ticket[0] = 0u; occ_ticket[1] = 0u;
+            occ_ticket[2] = m;                       // bin_place reads it: launched before the host has looked at the word below
             __hip_atomic_store(host_word, (1ull << 32) | (unsigned long long)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -723,6 +724,10 @@ __global__ void __launch_bounds__(kBinPlaceThreads) bin_place_kernel(const float
     __shared__ uint32_t wsum[kBinPlaceThreads / 64];
     __shared__ uint32_t s_occ;
     const uint32_t bin = blockIdx.x, tid = threadIdx.x;
+    // The launch is enqueued right behind the scatter pass, before the host knows the bins' populations (no bubble on the stream
+    // for its decision): when a bin does not fit a block's LDS every block leaves here, nothing written, and the host -- which
+    // reads the same number from its pinned word -- enqueues the atomic counting sort.
+    if (occ_ticket[2] > kBinCap) return;
     const uint32_t bs = binstart[bin], P = binstart[bin + 1] - bs;
     const uint32_t k0 = bin * kpb, K = min(kpb, nkeys + 1u - k0);          // this bin's keys: k0 .. k0 + K
     for (uint32_t k = tid; k < K; k += kBinPlaceThreads) cnt[k] = 0u;
@@ -908,24 +913,24 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
                     hipLaunchKernelGGL(bin_offsets_kernel, dim3((nbins + 3) / 4), dim3(256), 0, st, cnt, nbins, tot);
                 }
                 if (tc_status s = ensure(ctx, ctx->build_tmp, (n + kPtsPad) * sizeof(float4))) return s;
-                // the scatter is valid whatever the bins' populations are: it runs while the host waits for the largest one (no bubble
-                // on the stream for the decision; a build that falls back has wasted these 10 us)
+                // the scatter is valid whatever the bins' populations are (a build that falls back has wasted these 10 us)
                 {
                     ProfScope ps(ctx, "cell_bin_scatter");
                     hipLaunchKernelGGL(bin_scatter_kernel, dim3(kBinBlocks), dim3(kBinWalkThreads), 0, st, d_xyz, n32, g, d_state_transform, tg, tile_major ? 1 : 0, nkeys,
                                        kpb, nbins, (const uint32_t *)cnt, (const uint32_t *)tot, binstart, occ_ticket, d_max, (float4 *)ctx->build_tmp.p);
                 }
+                if (check) { h_occ[0] = 0u; h_occ[1] = 0u; }
+                unsigned long long *d_occ_host = check ? (unsigned long long *)pinned_dev_ptr(ctx, (const void *)h_occ) : nullptr;
+                {
+                    ProfScope ps(ctx, "cell_bin_place");
+                    hipLaunchKernelGGL(bin_place_kernel, dim3(nbins), dim3(kBinPlaceThreads), 0, st, (const float4 *)ctx->build_tmp.p, (const uint32_t *)binstart,
+                                       nbins, kpb, nkeys, g, d_state_transform, tg, tile_major ? 1 : 0, cs, (float4 *)ix.pts.p, occ_ticket,
+                                       (uint32_t *)ix.cell_start.p, d_occ_host);
+                }
                 TC_HIP_TRY(ctx, hipGetLastError());
+                // (the placement runs -- or has found out that it must not -- while the host waits for the same number)
                 if (tc_status s = wait_pinned_word(ctx, h_max + 1, "index build (bin populations)")) return s;
                 if (h_max[0] <= kBinCap) {
-                    if (check) { h_occ[0] = 0u; h_occ[1] = 0u; }
-                    unsigned long long *d_occ_host = check ? (unsigned long long *)pinned_dev_ptr(ctx, (const void *)h_occ) : nullptr;
-                    {
-                        ProfScope ps(ctx, "cell_bin_place");
-                        hipLaunchKernelGGL(bin_place_kernel, dim3(nbins), dim3(kBinPlaceThreads), 0, st, (const float4 *)ctx->build_tmp.p, (const uint32_t *)binstart,
-                                           nbins, kpb, nkeys, g, d_state_transform, tg, tile_major ? 1 : 0, cs, (float4 *)ix.pts.p, occ_ticket,
-                                           (uint32_t *)ix.cell_start.p, d_occ_host);
-                    }
                     binned_done = true;
                 } else if (dbg & 256) {
                     fprintf(stderr, "[tc] index: largest bin holds %u points (> %u): atomic counting sort\n", h_max[0], kBinCap);

@@ -1,4 +1,3 @@
-TC_HIP_LIB=$GRAFT_REPO_ROOT/threecrate_amd/variants/libthreecrate_hip_anchor.so python tools/dev/anchor_stats.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/anchor_stats.txt
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/step_trace; mkdir -p gpurun_out/step_trace
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/step_trace/t -- python3 bench.py --steps 3 --warmup 2 --no-extras --no-cpu-baseline --no-copy-probe > gpurun_out/step_trace/log.txt 2>&1
