@@ -98,19 +98,19 @@ def reference_solver_spread(nb_pts, trials=None, seed=0, query=None):
             if len(g) > 1: groups.append(g)
     if trials is None:          # (the bad summation orders can be a few per cent of all orders: sample small neighbourhoods densely)
         trials = 600 if groups else (240 if len(P) <= 12 else 96)
+        if len(P) > 128: trials = max(24, min(trials, 40000 // len(P)))       # (a radius ball of thousands of points: bounded work)
     def tie_permuted():
         idx = np.arange(len(P))
         for g in groups: idx[g] = g[rng.permutation(len(g))]
         return idx
     def cov_of(Q):
+        # normals.rs:164-177 in f32, sequential: np.add.accumulate adds one element after the other in the array's dtype (0 + q0 is
+        # exact, so starting from the first element is starting from zero); the products of np.outer are rounded to f32 one by one
         n = np.float32(len(Q))
-        cen = np.zeros(3, np.float32)
-        for q in Q: cen = (cen + q).astype(np.float32)
-        cen = (cen / n).astype(np.float32)
-        C = np.zeros((3, 3), np.float32)
-        for q in Q:
-            d = (q - cen).astype(np.float32)
-            C = (C + np.outer(d, d).astype(np.float32)).astype(np.float32)
+        Q = np.asarray(Q, np.float32)
+        cen = (np.add.accumulate(Q, axis=0, dtype=np.float32)[-1] / n).astype(np.float32)
+        d = (Q - cen).astype(np.float32)
+        C = np.add.accumulate((d[:, :, None] * d[:, None, :]).astype(np.float32), axis=0, dtype=np.float32)[-1]
         return (C / n).astype(np.float32)
     normals = [reference_normal_of_cov(cov_of(P))]
     for t in range(trials):

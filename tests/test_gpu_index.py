@@ -80,3 +80,24 @@ def test_a_cell_of_a_hundred_thousand_points_is_ordered_deterministically(ctx, m
     monkeypatch.delenv("TC_RANK_QUADRATIC_MAX")
     dev = 1.0 - np.abs((nrm.cpu().numpy()[:, 3:] * runs[0][0][:, 3:]).sum(1))
     assert (dev > 1e-4).mean() < 1e-4          # (an equidistant pair here and there may be resolved the other way)
+
+
+def test_a_cloud_that_does_not_start_on_a_16_byte_boundary(ctx):
+    """The bounding-box pass reads four points as three 16-byte loads when the cloud starts on a 16-byte boundary, point by point
+    otherwise (a view into a larger tensor: row 1 of an (n, 3) array starts 12 bytes in); both give the same box and the same
+    sample boxes, hence the same grid and the same answers."""
+    pts = synth.uniform_cloud(300_001, seed=12)
+    pts[[5, 77_000, 299_999]] = [[-3.0, 0.5, 0.5], [0.5, 4.0, 0.5], [0.5, 0.5, -2.5]]       # (outliers: the robust box's sample logic runs)
+    big = torch.from_numpy(np.concatenate([np.zeros((1, 3), np.float32), pts])).cuda()
+    view = big[1:]                                       # contiguous, 12 bytes into its allocation
+    assert view.data_ptr() % 16 != 0 and view.is_contiguous()
+    own = torch.from_numpy(pts).cuda()
+    assert own.data_ptr() % 16 == 0
+    a, b = ctx.estimate_normals(view, 10), ctx.estimate_normals(own, 10)
+    assert torch.equal(a, b)
+    src = torch.from_numpy((pts[::4] + np.float32(0.002)).astype(np.float32)).cuda()
+    ra = ctx.icp_point_to_plane_detailed(src, view, a, None, 4, None, 0.0, correspondences=True)
+    rb = ctx.icp_point_to_plane_detailed(src, own, b, None, 4, None, 0.0, correspondences=True)
+    assert np.array_equal(ra.transformation, rb.transformation) and ra.mse == rb.mse and np.array_equal(ra.correspondences, rb.correspondences)
+    va, vb = ctx.voxel_grid_filter(view, 0.05), ctx.voxel_grid_filter(own, 0.05)
+    assert torch.equal(va, vb)

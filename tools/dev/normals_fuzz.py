@@ -53,6 +53,7 @@ def explain_offender(p, i, k, radius, tree):
 def run(budget, seed, ctx, log=print, only_case=None):
     t_end = time.time() + budget
     cases = bad = explained = 0
+    most = (0, 0.0, "")            # the case with the most offenders (count, share of its points, tag): printed with the summary
     while time.time() < t_end:
         cases += 1
         if only_case is not None:
@@ -121,6 +122,7 @@ def run(budget, seed, ctx, log=print, only_case=None):
                     explained += 1
                 continue
             # every offender (a sample of 200 where ties are everywhere) through the per-point explanation
+            if len(off) > most[0]: most = (len(off), len(off) / len(p), tag)
             sample = off if len(off) <= 200 else rng.choice(off, 200, replace=False)
             tree = O.KdTree(p)
             unexplained = [(int(i_), why) for i_, (ok, why) in ((i_, explain_offender(p, int(i_), k, radius, tree)) for i_ in sample) if not ok]
@@ -131,6 +133,7 @@ def run(budget, seed, ctx, log=print, only_case=None):
         except Exception as e:
             bad += 1; log("EXCEPTION", tag, type(e).__name__, str(e)[:300])
     log(f"normals fuzz: {cases} cases, {bad} problems, {explained} with differences explained by ties / degenerate eigen-pairs")
+    if most[0]: log(f"   most offenders in one case: {most[0]} ({100 * most[1]:.1f} % of its points) -- {most[2]}")
     return cases, bad
 
 
