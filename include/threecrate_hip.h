@@ -202,8 +202,10 @@ tc_status tc_icp_point_to_plane_detailed_device(tc_context *ctx, const float *d_
  * The reference passes &PointCloud<Point3f> and rebuilds its KdTree inside every call (normals.rs:272, registration.rs:281,
  * :536).  A tc_cloud owns a device copy of the points and is indexed ONCE: tc_cloud_estimate_normals leaves the cell-sorted
  * records AND the cell-sorted normals in the handle -- the layout the ICP kernels read -- so the registration of the next frame
- * against it needs no second index build and no normals gather.  Same answers as the handle-free entry points (the cell edge
- * of the shared grid changes speed, never results).
+ * against it needs no second index build and no normals gather.  Same answers as the handle-free entry points: the cell edge
+ * of the shared grid changes speed, not results -- except where two candidates are at EXACTLY the same distance and lie in different
+ * cells (the lower position in the cell-sorted order wins, and that order belongs to the grid; the reference's own choice there is
+ * its heap's): a handful of rows per million points (tools/dev/paths_stress.py).
  *   tc_cloud_estimate_normals[_device](c, cfg, out): estimate_normals_with_config (normals.rs:257-357); out (n x 6
  *       NormalPoint3f, host / device) may be NULL when only the handle needs them (the 24-byte scattered stores are skipped).
  *   tc_cloud_set_normals_device: normals computed elsewhere (n x 3 with stride 3, or &NormalPoint3f[0].normal with stride 6).
