@@ -596,6 +596,14 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
         TC_STAMP(0);
 #pragma unroll
         for (int u = 0; u < kIcpGroup; ++u) {
+            // Wave priority by progress inside the group (round 4; s_setprio takes an immediate: u is a constant after unrolling).
+            // The launch is one round of blocks, four waves per SIMD, and under the default oldest-first arbitration they retire one
+            // after the other -- block durations p10 / p50 / max 33 / 37.5 / 46 us (TC_DEBUG=1024) -- the last ones at an occupancy
+            // that hides no latency.  A wave on its first point issues ahead of one on its fourth: 39.6 -> 38.3 us per pass, ICP
+            // alone +2.3 %, the 10 M-point sharded loop (ten groups per block) +5 % (profiles/r04_ab_wave_priority.txt; the
+            // opposite order, other level tables, priority by the share of the whole block done, a boost for the window reads:
+            // equal or worse).
+            if (u == 0) __builtin_amdgcn_s_setprio(3); else if (u == 1) __builtin_amdgcn_s_setprio(2); else if (u == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
             const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
             const bool in = fin[u];
             const float x = px[u], y = py[u], z = pz[u];
