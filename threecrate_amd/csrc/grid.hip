@@ -650,8 +650,9 @@ __global__ void __launch_bounds__(256) bin_offsets_kernel(uint32_t *__restrict__
 
 // Every block first scans the bin totals itself (nbins <= 8192 words: cheaper than the 4.7 us floor of a one-block launch in
 // between, which this was until the end of round 4): bin starts = exclusive scan of the totals.  Block 0 also writes them out for
-// bin_place (nbins + 1 entries), zeroes its {occupied cells, ticket} pair and sends the largest bin to the pinned host word
-// (flag << 32 | population) -- the host decides with it whether bin_place may run (a bin must fit a block's LDS).
+// bin_place (nbins + 1 entries), zeroes its {occupied cells, ticket} pair and publishes the largest bin's population twice: in
+// device memory for bin_place, which is enqueued right behind this kernel and leaves at once when a bin does not fit a block's
+// LDS, and in the pinned host word (flag << 32 | population), from which the host learns whether the atomic passes must follow.
 __global__ void __launch_bounds__(kBinWalkThreads) bin_scatter_kernel(const float *__restrict__ xyz, uint32_t n, GridGeom g, const IcpState *__restrict__ st,
                                                          TileGeom tg, int tile_major, uint32_t nkeys, uint32_t kpb, uint32_t nbins,
                                                          const uint32_t *__restrict__ off /* [nbins][kBinBlocks] */,
