@@ -487,8 +487,8 @@ def aux_modes(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the device-to-device copy bandwidth probe (profile runs)")
