@@ -12,8 +12,10 @@ OBJ=$ROOT/build/var_$NAME
 rm -rf "$OBJ"; mkdir -p "$OBJ" "$ROOT/threecrate_amd/variants"
 for f in api grid normals icp voxel stream comm cloud; do cp "$SRC/$f.o" "$OBJ/$f.o"; done
 pids=()
-for f in $FILES; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result $EXTRA -c "$SRC/$f.hip" -o "$OBJ/$f.o" &
+for spec in $FILES; do
+  # "icp" compiles csrc/icp.hip; "icp=/some/other/icp.hip" compiles that file in its place (e.g. an older revision: git show REV:path > file)
+  f=${spec%%=*}; src="$SRC/$f.hip"; [ "$spec" != "$f" ] && src=${spec#*=}
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result -I"$SRC" $EXTRA -c "$src" -o "$OBJ/$f.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
