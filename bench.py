@@ -290,10 +290,14 @@ def measure_sharded(ctx, dev, n, steps, warmup, plain_calls=False, world=1, rank
     th = tc.Cloud(ctx, tgt)
     th.set_normals(nrm)
 
+    # the partition is named HERE and passed down, so that the line below labels what was measured: original-index ranges for
+    # more than one rank (each rank orders ceil(n / W) points), a range of the spatially sorted source for one
+    shard = "index" if comm.size > 1 else "spatial"
+
     def step():
         if plain_calls:
-            return D.sharded_icp_point_to_plane(ctx, src, tgt, nrm, None, ICP_ITERS, None, 0.0, comm=comm, correspondences="device")
-        return D.sharded_icp_against_cloud(ctx, src, th, None, ICP_ITERS, None, 0.0, comm=comm, correspondences="device")
+            return D.sharded_icp_point_to_plane(ctx, src, tgt, nrm, None, ICP_ITERS, None, 0.0, comm=comm, correspondences="device", shard=shard)
+        return D.sharded_icp_against_cloud(ctx, src, th, None, ICP_ITERS, None, 0.0, comm=comm, correspondences="device", shard=shard)
     for _ in range(max(warmup, 1)):
         step()
     torch.cuda.synchronize()
@@ -317,8 +321,15 @@ def measure_sharded(ctx, dev, n, steps, warmup, plain_calls=False, world=1, rank
     kern = {k: round(1e3 * ms / max(c, 1), 2) for k, (c, ms) in ctx.profile_read().items()
             if k.startswith("icp_") or k.startswith("comm_")}
     ctx.profile_enable(0)
-    # the shard this rank's library call took (TC_SHARD_SPATIAL: positions [n r / W, n (r + 1) / W) of the sorted source)
-    lo, hi = n * rank // world, n * (rank + 1) // world
+    # the shard this rank's library call took: TC_SHARD_INDEX rows [r ceil(n / W), (r + 1) ceil(n / W)) of the ORIGINAL order,
+    # TC_SHARD_SPATIAL positions [n r / W, n (r + 1) / W) of the sorted source (icp_run_sharded)
+    if shard == "index":
+        rows = (n + world - 1) // world
+        lo = min(rank * rows, n); hi = min(lo + rows, n)
+    else:
+        lo, hi = n * rank // world, n * (rank + 1) // world
+    how = "by original-index range (TC_SHARD_INDEX)" if shard == "index" else "spatially (TC_SHARD_SPATIAL)"
+
     ev, ranks = rank_evidence(dist, world, rank, {"shard_points": hi - lo, "wall_s": wall, "kernels_us_avg": kern,
                                                   "n_ranks_seen_by_rccl": comm.size, "comm_rank": comm.rank}, local_rank)
     if world > 1:       # (every rank's native output before rank 0's line, see main())
@@ -327,12 +338,12 @@ def measure_sharded(ctx, dev, n, steps, warmup, plain_calls=False, world=1, rank
     err = float(np.linalg.norm(tc.isometry_to_matrix(r.transformation).astype(np.float64) - synth.isometry_matrix(T)))
     main_us = kern.get("icp_correspond_reduce_p2plane")
     it_us = 1e6 * wall / (ICP_ITERS * steps)
-    line = {"metric": "sharded point-to-plane ICP iterations/sec (one cloud, source sharded spatially, 1 ncclAllReduce/iteration in the library)",
+    line = {"metric": f"sharded point-to-plane ICP iterations/sec (one cloud, source sharded {how}, 1 ncclAllReduce/iteration in the library)",
             "value": ICP_ITERS * steps / wall, "unit": "it/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": 1e3 * wall / steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}-pt uniform cloud [0,10)x[0,10)x[0,1) (BASELINE configs[3]), 50-iter p2plane ICP, "
-                                   "source sharded spatially over the ranks, correspondences gathered",
+                                   f"source sharded {how} over the ranks, correspondences gathered", "shard_mode": shard,
                        "points": n, "parallelism": f"shard{world}",
                        "target": "rebuilt per call" if plain_calls else "tc_cloud handle (indexed once)"},
             "transform_frobenius_error_vs_truth": err, "n_correspondences": int((r.corr_target != -1).sum()),

@@ -221,7 +221,10 @@ size_t       tc_cloud_size(const tc_cloud *cloud);
 const float *tc_cloud_points_device(const tc_cloud *cloud);      /* n x 3, device */
 const float *tc_cloud_normals_device(const tc_cloud *cloud);     /* n x 6 NormalPoint3f in input order; NULL if the handle has no normals.
                                                                   * Only the host-output estimate keeps that copy; otherwise it is made from the
-                                                                  * cell-sorted normals by this call (one kernel + a stream synchronisation). */
+                                                                  * cell-sorted normals by this call (one kernel + a stream synchronisation):
+                                                                  * despite the const handle the call then allocates, launches and waits (same
+                                                                  * thread rule as every other call on the context), and NULL means failure with
+                                                                  * the reason in tc_last_error_message; "no normals" leaves the message alone. */
 tc_status    tc_cloud_estimate_normals(tc_cloud *cloud, const tc_normal_config *config, float *out_normal_points);
 tc_status    tc_cloud_estimate_normals_device(tc_cloud *cloud, const tc_normal_config *config, float *d_out_normal_points);
 tc_status    tc_cloud_set_normals_device(tc_cloud *cloud, const float *d_normals, size_t n_normals, size_t normal_stride);

@@ -235,3 +235,24 @@ def test_two_level_cell_scan_gives_the_same_index(ctx, monkeypatch):
     monkeypatch.delenv("TC_SCAN_FUSED_MAX")
     assert np.array_equal(a_n, b_n) and np.array_equal(a_v, b_v)
     assert np.array_equal(a_i.transformation, b_i.transformation) and a_i.mse == b_i.mse and np.array_equal(a_i.correspondences, b_i.correspondences)
+
+
+def test_copy_and_synchronise_fallback_of_the_pinned_words(ctx, monkeypatch):
+    """TC_NO_PINNED_POLL=1 (read per call since round 5) sends the bounding box, the index build's occupancy word and
+    the ICP state back through copies + stream synchronisations instead of polled pinned words.  Normals (a 300 k-point cloud: the
+    occupancy read-back of the edge adaptation runs), a registration and the voxel filter must come out bit for bit the same."""
+    src, tgt, T = synth.registration_pair(300000, seed=11, noise_sigma=1e-4)
+    a_n = ctx.estimate_normals(tgt, 16)
+    a_i = ctx.icp_point_to_plane_detailed(src, tgt, a_n, None, 12, None, 0.0)
+    a_p = ctx.icp_detailed(src, tgt, None, 5, None, 0.0)
+    a_v = ctx.voxel_grid_filter(tgt, 0.03)
+    monkeypatch.setenv("TC_NO_PINNED_POLL", "1")
+    b_n = ctx.estimate_normals(tgt, 16)
+    b_i = ctx.icp_point_to_plane_detailed(src, tgt, b_n, None, 12, None, 0.0)
+    b_p = ctx.icp_detailed(src, tgt, None, 5, None, 0.0)
+    b_v = ctx.voxel_grid_filter(tgt, 0.03)
+    monkeypatch.delenv("TC_NO_PINNED_POLL")
+    assert np.array_equal(a_n, b_n) and np.array_equal(a_v, b_v)
+    for a, b in ((a_i, b_i), (a_p, b_p)):
+        assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse and a.iterations == b.iterations
+        assert np.array_equal(a.correspondences, b.correspondences)

@@ -523,10 +523,19 @@ class GpuContext:
 def _hip_memcpy_dtoh(dst, src, nbytes):
     """hipMemcpy(dst, src, nbytes, hipMemcpyDeviceToHost) through the HIP runtime the library is bound to (already in the process'
     global namespace: _lib._preload_hip_runtime / the library's own NEEDED entry) -- never a second copy of the runtime"""
-    rt = C.CDLL(None)
+    fn = None
     try:
-        fn = rt.hipMemcpy
+        fn = C.CDLL(None).hipMemcpy
     except AttributeError:
+        # the runtime was loaded without RTLD_GLOBAL (no torch preload: it came in as the library's own NEEDED entry): take the
+        # copy that is ALREADY in the process by its soname -- RTLD_NOLOAD never loads a second one
+        for name in ("libamdhip64.so.7", "libamdhip64.so"):
+            try:
+                fn = C.CDLL(name, mode=os.RTLD_NOLOAD | os.RTLD_NOW).hipMemcpy
+                break
+            except (OSError, AttributeError):
+                continue
+    if fn is None:
         return -1
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     fn.restype = C.c_int

@@ -3,11 +3,13 @@
 // compute entry point needs a HIP device and returns TC_GPU otherwise.
 #include "tc_internal.h"
 #include <sched.h>
+#include <time.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 
 namespace tc {
@@ -18,8 +20,34 @@ int debug_flags() {
 }
 
 tc_status fail(tc_context *ctx, tc_status st, const std::string &msg) {
+    fault_point("fail");
     if (ctx) ctx->last_error = msg;
     return st;
+}
+
+// The handlers of the C ABI's function-try-blocks (TC_CATCH_STATUS): must not throw themselves.  The context's message buffer is
+// reserved at creation (256 bytes), so that storing a short message allocates nothing; if even that fails the old message stays.
+tc_status fail_nothrow(tc_context *ctx, tc_status st, const char *msg) noexcept {
+    if (ctx) {
+        try { ctx->last_error.assign(msg ? msg : "", std::min<size_t>(msg ? std::strlen(msg) : 0, 240)); } catch (...) { }
+    }
+    return st;
+}
+
+// Fault injection for the tests of those handlers (tests/test_abi_exceptions.py): TC_FAULT=<site>[,<site>...] makes the named sites
+// throw std::bad_alloc -- "fail" (every error return that builds a message), "context" (tc_context_create), "batch_thread" (the
+// second worker of tc_batch_icp fails to start), "stream_worker" (the frame streamer's thread body), "kitti" (tc_read_kitti_bin).
+// Read per call: a test sets it after the library has been loaded.
+void fault_point(const char *site) {
+    const char *e = getenv("TC_FAULT");
+    if (!e || !*e) return;
+    const size_t n = std::strlen(site);
+    for (const char *p = e; *p;) {
+        const char *q = std::strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : std::strlen(p);
+        if (len == n && std::strncmp(p, site, n) == 0) throw std::bad_alloc();
+        p = q ? q + 1 : p + len;
+    }
 }
 
 // The pool parks what destroyed handles give back so that a handle per frame costs no hipMalloc.  Its cap follows the blocks it has
@@ -102,8 +130,9 @@ ProfScope::~ProfScope() {
 }
 
 bool pinned_poll_enabled() {
-    static const bool on = [] { const char *e = getenv("TC_NO_PINNED_POLL"); return !(e && atoi(e) != 0); }();
-    return on;
+    // (read per call like the other switches: a test or tools/dev/paths_stress.py sets it after the library has already run)
+    const char *e = getenv("TC_NO_PINNED_POLL");
+    return !(e && atoi(e) != 0);
 }
 
 void *pinned_dev_ptr(tc_context *ctx, const void *host_addr) {
@@ -115,14 +144,38 @@ void *pinned_dev_ptr(tc_context *ctx, const void *host_addr) {
     return (char *)ctx->pinned_dev + ((const char *)host_addr - (const char *)ctx->pinned);
 }
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    sched_yield();
+#endif
+}
+
+// Three regimes: the words that arrive within a kernel or two (bounding box, occupancy: ~10-100 us) are caught spinning; a wait
+// that outlasts ~4 k spins yields the core between looks (the ranks of one host share its cores with each other and with
+// RCCL's proxy threads); a wait of more than ~2 ms -- the tail of a long registration -- sleeps 50 us between looks instead of
+// keeping a core busy for tens of milliseconds (the overshoot is noise at that length).
 tc_status wait_pinned_word(tc_context *ctx, volatile uint32_t *word, const char *what) {
+    struct timespec t0 = {0, 0};
+    bool sleeping = false;
     for (unsigned spins = 0; *word == 0u; ++spins) {
         if ((spins & 1023u) == 1023u) {
             const hipError_t q = hipStreamQuery(ctx->stream);
             if (q == hipSuccess) { if (*word == 0u) return fail(ctx, TC_GPU, std::string("internal error: ") + what + ": the stream drained without the word being written"); break; }
             if (q != hipErrorNotReady) return fail(ctx, TC_GPU, std::string(what) + ": " + hipGetErrorString(q));
+            if (!sleeping && spins >= 4096u) {
+                struct timespec t;
+                clock_gettime(CLOCK_MONOTONIC, &t);
+                if (t0.tv_sec == 0 && t0.tv_nsec == 0) t0 = t;
+                sleeping = (t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec) > 2000000ll;
+            }
         }
-        if (spins > 4096u) sched_yield(); else __builtin_ia32_pause();       // (a long wait gives the core away: ranks share the host's quota)
+        if (sleeping) { const struct timespec d = {0, 50000}; nanosleep(&d, nullptr); }
+        else if (spins > 4096u) sched_yield();
+        else cpu_relax();
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return TC_OK;
@@ -239,42 +292,44 @@ extern "C" {
 
 int tc_abi_version(void) { return TC_ABI_VERSION; }
 
-int tc_device_count(void) {
+int tc_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} TC_CATCH_VALUE(0)
 
 static tc_status context_create(int device, void *stream, bool own, tc_context **out) {
     if (!out) return TC_INVALID_DATA;
     *out = nullptr;
+    fault_point("context");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return TC_GPU;
     if (hipSetDevice(device) != hipSuccess) return TC_GPU;
-    tc_context *ctx = new tc_context();
+    std::unique_ptr<tc_context> holder(new tc_context());          // (an exception below must not leak it)
+    tc_context *ctx = holder.get();
+    ctx->last_error.reserve(256);          // fail_nothrow stores its messages without allocating
     ctx->device = device;
     ctx->own_stream = own;
     if (own) {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return TC_GPU; }
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return TC_GPU;
     } else {
         ctx->stream = (hipStream_t)stream;
     }
     ctx->pinned_cap = 1 << 16;
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_cap, hipHostMallocDefault) != hipSuccess) {
         if (own) (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
         return TC_GPU;
     }
-    *out = ctx;
+    *out = holder.release();
     return TC_OK;
 }
 
-tc_status tc_context_create(int device, tc_context **out) { return context_create(device, nullptr, true, out); }
-tc_status tc_context_create_on_stream(int device, void *hip_stream, tc_context **out) {
+tc_status tc_context_create(int device, tc_context **out) try { return context_create(device, nullptr, true, out); } TC_CATCH_STATUS(nullptr)
+tc_status tc_context_create_on_stream(int device, void *hip_stream, tc_context **out) try {
     return context_create(device, hip_stream, false, out);
-}
+} TC_CATCH_STATUS(nullptr)
 
-tc_status tc_context_wait_stream(tc_context *ctx, void *other_hip_stream) {
+tc_status tc_context_wait_stream(tc_context *ctx, void *other_hip_stream) try {
     if (!ctx) return TC_INVALID_DATA;
     hipStream_t other = (hipStream_t)other_hip_stream;
     if (other == ctx->stream) return TC_OK;
@@ -283,11 +338,11 @@ tc_status tc_context_wait_stream(tc_context *ctx, void *other_hip_stream) {
     TC_HIP_TRY(ctx, hipEventRecord(ctx->order_event, other));
     TC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->order_event, 0));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 // the other direction: work enqueued on `other` AFTER this call waits for everything the context's stream holds now (a caller that
 // is about to overwrite or free a buffer it just handed to tc_cloud_upload_device: no host wait)
-tc_status tc_stream_wait_context(tc_context *ctx, void *other_hip_stream) {
+tc_status tc_stream_wait_context(tc_context *ctx, void *other_hip_stream) try {
     if (!ctx) return TC_INVALID_DATA;
     hipStream_t other = (hipStream_t)other_hip_stream;
     if (other == ctx->stream) return TC_OK;
@@ -296,9 +351,9 @@ tc_status tc_stream_wait_context(tc_context *ctx, void *other_hip_stream) {
     TC_HIP_TRY(ctx, hipEventRecord(ctx->release_event, ctx->stream));
     TC_HIP_TRY(ctx, hipStreamWaitEvent(other, ctx->release_event, 0));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
-void tc_context_destroy(tc_context *ctx) {
+void tc_context_destroy(tc_context *ctx) try {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -316,9 +371,9 @@ void tc_context_destroy(tc_context *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
-}
+} TC_CATCH_VOID
 
-tc_status tc_context_trim(tc_context *ctx) {
+tc_status tc_context_trim(tc_context *ctx) try {
     if (!ctx) return TC_INVALID_DATA;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -327,24 +382,24 @@ tc_status tc_context_trim(tc_context *ctx) {
     ctx->pool_bytes = 0;
     ctx->pool_largest = 0;
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 const char *tc_last_error_message(const tc_context *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
-tc_status tc_synchronize(tc_context *ctx) {
+tc_status tc_synchronize(tc_context *ctx) try {
     if (!ctx) return TC_INVALID_DATA;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
-void tc_normal_config_default(tc_normal_config *cfg) {
+void tc_normal_config_default(tc_normal_config *cfg) try {
     if (!cfg) return;
     std::memset(cfg, 0, sizeof(*cfg));
     cfg->k_neighbors = 10;            // normals.rs:28-36
     cfg->has_radius = 0;
     cfg->consistent_orientation = 1;
     cfg->has_viewpoint = 0;
-}
+} TC_CATCH_VOID
 
 // ---- normals --------------------------------------------------------------------------------
 static tc_status normals_validate(tc_context *ctx, size_t n, const tc_normal_config *cfg, bool *empty) {
@@ -356,7 +411,7 @@ static tc_status normals_validate(tc_context *ctx, size_t n, const tc_normal_con
 }
 
 tc_status tc_estimate_normals_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg,
-                                     float *d_out) {
+                                     float *d_out) try {
     bool empty;
     if (tc_status s = normals_validate(ctx, n, cfg, &empty)) return s;
     if (empty) return TC_OK;
@@ -364,11 +419,11 @@ tc_status tc_estimate_normals_device(tc_context *ctx, const float *d_xyz, size_t
     if (tc_status s = normals_device(ctx, d_xyz, n, cfg, d_out)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 // ---- sharded normals of one big cloud over several GPUs ----
 tc_status tc_estimate_normals_slice_device(tc_context *ctx, const float *d_xyz, size_t n, const tc_normal_config *cfg, size_t begin,
-                                           size_t end, float *d_slice_out) {
+                                           size_t end, float *d_slice_out) try {
     bool empty;
     if (tc_status s = normals_validate(ctx, n, cfg, &empty)) return s;
     if (empty) return TC_OK;
@@ -377,9 +432,9 @@ tc_status tc_estimate_normals_slice_device(tc_context *ctx, const float *d_xyz, 
     if (tc_status s = normals_device(ctx, d_xyz, n, cfg, d_slice_out, begin, end, true)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
-tc_status tc_normals_unsort_device(tc_context *ctx, const float *d_sorted_all, size_t n, float *d_out) {
+tc_status tc_normals_unsort_device(tc_context *ctx, const float *d_sorted_all, size_t n, float *d_out) try {
     if (!ctx) return TC_INVALID_DATA;
     if (n == 0) return TC_OK;
     if (ctx->tgt_index.geom.n != n || !ctx->tgt_index.pts.p)
@@ -388,9 +443,9 @@ tc_status tc_normals_unsort_device(tc_context *ctx, const float *d_sorted_all, s
     if (tc_status s = launch_normals_unsort(ctx, ctx->tgt_index, d_sorted_all, d_out)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
-tc_status tc_estimate_normals(tc_context *ctx, const float *xyz, size_t n, const tc_normal_config *cfg, float *out) {
+tc_status tc_estimate_normals(tc_context *ctx, const float *xyz, size_t n, const tc_normal_config *cfg, float *out) try {
     bool empty;
     if (tc_status s = normals_validate(ctx, n, cfg, &empty)) return s;
     if (empty) return TC_OK;
@@ -402,7 +457,7 @@ tc_status tc_estimate_normals(tc_context *ctx, const float *xyz, size_t n, const
     TC_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out_a.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 // ---- ICP ------------------------------------------------------------------------------------
 static tc_status icp_validate(tc_context *ctx, size_t ns, size_t nt, size_t max_iters, const tc_icp_result *res) {
@@ -415,14 +470,14 @@ static tc_status icp_validate(tc_context *ctx, size_t ns, size_t nt, size_t max_
 
 tc_status tc_icp_detailed_device(tc_context *ctx, const float *d_source, size_t n_source, const float *d_target,
                                  size_t n_target, const float init[7], size_t max_iters, float max_dist, float conv_thr,
-                                 tc_icp_result *result) {
+                                 tc_icp_result *result) try {
     if (tc_status s = icp_validate(ctx, n_source, n_target, max_iters, result)) return s;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return icp_run(ctx, false, d_source, n_source, d_target, n_target, nullptr, 0, init, max_iters, max_dist, conv_thr, result, true);
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_icp_detailed(tc_context *ctx, const float *source, size_t n_source, const float *target, size_t n_target,
-                          const float init[7], size_t max_iters, float max_dist, float conv_thr, tc_icp_result *result) {
+                          const float init[7], size_t max_iters, float max_dist, float conv_thr, tc_icp_result *result) try {
     if (tc_status s = icp_validate(ctx, n_source, n_target, max_iters, result)) return s;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (tc_status s = ensure(ctx, ctx->in_a, n_source * 3 * sizeof(float))) return s;
@@ -436,18 +491,18 @@ tc_status tc_icp_detailed(tc_context *ctx, const float *source, size_t n_source,
                                  max_iters, max_dist, conv_thr, result, false);
     if (ctx->upload_pending) { ctx->upload_pending = false; (void)hipStreamSynchronize(ctx->copy_stream); }     // (an early error return)
     return rc;
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_icp_point_to_point(tc_context *ctx, const float *source, size_t n_source, const float *target, size_t n_target,
                                 const float init[7], size_t max_iterations, float conv_thr, float max_dist,
-                                tc_icp_result *result) {
+                                tc_icp_result *result) try {
     if (tc_status s = icp_validate(ctx, n_source, n_target, max_iterations, result)) return s;
     if (!(conv_thr > 0.0f)) return fail(ctx, TC_INVALID_DATA, "Convergence threshold must be positive");   // registration.rs:665-669
     return tc_icp_detailed(ctx, source, n_source, target, n_target, init, max_iterations, max_dist, conv_thr, result);
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_icp(tc_context *ctx, const float *source, size_t n_source, const float *target, size_t n_target,
-                 const float init[7], size_t max_iters, float out[7]) {
+                 const float init[7], size_t max_iters, float out[7]) try {
     if (!ctx || !out || !init) return TC_INVALID_DATA;
     tc_icp_result r;
     std::memset(&r, 0, sizeof(r));
@@ -455,7 +510,7 @@ tc_status tc_icp(tc_context *ctx, const float *source, size_t n_source, const fl
     if (s == TC_OK) std::memcpy(out, r.transformation, 7 * sizeof(float));
     else std::memcpy(out, init, 7 * sizeof(float));                                                             // :240
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 static tc_status p2plane_validate(tc_context *ctx, size_t ns, size_t nt, size_t nn, size_t stride, size_t max_iters,
                                   const tc_icp_result *res) {
@@ -471,17 +526,17 @@ static tc_status p2plane_validate(tc_context *ctx, size_t ns, size_t nt, size_t 
 tc_status tc_icp_point_to_plane_detailed_device(tc_context *ctx, const float *d_source, size_t n_source,
                                                 const float *d_target, size_t n_target, const float *d_normals,
                                                 size_t n_normals, size_t stride, const float init[7], size_t max_iters,
-                                                float max_dist, float conv_thr, tc_icp_result *result) {
+                                                float max_dist, float conv_thr, tc_icp_result *result) try {
     if (tc_status s = p2plane_validate(ctx, n_source, n_target, n_normals, stride, max_iters, result)) return s;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return icp_run(ctx, true, d_source, n_source, d_target, n_target, d_normals, stride, init, max_iters, max_dist, conv_thr,
                    result, true);
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_icp_point_to_plane_detailed(tc_context *ctx, const float *source, size_t n_source, const float *target,
                                          size_t n_target, const float *normals, size_t n_normals, size_t stride,
                                          const float init[7], size_t max_iters, float max_dist, float conv_thr,
-                                         tc_icp_result *result) {
+                                         tc_icp_result *result) try {
     if (tc_status s = p2plane_validate(ctx, n_source, n_target, n_normals, stride, max_iters, result)) return s;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t nbytes = ((n_normals - 1) * stride + 3) * sizeof(float);
@@ -498,13 +553,13 @@ tc_status tc_icp_point_to_plane_detailed(tc_context *ctx, const float *source, s
                                  (const float *)ctx->in_c.p, stride, init, max_iters, max_dist, conv_thr, result, false);
     if (ctx->upload_pending) { ctx->upload_pending = false; (void)hipStreamSynchronize(ctx->copy_stream); }     // (an early error return)
     return rc;
-}
+} TC_CATCH_STATUS(ctx)
 
 // ---- one registration / one cloud over the ranks of a communicator ----------------------------------
 tc_status tc_sharded_icp_point_to_plane_device(tc_context *ctx, tc_comm *comm, int shard_mode, const float *d_source, size_t n_source,
                                                const float *d_target, size_t n_target, const float *d_normals, size_t n_normals,
                                                size_t stride, const float init[7], size_t max_iters, float max_dist, float conv_thr,
-                                               tc_icp_result *result) {
+                                               tc_icp_result *result) try {
     if (!ctx || !comm || !result) return TC_INVALID_DATA;
     if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
     if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL && shard_mode != TC_SHARD_INDEX) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
@@ -514,11 +569,11 @@ tc_status tc_sharded_icp_point_to_plane_device(tc_context *ctx, tc_comm *comm, i
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return icp_run_sharded(ctx, comm, shard_mode, true, d_source, n_source, d_target, n_target, d_normals, stride, init, max_iters, max_dist,
                            conv_thr, result);
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_sharded_icp_detailed_device(tc_context *ctx, tc_comm *comm, int shard_mode, const float *d_source, size_t n_source,
                                          const float *d_target, size_t n_target, const float init[7], size_t max_iters, float max_dist,
-                                         float conv_thr, tc_icp_result *result) {
+                                         float conv_thr, tc_icp_result *result) try {
     if (!ctx || !comm || !result) return TC_INVALID_DATA;
     if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
     if (shard_mode != TC_SHARD_SPATIAL && shard_mode != TC_SHARD_LOCAL && shard_mode != TC_SHARD_INDEX) return fail(ctx, TC_INVALID_DATA, "unknown shard mode");
@@ -527,7 +582,7 @@ tc_status tc_sharded_icp_detailed_device(tc_context *ctx, tc_comm *comm, int sha
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return icp_run_sharded(ctx, comm, shard_mode, false, d_source, n_source, d_target, n_target, nullptr, 0, init, max_iters, max_dist,
                            conv_thr, result);
-}
+} TC_CATCH_STATUS(ctx)
 
 // this rank's slot of ceil(n / W) cell-sorted positions -> slot_out (rows x 6); the fallible part of the sharded normals
 static tc_status sharded_normals_slot(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n, const tc_normal_config *cfg,
@@ -539,7 +594,7 @@ static tc_status sharded_normals_slot(tc_context *ctx, tc_comm *comm, const floa
 }
 
 tc_status tc_sharded_estimate_normals_device(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n, const tc_normal_config *cfg,
-                                             float *d_out) {
+                                             float *d_out) try {
     if (!comm) return TC_INVALID_DATA;
     bool empty;
     if (tc_status s = normals_validate(ctx, n, cfg, &empty)) return s;
@@ -561,7 +616,7 @@ tc_status tc_sharded_estimate_normals_device(tc_context *ctx, tc_comm *comm, con
     if (tc_status s = launch_normals_unsort(ctx, ctx->tgt_index, sorted_all, d_out)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 __global__ void __launch_bounds__(256) slice_orig_index_kernel(const float4 *__restrict__ pts, uint32_t lo, uint32_t count, uint32_t *__restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,7 +624,7 @@ __global__ void __launch_bounds__(256) slice_orig_index_kernel(const float4 *__r
 }
 
 tc_status tc_sharded_estimate_normals_local_device(tc_context *ctx, tc_comm *comm, const float *d_xyz, size_t n, const tc_normal_config *cfg,
-                                                   float *d_out_slice, uint32_t *d_orig_index, size_t *first, size_t *count) {
+                                                   float *d_out_slice, uint32_t *d_orig_index, size_t *first, size_t *count) try {
     if (!comm || !first || !count) return TC_INVALID_DATA;
     *first = 0; *count = 0;
     bool empty;
@@ -587,15 +642,15 @@ tc_status tc_sharded_estimate_normals_local_device(tc_context *ctx, tc_comm *com
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *first = lo; *count = hi - lo;
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
-unsigned long long tc_debug_counter(const tc_context *ctx, int which) {
+unsigned long long tc_debug_counter(const tc_context *ctx, int which) try {
     if (!ctx) return 0;
     return which == TC_COUNTER_INDEXED_POINTS ? ctx->stat_indexed_points : which == TC_COUNTER_INDEX_BUILDS ? ctx->stat_index_builds : 0ull;
-}
+} TC_CATCH_VALUE(0)
 
 tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp_job *jobs, size_t n_jobs,
-                       tc_batch_icp_result *results) {
+                       tc_batch_icp_result *results) try {
     if (!ctxs || n_ctx == 0 || (!jobs && n_jobs) || (!results && n_jobs)) return TC_INVALID_DATA;
     static const float identity[7] = {0, 0, 0, 1, 0, 0, 0};   // gpu/icp.rs:202: always starts from identity
     auto worker = [&](size_t c) {
@@ -612,15 +667,27 @@ tc_status tc_batch_icp(tc_context *const *ctxs, size_t n_ctx, const tc_batch_icp
         }
     };
     if (n_ctx == 1) { worker(0); return TC_OK; }
+    // One thread per context.  A thread that cannot be started (std::system_error, std::bad_alloc) must not take the started ones
+    // down with it -- destroying a joinable std::thread is std::terminate --: the contexts left without a thread are served on the
+    // caller's thread, one after the other, and every started thread is joined.  (worker() itself cannot throw: it calls wrapped
+    // entry points and copies plain structs.)
     std::vector<std::thread> th;
-    for (size_t c = 0; c < n_ctx; ++c) th.emplace_back(worker, c);
+    size_t started = 0;
+    try {
+        th.reserve(n_ctx);
+        for (; started < n_ctx; ++started) {
+            if (started == 1) fault_point("batch_thread");
+            th.emplace_back(worker, started);
+        }
+    } catch (...) { }
+    for (size_t c = started; c < n_ctx; ++c) worker(c);
     for (auto &t : th) t.join();
     return TC_OK;
-}
+} TC_CATCH_STATUS(nullptr)
 
 // ---- multiscale ICP (registration.rs:704-789) ---------------------------------------------------
 tc_status tc_multiscale_icp_point_to_point(tc_context *ctx, const float *source, size_t ns, const float *target, size_t nt,
-                                           const float init[7], const tc_multiscale_icp_config *cfg, tc_icp_result *result) {
+                                           const float init[7], const tc_multiscale_icp_config *cfg, tc_icp_result *result) try {
     if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
     if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");              // :710-714
     if (cfg->n_levels == 0) return fail(ctx, TC_INVALID_DATA, "At least one ICP scale level is required");          // :715-719
@@ -681,7 +748,7 @@ tc_status tc_multiscale_icp_point_to_point(tc_context *ctx, const float *source,
     if (dcorr.p) (void)hipFree(dcorr.p);
     cleanup();
     return st;
-}
+} TC_CATCH_STATUS(ctx)
 
 // ---- KISS-ICP (kiss_icp.rs:183-300) ----------------------------------------------------------------
 // range filter -> voxel down-sampling of the source -> point-to-point ICP against the full target with the
@@ -694,7 +761,7 @@ static float kiss_adaptive_threshold(const float init[7], float voxel_size) {   
 }
 
 tc_status tc_kiss_icp_device(tc_context *ctx, const float *d_source, size_t ns, const float *d_target, size_t nt, const float init[7],
-                             const tc_kiss_icp_config *cfg, tc_icp_result *result, size_t *n_source_down) {
+                             const tc_kiss_icp_config *cfg, tc_icp_result *result, size_t *n_source_down) try {
     if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
     if (n_source_down) *n_source_down = 0;
     if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "KISS-ICP: source or target point cloud is empty");     // :189-193
@@ -715,10 +782,10 @@ tc_status tc_kiss_icp_device(tc_context *ctx, const float *d_source, size_t ns, 
     st = icp_run(ctx, false, (const float *)down.p, nd, d_target, nt, nullptr, 0, init, cfg->max_iterations, sigma, 1e-6f, result, true, 1);
     cleanup();
     return st;
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_kiss_icp(tc_context *ctx, const float *source, size_t ns, const float *target, size_t nt, const float init[7],
-                      const tc_kiss_icp_config *cfg, tc_icp_result *result, size_t *n_source_down) {
+                      const tc_kiss_icp_config *cfg, tc_icp_result *result, size_t *n_source_down) try {
     if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
     if (n_source_down) *n_source_down = 0;
     if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "KISS-ICP: source or target point cloud is empty");
@@ -742,7 +809,7 @@ tc_status tc_kiss_icp(tc_context *ctx, const float *source, size_t ns, const flo
     if (dcorr.p) (void)hipFree(dcorr.p);
     if (n_source_down) *n_source_down = nd;
     return st;
-}
+} TC_CATCH_STATUS(ctx)
 
 // ---- GICP (gicp.rs:100-305) ----------------------------------------------------------------------
 // compute_covariances (gicp.rs:52-86): the k nearest points INCLUDING the point itself (ascending distance),
@@ -792,7 +859,7 @@ static tc_status gicp_covariances_device(tc_context *ctx, const float *d_xyz, si
 }
 
 tc_status tc_gicp_device(tc_context *ctx, const float *d_source, size_t ns, const float *d_target, size_t nt, const float init[7],
-                         const tc_gicp_config *cfg, tc_icp_result *result) {
+                         const tc_gicp_config *cfg, tc_icp_result *result) try {
     if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
     if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "GICP: source or target point cloud is empty");           // :107-111
     if (cfg->max_iterations == 0) return fail(ctx, TC_INVALID_DATA, "GICP: max_iterations must be > 0");                // :112-116
@@ -817,10 +884,10 @@ tc_status tc_gicp_device(tc_context *ctx, const float *d_source, size_t ns, cons
                       cfg->max_correspondence_distance, cfg->convergence_threshold, result, true);
     cleanup();
     return st;
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_gicp(tc_context *ctx, const float *source, size_t ns, const float *target, size_t nt, const float init[7],
-                  const tc_gicp_config *cfg, tc_icp_result *result) {
+                  const tc_gicp_config *cfg, tc_icp_result *result) try {
     if (!ctx || !cfg || !result || !init) return TC_INVALID_DATA;
     if (ns == 0 || nt == 0) return fail(ctx, TC_INVALID_DATA, "GICP: source or target point cloud is empty");
     if (cfg->max_iterations == 0) return fail(ctx, TC_INVALID_DATA, "GICP: max_iterations must be > 0");
@@ -840,11 +907,11 @@ tc_status tc_gicp(tc_context *ctx, const float *source, size_t ns, const float *
     if (st == TC_OK && host_corr) (void)hipMemcpy(host_corr, dcorr.p, ns * 4, hipMemcpyDeviceToHost);
     if (dcorr.p) (void)hipFree(dcorr.p);
     return st;
-}
+} TC_CATCH_STATUS(ctx)
 
 // ---- batch k-NN (nearest_neighbor.rs:177-251; gpu/nearest_neighbor.rs:332-355) ----------------
 tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, size_t k,
-                        uint32_t *d_idx, float *d_dist, uint32_t *d_count) {
+                        uint32_t *d_idx, float *d_dist, uint32_t *d_count) try {
     if (!ctx) return TC_INVALID_DATA;
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -859,11 +926,11 @@ tc_status tc_knn_device(tc_context *ctx, const float *d_cloud, size_t n, const f
     if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k, d_idx, d_dist, d_count)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 // ---- radius search export (nearest_neighbor.rs:254-298; gpu_find_radius_neighbors gpu/nearest_neighbor.rs:357-367) ----
 tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t n, const float *d_queries, size_t nq, float radius, size_t k_max,
-                                  uint32_t *d_idx, float *d_dist, uint32_t *d_count) {
+                                  uint32_t *d_idx, float *d_dist, uint32_t *d_count) try {
     if (!ctx) return TC_INVALID_DATA;
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -878,10 +945,10 @@ tc_status tc_radius_search_device(tc_context *ctx, const float *d_cloud, size_t 
     if (tc_status s = launch_knn(ctx, ctx->tgt_index, d_queries, nq, k_max, d_idx, d_dist, d_count, radius * radius)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_radius_search(tc_context *ctx, const float *cloud, size_t n, const float *queries, size_t nq, float radius, size_t k_max,
-                           uint32_t *idx, float *dist, uint32_t *count) {
+                           uint32_t *idx, float *dist, uint32_t *count) try {
     if (!ctx) return TC_INVALID_DATA;
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -902,10 +969,10 @@ tc_status tc_radius_search(tc_context *ctx, const float *cloud, size_t n, const 
     }
     cleanup();
     return st;
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *queries, size_t nq, size_t k,
-                 uint32_t *idx, float *dist, uint32_t *count) {
+                 uint32_t *idx, float *dist, uint32_t *count) try {
     if (!ctx) return TC_INVALID_DATA;
     if (nq == 0) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -925,7 +992,7 @@ tc_status tc_knn(tc_context *ctx, const float *cloud, size_t n, const float *que
     TC_HIP_TRY(ctx, hipMemcpyAsync(count, d_cnt, nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 // ---- persistent search index: KdTree::new once, many find_k_nearest / find_radius_neighbors calls --------------
 // (threecrate-core/src/traits.rs:6-12; nearest_neighbor.rs:37-58, :177-298; Python KdTree lib.rs:707-776)
@@ -940,7 +1007,7 @@ struct tc_search_index {
 
 extern "C" {
 
-tc_status tc_search_index_create_device(tc_context *ctx, const float *d_cloud, size_t n, size_t k_hint, tc_search_index **out) {
+tc_status tc_search_index_create_device(tc_context *ctx, const float *d_cloud, size_t n, size_t k_hint, tc_search_index **out) try {
     if (!ctx || !out) return TC_INVALID_DATA;
     *out = nullptr;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -956,9 +1023,9 @@ tc_status tc_search_index_create_device(tc_context *ctx, const float *d_cloud, s
     }
     *out = s;
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
-tc_status tc_search_index_create(tc_context *ctx, const float *cloud, size_t n, size_t k_hint, tc_search_index **out) {
+tc_status tc_search_index_create(tc_context *ctx, const float *cloud, size_t n, size_t k_hint, tc_search_index **out) try {
     if (!ctx || !out) return TC_INVALID_DATA;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n) {
@@ -966,13 +1033,13 @@ tc_status tc_search_index_create(tc_context *ctx, const float *cloud, size_t n, 
         TC_HIP_TRY(ctx, hipMemcpyAsync(ctx->in_a.p, cloud, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
     return tc_search_index_create_device(ctx, (const float *)ctx->in_a.p, n, k_hint, out);   // the index holds its own sorted copy
-}
+} TC_CATCH_STATUS(ctx)
 
 size_t tc_search_index_size(const tc_search_index *s) { return s ? s->n : 0; }
 
 // radius < 0: k nearest; radius >= 0: the neighbours within radius among the k nearest
 tc_status tc_search_index_query_device(tc_search_index *s, const float *d_queries, size_t nq, size_t k, float radius,
-                                       uint32_t *d_idx, float *d_dist, uint32_t *d_count) {
+                                       uint32_t *d_idx, float *d_dist, uint32_t *d_count) try {
     if (!s) return TC_INVALID_DATA;
     tc_context *ctx = s->ctx;
     if (nq == 0) return TC_OK;
@@ -988,10 +1055,10 @@ tc_status tc_search_index_query_device(tc_search_index *s, const float *d_querie
     if (tc_status rc = launch_knn(ctx, s->ix, d_queries, nq, k, d_idx, d_dist, d_count, by_radius ? radius * radius : INFINITY)) return rc;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
 tc_status tc_search_index_query(tc_search_index *s, const float *queries, size_t nq, size_t k, float radius, uint32_t *idx, float *dist,
-                                uint32_t *count) {
+                                uint32_t *count) try {
     if (!s) return TC_INVALID_DATA;
     tc_context *ctx = s->ctx;
     if (nq == 0) return TC_OK;
@@ -1010,10 +1077,10 @@ tc_status tc_search_index_query(tc_search_index *s, const float *queries, size_t
     TC_HIP_TRY(ctx, hipMemcpyAsync(count, d_cnt, nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
 // find_radius_neighbors without a cap (nearest_neighbor.rs:254-298): count, then fill at the caller's offsets
-tc_status tc_search_index_radius_count(tc_search_index *s, const float *queries, size_t nq, float radius, uint32_t *counts) {
+tc_status tc_search_index_radius_count(tc_search_index *s, const float *queries, size_t nq, float radius, uint32_t *counts) try {
     if (!s) return TC_INVALID_DATA;
     tc_context *ctx = s->ctx;
     if (nq == 0) return TC_OK;
@@ -1027,10 +1094,10 @@ tc_status tc_search_index_radius_count(tc_search_index *s, const float *queries,
     TC_HIP_TRY(ctx, hipMemcpyAsync(counts, s->out.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
 tc_status tc_search_index_radius_fill(tc_search_index *s, const float *queries, size_t nq, float radius, const uint64_t *offsets, size_t total,
-                                      uint32_t *idx, float *dist) {
+                                      uint32_t *idx, float *dist) try {
     if (!s) return TC_INVALID_DATA;
     tc_context *ctx = s->ctx;
     if (nq == 0 || total == 0) return TC_OK;
@@ -1050,16 +1117,16 @@ tc_status tc_search_index_radius_fill(tc_search_index *s, const float *queries, 
     TC_HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, total * 4, hipMemcpyDeviceToHost, ctx->stream));
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
-void tc_search_index_destroy(tc_search_index *s) {
+void tc_search_index_destroy(tc_search_index *s) try {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     free_index(s->ix);
     free_buf(s->q); free_buf(s->out);
     delete s;
-}
+} TC_CATCH_VOID
 
 // ---- voxel_grid_filter (filtering.rs:38-133) --------------------------------------------------
 static tc_status voxel_validate(tc_context *ctx, size_t n, float voxel, size_t *n_out, bool *empty) {
@@ -1072,15 +1139,15 @@ static tc_status voxel_validate(tc_context *ctx, size_t n, float voxel, size_t *
     return TC_OK;
 }
 
-tc_status tc_voxel_grid_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float voxel_size, float *d_out, size_t *n_out) {
+tc_status tc_voxel_grid_filter_device(tc_context *ctx, const float *d_xyz, size_t n, float voxel_size, float *d_out, size_t *n_out) try {
     bool empty;
     if (tc_status s = voxel_validate(ctx, n, voxel_size, n_out, &empty)) return s;
     if (empty) return TC_OK;
     TC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return voxel_filter_device(ctx, d_xyz, n, voxel_size, d_out, n_out);
-}
+} TC_CATCH_STATUS(ctx)
 
-tc_status tc_voxel_grid_filter(tc_context *ctx, const float *xyz, size_t n, float voxel_size, float *out, size_t *n_out) {
+tc_status tc_voxel_grid_filter(tc_context *ctx, const float *xyz, size_t n, float voxel_size, float *out, size_t *n_out) try {
     bool empty;
     if (tc_status s = voxel_validate(ctx, n, voxel_size, n_out, &empty)) return s;
     if (empty) return TC_OK;
@@ -1092,7 +1159,7 @@ tc_status tc_voxel_grid_filter(tc_context *ctx, const float *xyz, size_t n, floa
     TC_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out_a.p, *n_out * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 // ---- profiling ------------------------------------------------------------------------------
 void tc_profile_enable(tc_context *ctx, int on) { if (ctx) { ctx->profiling = on; ctx->prof_tick = 0; } }
@@ -1113,13 +1180,13 @@ static void profile_collect(tc_context *ctx) {
     }
 }
 
-void tc_profile_reset(tc_context *ctx) {
+void tc_profile_reset(tc_context *ctx) try {
     if (!ctx) return;
     profile_collect(ctx);
     for (auto &t : ctx->timers) { t.launches = 0; t.total_ms = 0.0; t.min_ms = 1e300; t.max_ms = 0.0; }
-}
+} TC_CATCH_VOID
 
-size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap) {
+size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap) try {
     if (!ctx) return 0;
     profile_collect(ctx);
     size_t n = 0;
@@ -1135,6 +1202,6 @@ size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap) {
         ++n;
     }
     return n;
-}
+} TC_CATCH_VALUE(0)
 
 }  // extern "C"

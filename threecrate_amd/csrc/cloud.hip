@@ -141,7 +141,7 @@ extern "C" {
 // index, normals and inscribed-ball bounds are built once per handle, not once per call -- a map that many scans are registered
 // against).  The source is a plain device buffer, sharded as in tc_sharded_icp_point_to_plane_device.
 tc_status tc_cloud_sharded_icp(tc_comm *comm, int shard_mode, int point_to_plane, const float *d_source, size_t n_source, tc_cloud *target,
-                               const float init[7], size_t max_iters, float max_dist, float conv_thr, tc_icp_result *result) {
+                               const float init[7], size_t max_iters, float max_dist, float conv_thr, tc_icp_result *result) try {
     if (!comm || !target || !result || !init) return TC_INVALID_DATA;
     tc_context *ctx = target->ctx;
     if (comm->ctx != ctx) return fail(ctx, TC_INVALID_DATA, "the communicator belongs to another context");
@@ -155,29 +155,34 @@ tc_status tc_cloud_sharded_icp(tc_comm *comm, int shard_mode, int point_to_plane
     if (tc_status s = prepare_target(target, point_to_plane != 0)) return s;
     return icp_run_sharded(ctx, comm, shard_mode, point_to_plane != 0, d_source, n_source, (const float *)target->xyz.p, target->n, nullptr, 0, init,
                            max_iters, max_dist, conv_thr, result, &target->ix);
-}
+} TC_CATCH_STATUS((comm ? comm->ctx : nullptr))
 
-tc_status tc_cloud_upload(tc_context *ctx, const float *xyz, size_t n, tc_cloud **out) { return cloud_create(ctx, xyz, n, true, out); }
-tc_status tc_cloud_upload_device(tc_context *ctx, const float *d_xyz, size_t n, tc_cloud **out) { return cloud_create(ctx, d_xyz, n, false, out); }
+tc_status tc_cloud_upload(tc_context *ctx, const float *xyz, size_t n, tc_cloud **out) try { return cloud_create(ctx, xyz, n, true, out); } TC_CATCH_STATUS(ctx)
+tc_status tc_cloud_upload_device(tc_context *ctx, const float *d_xyz, size_t n, tc_cloud **out) try { return cloud_create(ctx, d_xyz, n, false, out); } TC_CATCH_STATUS(ctx)
 size_t tc_cloud_size(const tc_cloud *c) { return c ? c->n : 0; }
 const float *tc_cloud_points_device(const tc_cloud *c) { return c ? (const float *)c->xyz.p : nullptr; }
 // The input-order N x 6 copy is kept by the host-output variant of tc_cloud_estimate_normals; after the device-output variant,
 // a NULL output or tc_cloud_set_normals_device the handle holds the cell-sorted normals only and the copy is made here on demand.
-const float *tc_cloud_normals_device(const tc_cloud *cc) {
+const float *tc_cloud_normals_device(const tc_cloud *cc) try {
     tc_cloud *c = const_cast<tc_cloud *>(cc);
     if (!c || c->n == 0) return nullptr;
     if (c->has_normals6) return (const float *)c->normals6.p;
     if (!c->has_normals || !c->indexed) return nullptr;
+    // (From here on the call is NOT read-only despite the const handle: it allocates the input-order copy, launches a kernel on the
+    // context's stream and waits for it -- not thread-safe against other calls on the same context.  NULL then means "failed", and
+    // the context's last error says why; "the handle has no normals" returns NULL above without touching the message.)
     tc_context *ctx = c->ctx;
-    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
-    if (ensure(ctx, c->normals6, c->n * 6 * sizeof(float)) != TC_OK) return nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) { (void)fail(ctx, TC_GPU, "tc_cloud_normals_device: hipSetDevice failed"); return nullptr; }
+    if (ensure(ctx, c->normals6, c->n * 6 * sizeof(float)) != TC_OK) return nullptr;          // (ensure has set the message)
     hipLaunchKernelGGL(cloud_unsort_normals_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const float4 *)c->ix.pts.p, (const float4 *)c->ix.normals.p, (const float *)c->xyz.p, (uint32_t)c->n,
                        (float *)c->normals6.p);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)fail(ctx, TC_GPU, std::string("tc_cloud_normals_device: ") + hipGetErrorString(e)); return nullptr; }
     c->has_normals6 = true;
     return (const float *)c->normals6.p;
-}
+} TC_CATCH_VALUE(nullptr)
 
 static tc_status cloud_normals(tc_cloud *c, const tc_normal_config *cfg, float *out, bool out_on_host, bool keep6) {
     if (!c || !cfg) return TC_INVALID_DATA;
@@ -214,10 +219,10 @@ static tc_status cloud_normals(tc_cloud *c, const tc_normal_config *cfg, float *
     return TC_OK;
 }
 
-tc_status tc_cloud_estimate_normals(tc_cloud *c, const tc_normal_config *cfg, float *out) { return cloud_normals(c, cfg, out, true, false); }
-tc_status tc_cloud_estimate_normals_device(tc_cloud *c, const tc_normal_config *cfg, float *d_out) { return cloud_normals(c, cfg, d_out, false, false); }
+tc_status tc_cloud_estimate_normals(tc_cloud *c, const tc_normal_config *cfg, float *out) try { return cloud_normals(c, cfg, out, true, false); } TC_CATCH_STATUS(c ? c->ctx : nullptr)
+tc_status tc_cloud_estimate_normals_device(tc_cloud *c, const tc_normal_config *cfg, float *d_out) try { return cloud_normals(c, cfg, d_out, false, false); } TC_CATCH_STATUS(c ? c->ctx : nullptr)
 
-tc_status tc_cloud_set_normals_device(tc_cloud *c, const float *d_normals, size_t n_normals, size_t stride) {
+tc_status tc_cloud_set_normals_device(tc_cloud *c, const float *d_normals, size_t n_normals, size_t stride) try {
     if (!c) return TC_INVALID_DATA;
     tc_context *ctx = c->ctx;
     if (n_normals != c->n) return fail(ctx, TC_INVALID_DATA, "target_normals length must equal the number of target points");   // registration.rs:522-526
@@ -231,19 +236,19 @@ tc_status tc_cloud_set_normals_device(tc_cloud *c, const float *d_normals, size_
     if (tc_status s = adopt_normals(c, d_normals, stride)) return s;
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the caller's array is free on return
     return TC_OK;
-}
+} TC_CATCH_STATUS((c ? c->ctx : nullptr))
 
 tc_status tc_cloud_icp_point_to_plane(tc_cloud *source, tc_cloud *target, const float init[7], size_t max_iters, float max_dist,
-                                      float conv_thr, tc_icp_result *result) {
+                                      float conv_thr, tc_icp_result *result) try {
     return cloud_icp(source, target, true, init, max_iters, max_dist, conv_thr, result);
-}
+} TC_CATCH_STATUS((source ? source->ctx : nullptr))
 
 tc_status tc_cloud_icp_detailed(tc_cloud *source, tc_cloud *target, const float init[7], size_t max_iters, float max_dist,
-                                float conv_thr, tc_icp_result *result) {
+                                float conv_thr, tc_icp_result *result) try {
     return cloud_icp(source, target, false, init, max_iters, max_dist, conv_thr, result);
-}
+} TC_CATCH_STATUS((source ? source->ctx : nullptr))
 
-void tc_cloud_destroy(tc_cloud *c) {
+void tc_cloud_destroy(tc_cloud *c) try {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
@@ -251,6 +256,6 @@ void tc_cloud_destroy(tc_cloud *c) {
     tc::recycle(c->ctx, c->xyz); tc::recycle(c->ctx, c->normals6);
     tc::recycle_index(c->ctx, c->ix);
     delete c;
-}
+} TC_CATCH_VOID
 
 }  // extern "C"

@@ -148,7 +148,7 @@ tc_status alloc_agree_word(tc_comm *c) {
 
 extern "C" {
 
-tc_status tc_comm_unique_id(uint8_t id[TC_COMM_ID_BYTES]) {
+tc_status tc_comm_unique_id(uint8_t id[TC_COMM_ID_BYTES]) try {
     if (!id) return TC_INVALID_DATA;
     Rccl &r = rccl();
     if (!r.ok) return TC_UNSUPPORTED;
@@ -156,7 +156,7 @@ tc_status tc_comm_unique_id(uint8_t id[TC_COMM_ID_BYTES]) {
     if (r.GetUniqueId(&u) != kNcclSuccess) return TC_GPU;
     std::memcpy(id, u.internal, TC_COMM_ID_BYTES);
     return TC_OK;
-}
+} TC_CATCH_STATUS(nullptr)
 
 static tc_status comm_args(tc_context *ctx, int nranks, int rank, tc_comm **out) {
     if (!ctx || !out) return TC_INVALID_DATA;
@@ -165,7 +165,7 @@ static tc_status comm_args(tc_context *ctx, int nranks, int rank, tc_comm **out)
     return TC_OK;
 }
 
-tc_status tc_comm_create(tc_context *ctx, int nranks, int rank, const uint8_t id[TC_COMM_ID_BYTES], tc_comm **out) {
+tc_status tc_comm_create(tc_context *ctx, int nranks, int rank, const uint8_t id[TC_COMM_ID_BYTES], tc_comm **out) try {
     if (tc_status s = comm_args(ctx, nranks, rank, out)) return s;
     if (!id) return TC_INVALID_DATA;
     Rccl &r = rccl();
@@ -181,9 +181,9 @@ tc_status tc_comm_create(tc_context *ctx, int nranks, int rank, const uint8_t id
     if (tc_status s = tc::alloc_agree_word(c)) { tc_comm_destroy(c); return s; }
     *out = c;
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
-tc_status tc_comm_adopt(tc_context *ctx, void *nccl_comm, int nranks, int rank, tc_comm **out) {
+tc_status tc_comm_adopt(tc_context *ctx, void *nccl_comm, int nranks, int rank, tc_comm **out) try {
     if (tc_status s = comm_args(ctx, nranks, rank, out)) return s;
     if (!nccl_comm) return tc::fail(ctx, TC_INVALID_DATA, "communicator: null ncclComm_t");
     Rccl &r = rccl();
@@ -193,9 +193,9 @@ tc_status tc_comm_adopt(tc_context *ctx, void *nccl_comm, int nranks, int rank, 
     if (tc_status s = tc::alloc_agree_word(c)) { tc_comm_destroy(c); return s; }
     *out = c;
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
-tc_status tc_comm_create_host(tc_context *ctx, int nranks, int rank, tc_host_collective_fn fn, void *user, tc_comm **out) {
+tc_status tc_comm_create_host(tc_context *ctx, int nranks, int rank, tc_host_collective_fn fn, void *user, tc_comm **out) try {
     if (tc_status s = comm_args(ctx, nranks, rank, out)) return s;
     if (!fn && nranks > 1) return tc::fail(ctx, TC_INVALID_DATA, "communicator: a host collective callback is required for nranks > 1");
     tc_comm *c = new tc_comm();
@@ -203,14 +203,14 @@ tc_status tc_comm_create_host(tc_context *ctx, int nranks, int rank, tc_host_col
     if (tc_status s = tc::alloc_agree_word(c)) { tc_comm_destroy(c); return s; }
     *out = c;
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 tc_status tc_comm_create_local(tc_context *ctx, tc_comm **out) { return tc_comm_create_host(ctx, 1, 0, nullptr, nullptr, out); }
 
 int tc_comm_rank(const tc_comm *c) { return c ? c->rank : 0; }
 int tc_comm_size(const tc_comm *c) { return c ? c->nranks : 1; }
 
-void tc_comm_destroy(tc_comm *c) {
+void tc_comm_destroy(tc_comm *c) try {
     if (!c) return;
     if (c->nccl && c->own_nccl) {
         (void)hipSetDevice(c->ctx->device);
@@ -219,6 +219,6 @@ void tc_comm_destroy(tc_comm *c) {
     }
     if (c->agree_word) (void)hipFree(c->agree_word);
     delete c;
-}
+} TC_CATCH_VOID
 
 }  // extern "C"

@@ -587,6 +587,12 @@ constexpr int kBinWalkThreads = 1024;         // their threads (the walks are la
 constexpr uint32_t kBinTarget = TC_BIN_TARGET;          // points per bin aimed at
 constexpr uint32_t kBinCap = 2 * kBinTarget;            // records one bin_place block holds in LDS
 constexpr uint32_t kBinKeysMax = 2 * kBinTarget;        // keys (cells) per bin: one LDS counter each
+// bin_place_kernel holds cnt + rkey + ridx + slot (+ a few words) in static LDS: 64 KB and a bit -- fine on gfx950 (160 KB per CU),
+// not on a 64 KB-LDS target: this library is gfx950 only (Makefile: ARCH), say so here rather than in a linker error
+static_assert((kBinKeysMax + 3 * kBinCap) * sizeof(uint32_t) + 256 <= 160 * 1024, "bin_place_kernel's static LDS exceeds a gfx950 CU's 160 KB");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libthreecrate_hip is written for gfx950 (MI355X): bin_place_kernel alone needs more than 64 KB of LDS per workgroup"
+#endif
 constexpr uint32_t kBinMaxBins = 8192;                  // LDS counters of the count / scatter passes
 constexpr int kBinPlaceThreads = TC_BIN_PLACE_THREADS;
 
@@ -622,7 +628,7 @@ __global__ void __launch_bounds__(kBinWalkThreads) bin_count_kernel(const float 
     const uint32_t i0 = blockIdx.x * per, i1 = min(i0 + per, n);
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += kBinWalkThreads) {
         const uint32_t k = point_key(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], g, st, tg, tile_major, nkeys);
-        atomicAdd(&c[k / kpb], 1u);
+        atomicAdd(&c[min(k / kpb, nbins - 1u)], 1u);          // (k <= nkeys < nbins * kpb; the clamp only keeps a key that broke that rule inside LDS)
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbins; b += kBinWalkThreads) cnt[(size_t)b * kBinBlocks + blockIdx.x] = c[b];        // [bin][block]
@@ -708,7 +714,7 @@ __global__ void __launch_bounds__(kBinWalkThreads) bin_scatter_kernel(const floa
         const uint32_t k = point_key(r.x, r.y, r.z, g, st, tg, tile_major, nkeys);
         if (k == nkeys) r.x = r.y = r.z = __uint_as_float(0x7F7F7F7Fu);     // the non-finite bucket (see place_kernel)
         r.w = __uint_as_float(i);
-        tmp[atomicAdd(&cur[k / kpb], 1u)] = r;
+        tmp[atomicAdd(&cur[min(k / kpb, nbins - 1u)], 1u)] = r;
     }
 }
 
@@ -737,7 +743,10 @@ __global__ void __launch_bounds__(kBinPlaceThreads) bin_place_kernel(const float
     for (uint32_t i = tid; i < P; i += kBinPlaceThreads) {
         const float4 r = tmp[bs + i];
         // (the record's key is computed again from its coordinates: the placeholder of a non-finite point fails the finiteness test)
-        const uint32_t k = point_key(r.x, r.y, r.z, g, st, tg, tile_major, nkeys) - k0;
+        // (bin_count, bin_scatter and this kernel each derive the key from the coordinates with the same inlined expressions,
+        // compiled without contraction: they agree.  Should they ever not, the clamp keeps the index inside cnt[] -- a misplaced
+        // record instead of a write outside LDS; tests/test_gpu_index.py compares every product of this build with the atomic build's.)
+        const uint32_t k = min(point_key(r.x, r.y, r.z, g, st, tg, tile_major, nkeys) - k0, K - 1u);
         const uint32_t a = atomicAdd(&cnt[k], 1u);
         rkey[i] = k | (a << 16);
         ridx[i] = __float_as_uint(r.w);

@@ -2022,7 +2022,7 @@ extern "C" {
 tc_status tc_icp_shard_create(tc_context *ctx, int point_to_plane, const float *d_source_slice, size_t n_source_slice,
                               const float *d_target, size_t n_target, const float *d_target_normals, size_t normal_stride,
                               const float init[7], float max_correspondence_distance, float convergence_threshold,
-                              tc_icp_shard **out) {
+                              tc_icp_shard **out) try {
     if (!ctx || !out) return TC_INVALID_DATA;
     if (n_source_slice == 0 || n_target == 0) return tc::fail(ctx, TC_INVALID_DATA, "Source or target point cloud is empty");
     // the step-wise building blocks have no cross-rank post-loop mse recompute (registration.rs:343-361):
@@ -2034,34 +2034,34 @@ tc_status tc_icp_shard_create(tc_context *ctx, int point_to_plane, const float *
     if (rc != TC_OK) { delete s; return rc; }
     *out = s;
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
 double *tc_icp_shard_sums(tc_icp_shard *s) { return ((tc::IcpState *)s->ctx->state.p)->sums; }
 
-tc_status tc_icp_shard_get_sums(tc_icp_shard *s, double *d_out) {
+tc_status tc_icp_shard_get_sums(tc_icp_shard *s, double *d_out) try {
     tc_context *ctx = s->ctx;
     TC_HIP_TRY(ctx, hipMemcpyAsync(d_out, ((tc::IcpState *)ctx->state.p)->sums, TC_ICP_SUMS_STRIDE * sizeof(double),
                                    hipMemcpyDeviceToDevice, ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
-tc_status tc_icp_shard_set_sums(tc_icp_shard *s, const double *d_in) {
+tc_status tc_icp_shard_set_sums(tc_icp_shard *s, const double *d_in) try {
     tc_context *ctx = s->ctx;
     TC_HIP_TRY(ctx, hipMemcpyAsync(((tc::IcpState *)ctx->state.p)->sums, d_in, TC_ICP_SUMS_STRIDE * sizeof(double),
                                    hipMemcpyDeviceToDevice, ctx->stream));
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
-tc_status tc_icp_shard_done(tc_icp_shard *s, int *done) {
+tc_status tc_icp_shard_done(tc_icp_shard *s, int *done) try {
     tc_context *ctx = s->ctx;
     int32_t *h = (int32_t *)((char *)ctx->pinned + 1024);
     TC_HIP_TRY(ctx, hipMemcpyAsync(h, &((tc::IcpState *)ctx->state.p)->done, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     TC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *done = *h;
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
-tc_status tc_icp_shard_reduce(tc_icp_shard *s) {
+tc_status tc_icp_shard_reduce(tc_icp_shard *s) try {
     tc_context *ctx = s->ctx;
     uint32_t *corr = (uint32_t *)ctx->corr.p;
     tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
@@ -2069,9 +2069,9 @@ tc_status tc_icp_shard_reduce(tc_icp_shard *s) {
                          (double *)ctx->partials.p, true, false, true);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
-tc_status tc_icp_shard_apply(tc_icp_shard *s) {
+tc_status tc_icp_shard_apply(tc_icp_shard *s) try {
     tc_context *ctx = s->ctx;
     uint32_t *corr = (uint32_t *)ctx->corr.p;
     tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
@@ -2079,9 +2079,9 @@ tc_status tc_icp_shard_apply(tc_icp_shard *s) {
                          (double *)ctx->partials.p, false, true, false);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
-tc_status tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *res) {
+tc_status tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *res) try {
     tc_context *ctx = s->ctx;
     hipStream_t st = ctx->stream;
     tc::IcpState *dstate = (tc::IcpState *)ctx->state.p;
@@ -2105,7 +2105,7 @@ tc_status tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *
     res->converged = hs->converged;
     res->n_correspondences = hs->n_corr;
     return TC_OK;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
 void tc_icp_shard_destroy(tc_icp_shard *s) { delete s; }
 

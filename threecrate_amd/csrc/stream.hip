@@ -54,8 +54,28 @@ void release_slot(tc_frame_stream *s, int slot) {
     s->cv_free.notify_one();
 }
 
-// registration of consecutive frames; runs until the input is closed and drained
+void worker_body(tc_frame_stream *s);
+
+// The thread body: an exception that escaped it would be std::terminate for the whole process (the caller may be a Rust or Python
+// host).  The stream fails instead: status TC_GPU for tc_frame_stream_finish, the queue closed, the queued frames dropped
+// and every sender that waits for a slot woken (enqueue returns TC_INVALID_DATA on a closed stream).
 void worker_main(tc_frame_stream *s) {
+    try {
+        tc::fault_point("stream_worker");
+        worker_body(s);
+    } catch (...) {
+        s->worker_status = TC_GPU;
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            s->closed = true;
+            s->ready.clear();          // (noexcept; the queued frames are dropped with the stream)
+        }
+        s->cv_free.notify_all();
+    }
+}
+
+// registration of consecutive frames; runs until the input is closed and drained
+void worker_body(tc_frame_stream *s) {
     tc_context *ctx = s->ctx;
     if (hipSetDevice(ctx->device) != hipSuccess) { s->worker_status = TC_GPU; return; }
     const tc_frame_stream_config &c = s->cfg;
@@ -156,7 +176,8 @@ tc_status enqueue(tc_frame_stream *s, const float *frame, size_t n, size_t strid
                 if (accepted) *accepted = 0;
                 return TC_OK;
             }
-            s->cv_free.wait(lk, [&] { return !s->free_slots.empty(); });
+            s->cv_free.wait(lk, [&] { return !s->free_slots.empty() || s->closed; });
+            if (s->free_slots.empty()) return TC_INVALID_DATA;             // closed while waiting (finished, or the worker failed)
         }
         slot = s->free_slots.front(); s->free_slots.pop_front();
     }
@@ -182,7 +203,7 @@ tc_status enqueue(tc_frame_stream *s, const float *frame, size_t n, size_t strid
 
 extern "C" {
 
-tc_status tc_frame_stream_create(tc_context *ctx, const tc_frame_stream_config *cfg, tc_frame_stream **out) {
+tc_status tc_frame_stream_create(tc_context *ctx, const tc_frame_stream_config *cfg, tc_frame_stream **out) try {
     if (!ctx || !cfg || !out) return TC_INVALID_DATA;
     *out = nullptr;
     if (cfg->max_points == 0 || cfg->max_queue_depth == 0) return tc::fail(ctx, TC_INVALID_DATA, "max_points and max_queue_depth must be >= 1");
@@ -197,6 +218,7 @@ tc_status tc_frame_stream_create(tc_context *ctx, const tc_frame_stream_config *
         return tc::fail(ctx, TC_GPU, std::string("tc_frame_stream_create: ") + what);
     };
     const size_t bytes = cfg->max_points * 3 * sizeof(float);
+    try {          // (vector / deque growth and the thread's start can throw: the half-built stream must not leak its pinned slots)
     s->slots.resize(cfg->max_queue_depth);
     for (size_t i = 0; i < s->slots.size(); ++i) {
         if (hipHostMalloc((void **)&s->slots[i].host, bytes, hipHostMallocDefault) != hipSuccess) return bail("pinned frame slot");
@@ -209,20 +231,21 @@ tc_status tc_frame_stream_create(tc_context *ctx, const tc_frame_stream_config *
         if (hipMalloc((void **)&s->d_frame[b], bytes) != hipSuccess) return bail("device frame");
     }
     s->worker = std::thread(worker_main, s);
+    } catch (...) { tc_frame_stream_destroy(s); throw; }
     *out = s;
     return TC_OK;
-}
+} TC_CATCH_STATUS(ctx)
 
-tc_status tc_frame_stream_send(tc_frame_stream *s, const float *frame, size_t n, size_t stride_floats) {
+tc_status tc_frame_stream_send(tc_frame_stream *s, const float *frame, size_t n, size_t stride_floats) try {
     return enqueue(s, frame, n, stride_floats, true, nullptr);
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
-tc_status tc_frame_stream_try_send(tc_frame_stream *s, const float *frame, size_t n, size_t stride_floats, int *accepted) {
+tc_status tc_frame_stream_try_send(tc_frame_stream *s, const float *frame, size_t n, size_t stride_floats, int *accepted) try {
     return enqueue(s, frame, n, stride_floats, false, accepted);
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
 tc_status tc_frame_stream_finish(tc_frame_stream *s, tc_frame_result *results, size_t capacity, size_t *n_results,
-                                 tc_frame_stream_metrics *metrics) {
+                                 tc_frame_stream_metrics *metrics) try {
     if (!s) return TC_INVALID_DATA;
     {
         std::lock_guard<std::mutex> lk(s->mu);
@@ -235,9 +258,9 @@ tc_status tc_frame_stream_finish(tc_frame_stream *s, tc_frame_result *results, s
     if (n_results) *n_results = s->results.size();
     if (metrics) *metrics = s->metrics;
     return s->worker_status;
-}
+} TC_CATCH_STATUS((s ? s->ctx : nullptr))
 
-void tc_frame_stream_destroy(tc_frame_stream *s) {
+void tc_frame_stream_destroy(tc_frame_stream *s) try {
     if (!s) return;
     {
         std::lock_guard<std::mutex> lk(s->mu);
@@ -256,11 +279,12 @@ void tc_frame_stream_destroy(tc_frame_stream *s) {
     if (s->prev_h) tc_cloud_destroy(s->prev_h);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     delete s;
-}
+} TC_CATCH_VOID
 
-tc_status tc_read_kitti_bin(const char *path, float *out_xyz, size_t capacity_points, size_t *n_points) {
+tc_status tc_read_kitti_bin(const char *path, float *out_xyz, size_t capacity_points, size_t *n_points) try {
     if (!path || !n_points) return TC_INVALID_DATA;
     *n_points = 0;
+    tc::fault_point("kitti");
     FILE *f = std::fopen(path, "rb");
     if (!f) return TC_INVALID_DATA;
     if (std::fseek(f, 0, SEEK_END) != 0) { std::fclose(f); return TC_INVALID_DATA; }
@@ -282,6 +306,6 @@ tc_status tc_read_kitti_bin(const char *path, float *out_xyz, size_t capacity_po
     }
     std::fclose(f);
     return TC_OK;
-}
+} TC_CATCH_STATUS(nullptr)
 
 }   // extern "C"

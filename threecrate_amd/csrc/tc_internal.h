@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <new>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -191,6 +193,17 @@ namespace tc {
 
 // error plumbing
 tc_status fail(tc_context *ctx, tc_status st, const std::string &msg);
+tc_status fail_nothrow(tc_context *ctx, tc_status st, const char *msg) noexcept;
+void fault_point(const char *site);       // TC_FAULT: test-only fault injection (api.hip)
+// No C++ exception crosses the C ABI (threecrate-core/src/error.rs:7-28: every failure is an Error value; unwinding into a Rust or C
+// caller is undefined behaviour): every extern "C" entry point with a body that can allocate is a function-try-block closed by one
+// of these, and every thread body catches for itself.
+#define TC_CATCH_STATUS(CTX)                                                                                            \
+    catch (const std::bad_alloc &) { return tc::fail_nothrow((CTX), TC_GPU, "out of host memory"); }                    \
+    catch (const std::exception &e_) { return tc::fail_nothrow((CTX), TC_GPU, e_.what()); }                             \
+    catch (...) { return tc::fail_nothrow((CTX), TC_GPU, "unknown C++ exception"); }
+#define TC_CATCH_VOID catch (...) { }
+#define TC_CATCH_VALUE(V) catch (...) { return V; }
 #define TC_HIP_TRY(ctx, expr)                                                                  \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
