@@ -47,6 +47,28 @@ pub struct tc_icp_result {                    // ICPResult, registration.rs:13-2
 }
 
 #[repr(C)] #[derive(Clone, Copy, Debug)]
+pub struct tc_batch_icp_job {                 // BatchICPJob, threecrate-gpu/src/icp.rs:132-139 (clouds as n x 3 host floats)
+    pub source: *const f32, pub n_source: usize,
+    pub target: *const f32, pub n_target: usize,
+    pub max_iterations: usize,
+    pub convergence_threshold: f32,
+    pub max_correspondence_distance: f32,     // < 0: none
+}
+
+#[repr(C)] #[derive(Clone, Copy, Debug)]
+pub struct tc_batch_icp_result {              // BatchICPResult, threecrate-gpu/src/icp.rs:142-147 (+ the job's tc_status)
+    pub transformation: [f32; 7],
+    pub final_error: f32,
+    pub iterations: u64,
+    pub status: i32,
+}
+
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct tc_kernel_stat { pub name: [c_char; 48], pub launches: u64, pub total_ms: f64, pub min_ms: f64, pub max_ms: f64 }
+
+#[repr(C)] pub struct tc_icp_shard { _private: [u8; 0] }
+
+#[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct tc_gicp_config { pub max_iterations: usize, pub max_correspondence_distance: f32, pub convergence_threshold: f32, pub k_correspondences: usize }
 
 #[repr(C)] #[derive(Clone, Copy, Debug)]
@@ -168,4 +190,40 @@ extern "C" {
                                 target: *mut tc_cloud, init: *const f32, max_iters: usize, max_dist: f32, conv_thr: f32,
                                 res: *mut tc_icp_result) -> c_int;
     pub fn tc_cloud_destroy(cloud: *mut tc_cloud);
+    // ---- the rest of the header (device-pointer variants, batch, shard sessions, profiling): every tc_* export is declared ----
+    pub fn tc_synchronize(ctx: *mut tc_context) -> c_int;
+    pub fn tc_estimate_normals_device(ctx: *mut tc_context, d_xyz: *const f32, n: usize, cfg: *const tc_normal_config, d_out: *mut f32) -> c_int;
+    pub fn tc_icp_detailed_device(ctx: *mut tc_context, d_src: *const f32, ns: usize, d_tgt: *const f32, nt: usize, init: *const f32,
+                                  max_iters: usize, max_dist: f32, conv_thr: f32, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_icp_point_to_plane_detailed_device(ctx: *mut tc_context, d_src: *const f32, ns: usize, d_tgt: *const f32, nt: usize,
+                                                 d_normals: *const f32, n_normals: usize, stride: usize, init: *const f32, max_iters: usize,
+                                                 max_dist: f32, conv_thr: f32, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_batch_icp(ctxs: *const *mut tc_context, n_ctx: usize, jobs: *const tc_batch_icp_job, n_jobs: usize,
+                        results: *mut tc_batch_icp_result) -> c_int;
+    pub fn tc_icp_shard_create(ctx: *mut tc_context, point_to_plane: c_int, d_src_slice: *const f32, ns: usize, d_tgt: *const f32, nt: usize,
+                               d_normals: *const f32, stride: usize, init: *const f32, max_dist: f32, conv_thr: f32,
+                               out: *mut *mut tc_icp_shard) -> c_int;
+    pub fn tc_icp_shard_sums(s: *mut tc_icp_shard) -> *mut f64;
+    pub fn tc_icp_shard_reduce(s: *mut tc_icp_shard) -> c_int;
+    pub fn tc_icp_shard_get_sums(s: *mut tc_icp_shard, d_out: *mut f64) -> c_int;
+    pub fn tc_icp_shard_set_sums(s: *mut tc_icp_shard, d_in: *const f64) -> c_int;
+    pub fn tc_icp_shard_done(s: *mut tc_icp_shard, done: *mut c_int) -> c_int;
+    pub fn tc_icp_shard_apply(s: *mut tc_icp_shard) -> c_int;
+    pub fn tc_icp_shard_finish(s: *mut tc_icp_shard, max_iters: usize, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_icp_shard_destroy(s: *mut tc_icp_shard);
+    pub fn tc_gicp_device(ctx: *mut tc_context, d_src: *const f32, ns: usize, d_tgt: *const f32, nt: usize, init: *const f32,
+                          cfg: *const tc_gicp_config, res: *mut tc_icp_result) -> c_int;
+    pub fn tc_kiss_icp_device(ctx: *mut tc_context, d_src: *const f32, ns: usize, d_tgt: *const f32, nt: usize, init: *const f32,
+                              cfg: *const tc_kiss_icp_config, res: *mut tc_icp_result, n_source_down: *mut usize) -> c_int;
+    pub fn tc_knn_device(ctx: *mut tc_context, d_cloud: *const f32, n: usize, d_queries: *const f32, nq: usize, k: usize,
+                         d_idx: *mut u32, d_dist: *mut f32, d_count: *mut u32) -> c_int;
+    pub fn tc_radius_search_device(ctx: *mut tc_context, d_cloud: *const f32, n: usize, d_queries: *const f32, nq: usize, radius: f32, k_max: usize,
+                                   d_idx: *mut u32, d_dist: *mut f32, d_count: *mut u32) -> c_int;
+    pub fn tc_search_index_create_device(ctx: *mut tc_context, d_cloud: *const f32, n: usize, k_hint: usize, out: *mut *mut tc_search_index) -> c_int;
+    pub fn tc_search_index_query_device(index: *mut tc_search_index, d_queries: *const f32, nq: usize, k: usize, radius: f32,
+                                        d_idx: *mut u32, d_dist: *mut f32, d_count: *mut u32) -> c_int;
+    pub fn tc_voxel_grid_filter_device(ctx: *mut tc_context, d_xyz: *const f32, n: usize, voxel_size: f32, d_out: *mut f32, n_out: *mut usize) -> c_int;
+    pub fn tc_profile_enable(ctx: *mut tc_context, on: c_int);
+    pub fn tc_profile_reset(ctx: *mut tc_context);
+    pub fn tc_profile_read(ctx: *mut tc_context, out: *mut tc_kernel_stat, capacity: usize) -> usize;
 }

@@ -1,7 +1,10 @@
 //! threecrate-hip: the normals + ICP path of threecrate on an AMD MI355X, behind the signatures of
-//! threecrate-algorithms (`estimate_normals*`, `icp*`, `icp_point_to_plane*`, `multiscale_icp_point_to_point`,
-//! `gicp`, `kiss_icp`, `voxel_grid_filter`) and of the `threecrate-gpu` facade (`gpu_estimate_normals`, `gpu_icp`,
-//! `gpu_icp_point_to_plane`).  Every function takes a [`HipContext`] (the role `GpuContext` plays in
+//! threecrate-algorithms (`estimate_normals*`, `icp*`, `icp_point_to_point[_default]`, `icp_point_to_plane*`,
+//! `multiscale_icp_point_to_point`, `gicp`, `kiss_icp`, `voxel_grid_filter`) and of the `threecrate-gpu` facade
+//! (`gpu_estimate_normals`, `gpu_icp`, `gpu_icp_point_to_plane`, `gpu_batch_icp`, `gpu_voxel_grid_filter`,
+//! `gpu_find_k_nearest[_batch]`, `gpu_find_radius_neighbors`; the reference's are `async fn`s around a wgpu queue, these
+//! return when the result is there).  tests/test_abi_conformance.py checks that every name listed here has its `pub fn`
+//! and that ffi.rs declares every `tc_*` export of the header.  Every function takes a [`HipContext`] (the role `GpuContext` plays in
 //! threecrate-gpu: one device + one stream; not thread-safe, one context per thread / GPU).
 //!
 //! Layout facts the zero-copy calls rely on: `Point3f` = `nalgebra::Point3<f32>` is three contiguous f32
@@ -11,7 +14,7 @@ pub mod ffi;
 
 use nalgebra::{Isometry3, Quaternion, Translation3, UnitQuaternion};
 use std::ffi::CStr;
-use threecrate_algorithms::{GicpConfig, ICPResult, KissIcpConfig, NormalEstimationConfig};
+use threecrate_algorithms::{GicpConfig, ICPResult, IcpScaleLevel, KissIcpConfig, MultiScaleIcpConfig, NormalEstimationConfig};
 use threecrate_core::{Error, NearestNeighborSearch, NormalPoint3f, Point3f, PointCloud, Result, Vector3f};
 
 /// One HIP device + stream + the library's grow-only device buffers (`tc_context`).
@@ -181,6 +184,36 @@ pub fn icp_point_to_point(ctx: &HipContext, source: &PointCloud<Point3f>, target
     Ok(result_from(&r, &corr, ns))
 }
 
+/// `icp_point_to_point_default` (registration.rs:694-701): threshold 1e-6, no correspondence cut-off
+pub fn icp_point_to_point_default(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, init: Isometry3<f32>,
+                                  max_iterations: usize) -> Result<ICPResult> {
+    icp_point_to_point(ctx, source, target, init, max_iterations, 1e-6, None)
+}
+
+/// `multiscale_icp_point_to_point` (registration.rs:704-789): voxel-downsampled coarse-to-fine levels, then a final refinement on
+/// the full clouds; the levels run on the device (tc_multiscale_icp_point_to_point), validation order and messages as the reference's.
+/// A negative `Some(d)` cut-off of a level is passed through as `Some` (`f32::MIN_POSITIVE` keeps it from aliasing `None`; the level
+/// then rejects every pair like the reference does).
+pub fn multiscale_icp_point_to_point(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, init: Isometry3<f32>,
+                                     config: &MultiScaleIcpConfig) -> Result<ICPResult> {
+    let ns = source.points.len();
+    let enc = |d: Option<f32>| match d { None => -1.0f32, Some(v) if v < 0.0 => f32::MIN_POSITIVE, Some(v) => v };
+    let levels: Vec<ffi::tc_icp_scale_level> = config.levels.iter().map(|l: &IcpScaleLevel| ffi::tc_icp_scale_level {
+        voxel_size: l.voxel_size, max_iterations: l.max_iterations, max_correspondence_distance: enc(l.max_correspondence_distance),
+    }).collect();
+    let cfg = ffi::tc_multiscale_icp_config {
+        levels: levels.as_ptr(), n_levels: levels.len(),
+        final_refinement_iterations: config.final_refinement_iterations,
+        final_max_correspondence_distance: enc(config.final_max_correspondence_distance),
+        convergence_threshold: config.convergence_threshold,
+    };
+    let mut corr = vec![u32::MAX; ns.max(1)];
+    let mut r = empty_result(&mut corr);
+    let i7 = iso_to7(&init);
+    ctx.check(unsafe { ffi::tc_multiscale_icp_point_to_point(ctx.0, xyz(source), ns, xyz(target), target.points.len(), i7.as_ptr(), &cfg, &mut r) })?;
+    Ok(result_from(&r, &corr, ns))
+}
+
 /// `icp_point_to_plane_detailed` (registration.rs:508-516)
 pub fn icp_point_to_plane_detailed(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>,
                                    target_normals: &[Vector3f], init: Isometry3<f32>, max_iters: usize,
@@ -294,8 +327,11 @@ impl<'a> HipKdTree<'a> {
 }
 
 impl NearestNeighborSearch for HipKdTree<'_> {
+    /// `KdTree::find_k_nearest` (nearest_neighbor.rs:177-251): at most `len()` neighbours.  The device list holds up to 2047
+    /// entries (`TC_KNN_MAX_K`; a larger k is TC_UNSUPPORTED at the ABI): the trait returns a plain Vec, so such a request comes
+    /// back EMPTY rather than silently shortened -- use `find_k_nearest_batch`, which returns the error.
     fn find_k_nearest(&self, query: &Point3f, k: usize) -> Vec<(usize, f32)> {
-        self.query(std::slice::from_ref(query), k.min(self.len()).min(2048), -1.0).map(|mut v| v.remove(0)).unwrap_or_default()
+        self.query(std::slice::from_ref(query), k.min(self.len()), -1.0).map(|mut v| v.remove(0)).unwrap_or_default()
     }
 
     /// every neighbour within `radius`, nearest first (nearest_neighbor.rs:254-298): count, then fill
@@ -331,6 +367,95 @@ pub fn gpu_icp(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointClo
 /// `gpu_estimate_normals(&ctx, &mut cloud, k)`
 pub fn gpu_estimate_normals(ctx: &HipContext, cloud: &mut PointCloud<Point3f>, k: usize) -> Result<PointCloud<NormalPoint3f>> {
     estimate_normals(ctx, cloud, k)
+}
+
+/// `GpuPointToPlaneICPResult` (threecrate-gpu/src/icp.rs:821-828)
+#[derive(Debug, Clone)]
+pub struct GpuPointToPlaneICPResult {
+    pub transformation: Isometry3<f32>,
+    pub final_error: f32,
+    pub iterations: usize,
+    pub converged: bool,
+}
+
+/// `gpu_icp_point_to_plane(&ctx, source, target, target_normals, max_iterations, convergence_threshold,
+/// max_correspondence_distance)` (threecrate-gpu/src/icp.rs:1017-1036); starts from the identity like the reference's.
+pub fn gpu_icp_point_to_plane(ctx: &HipContext, source: &PointCloud<Point3f>, target: &PointCloud<Point3f>, target_normals: &[Vector3f],
+                              max_iterations: usize, convergence_threshold: f32, max_correspondence_distance: f32)
+    -> Result<GpuPointToPlaneICPResult> {
+    let r = icp_point_to_plane_detailed(ctx, source, target, target_normals, Isometry3::identity(), max_iterations,
+                                        Some(max_correspondence_distance), convergence_threshold)?;
+    Ok(GpuPointToPlaneICPResult { transformation: r.transformation, final_error: r.mse, iterations: r.iterations, converged: r.converged })
+}
+
+/// `BatchICPJob` (threecrate-gpu/src/icp.rs:132-139)
+#[derive(Debug, Clone)]
+pub struct BatchICPJob {
+    pub source: PointCloud<Point3f>,
+    pub target: PointCloud<Point3f>,
+    pub max_iterations: usize,
+    pub convergence_threshold: f32,
+    pub max_correspondence_distance: f32,
+}
+
+/// `BatchICPResult` (threecrate-gpu/src/icp.rs:142-147)
+#[derive(Debug, Clone)]
+pub struct BatchICPResult {
+    pub transformation: Isometry3<f32>,
+    pub final_error: f32,
+    pub iterations: usize,
+}
+
+/// `gpu_batch_icp(&ctx, &jobs)` (threecrate-gpu/src/icp.rs:997-1002, semantics :151-185): independent pairs, each from the
+/// identity.  Job i runs on `contexts[i % contexts.len()]` -- one context per GPU of the node gives one pair per GPU
+/// (tc_batch_icp: a host thread per context).  A job that fails returns its error for the whole batch, like the reference's `?`.
+pub fn gpu_batch_icp(contexts: &[&HipContext], jobs: &[BatchICPJob]) -> Result<Vec<BatchICPResult>> {
+    if contexts.is_empty() {
+        return Err(Error::InvalidData("gpu_batch_icp needs at least one context".to_string()));
+    }
+    let raw_ctx: Vec<*mut ffi::tc_context> = contexts.iter().map(|c| c.0).collect();
+    let cj: Vec<ffi::tc_batch_icp_job> = jobs.iter().map(|j| ffi::tc_batch_icp_job {
+        source: xyz(&j.source), n_source: j.source.points.len(), target: xyz(&j.target), n_target: j.target.points.len(),
+        max_iterations: j.max_iterations, convergence_threshold: j.convergence_threshold,
+        max_correspondence_distance: j.max_correspondence_distance,
+    }).collect();
+    let mut cr = vec![ffi::tc_batch_icp_result { transformation: [0.0; 7], final_error: 0.0, iterations: 0, status: ffi::TC_OK }; jobs.len()];
+    let rc = unsafe { ffi::tc_batch_icp(raw_ctx.as_ptr(), raw_ctx.len(), cj.as_ptr(), cj.len(), cr.as_mut_ptr()) };
+    if rc != ffi::TC_OK {
+        return Err(Error::InvalidData("tc_batch_icp: bad arguments".to_string()));
+    }
+    cr.iter().enumerate().map(|(i, r)| {
+        contexts[i % contexts.len()].check(r.status)?;
+        Ok(BatchICPResult { transformation: iso_from7(&r.transformation), final_error: r.final_error, iterations: r.iterations as usize })
+    }).collect()
+}
+
+/// `gpu_voxel_grid_filter(&ctx, &cloud, voxel_size)` (threecrate-gpu/src/filtering.rs:908-917) with the CPU filter's semantics
+/// (centroid per occupied voxel, filtering.rs:38-133 -- not the wgpu shader's hash-bucket "first point wins")
+pub fn gpu_voxel_grid_filter(ctx: &HipContext, cloud: &PointCloud<Point3f>, voxel_size: f32) -> Result<PointCloud<Point3f>> {
+    voxel_grid_filter(ctx, cloud, voxel_size)
+}
+
+/// `gpu_find_k_nearest(&ctx, points, &query, k)` (threecrate-gpu/src/nearest_neighbor.rs:332-342)
+pub fn gpu_find_k_nearest(ctx: &HipContext, points: &[Point3f], query: &Point3f, k: usize) -> Result<Vec<(usize, f32)>> {
+    Ok(find_k_nearest_batch(ctx, points, std::slice::from_ref(query), k)?.into_iter().next().unwrap_or_default())
+}
+
+/// `gpu_find_k_nearest_batch(&ctx, points, query_points, k)` (threecrate-gpu/src/nearest_neighbor.rs:345-355)
+pub fn gpu_find_k_nearest_batch(ctx: &HipContext, points: &[Point3f], query_points: &[Point3f], k: usize) -> Result<Vec<Vec<(usize, f32)>>> {
+    find_k_nearest_batch(ctx, points, query_points, k)
+}
+
+/// `gpu_find_radius_neighbors(&ctx, points, &query, radius)` (threecrate-gpu/src/nearest_neighbor.rs:358-367): the reference asks
+/// its kernel for the 32 nearest and keeps those within `radius`; same rule here (tc_radius_search with k_max = 32), nearest first.
+pub fn gpu_find_radius_neighbors(ctx: &HipContext, points: &[Point3f], query: &Point3f, radius: f32) -> Result<Vec<(usize, f32)>> {
+    const K_MAX: usize = 32;
+    let (mut idx, mut dist, mut cnt) = (vec![0u32; K_MAX], vec![0f32; K_MAX], [0u32; 1]);
+    ctx.check(unsafe {
+        ffi::tc_radius_search(ctx.0, points.as_ptr() as *const f32, points.len(), query as *const Point3f as *const f32, 1, radius, K_MAX,
+                              idx.as_mut_ptr(), dist.as_mut_ptr(), cnt.as_mut_ptr())
+    })?;
+    Ok((0..cnt[0] as usize).map(|j| (idx[j] as usize, dist[j])).collect())
 }
 
 

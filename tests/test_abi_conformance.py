@@ -79,7 +79,7 @@ def _rust_structs():
     """#[repr(C)] structs of the Rust shim -> {name: [(field, size, align)]} with the C layout rules for the types it uses"""
     text = open(os.path.join(ROOT, "bindings", "rust", "threecrate-hip", "src", "ffi.rs")).read()
     text = re.sub(r"//[^\n]*", "", text)
-    prim = {"u64": (8, 8), "usize": (8, 8), "i32": (4, 4), "f32": (4, 4), "u32": (4, 4), "f64": (8, 8), "u8": (1, 1)}
+    prim = {"u64": (8, 8), "usize": (8, 8), "i32": (4, 4), "f32": (4, 4), "u32": (4, 4), "f64": (8, 8), "u8": (1, 1), "c_char": (1, 1)}
     out = {}
     for m in re.finditer(r"#\[repr\(C\)\][^\n]*\n?\s*pub struct (\w+)\s*\{([^}]*)\}", text):
         fields = []
@@ -107,6 +107,39 @@ def test_rust_shim_structs_have_the_compiled_layout(exes):
             amax = max(amax, align)
         assert lay[f"sizeof.{name}"] == (off + amax - 1) // amax * amax, name
         assert len(fields) == sum(1 for k in lay if k.startswith(f"offsetof.{name}.")), name
+
+
+def test_rust_shim_covers_the_header_and_the_reference_names():
+    """Text level (no rustc in this image): ffi.rs declares EVERY tc_* export of the header -- with as many parameters --, and
+    lib.rs has a `pub fn` for every function name of threecrate-algorithms / the threecrate-gpu facade that this path replaces
+    (the shim used to stop short of gpu_icp_point_to_plane, gpu_batch_icp, multiscale_icp_point_to_point ...)."""
+    rs_dir = os.path.join(ROOT, "bindings", "rust", "threecrate-hip", "src")
+    ffi = re.sub(r"//[^\n]*", "", open(os.path.join(rs_dir, "ffi.rs")).read())
+    lib = open(os.path.join(rs_dir, "lib.rs")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "threecrate_hip.h")).read(), flags=re.S)
+
+    def nparams(args):
+        args = args.strip()
+        return 0 if args in ("", "void") else args.count(",") + 1
+    c_decl = {m.group(1): nparams(m.group(2)) for m in re.finditer(r"\b(tc_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", hdr)}
+    r_decl = {m.group(1): nparams(m.group(2)) for m in re.finditer(r"pub fn (tc_[a-z0-9_]+)\s*\(([^()]*)\)", ffi)}
+    assert sorted(c_decl) == sorted(_lib.EXPORTS)
+    assert sorted(r_decl) == sorted(c_decl), sorted(set(c_decl) ^ set(r_decl))
+    assert r_decl == c_decl, {k: (c_decl[k], r_decl[k]) for k in c_decl if c_decl[k] != r_decl[k]}
+    # the reference's names on this path: threecrate-algorithms normals.rs:238-380, registration.rs:232-789, gicp.rs:100, kiss_icp.rs:183,
+    # filtering.rs:38; threecrate-gpu lib.rs re-exports (normals.rs:443, icp.rs:977-1036, filtering.rs:908, nearest_neighbor.rs:332-367)
+    wanted = ["estimate_normals", "estimate_normals_with_config", "estimate_normals_radius", "icp", "icp_detailed", "icp_point_to_point",
+              "icp_point_to_point_default", "icp_point_to_plane", "icp_point_to_plane_detailed", "multiscale_icp_point_to_point", "gicp",
+              "kiss_icp", "voxel_grid_filter", "gpu_estimate_normals", "gpu_icp", "gpu_icp_point_to_plane", "gpu_batch_icp",
+              "gpu_voxel_grid_filter", "gpu_find_k_nearest", "gpu_find_k_nearest_batch", "gpu_find_radius_neighbors"]
+    missing = [n for n in wanted if not re.search(r"^pub fn " + n + r"\(", lib, re.M)]
+    assert not missing, missing
+    for s in ("BatchICPJob", "BatchICPResult", "GpuPointToPlaneICPResult"):
+        assert re.search(r"^pub struct " + s + r"\b", lib, re.M), s
+    assert "k.min(self.len()).min(2048)" not in lib          # (the silent clamp: the ABI's limit is 2047 and an error)
+    # every ffi:: call in lib.rs names a declared function
+    used = set(re.findall(r"ffi::(tc_[a-z0-9_]+)\(", lib))
+    assert used <= set(r_decl), used - set(r_decl)
 
 
 def _read_result(buf, pos, ns):
