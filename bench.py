@@ -717,6 +717,31 @@ def main():
                                            "avg_launch_us": 1e3 * nk[1] / max(nk[0], 1),
                                            "frac": ALG_BYTES_NORMALS * n / (1e-3 * nk[1] / max(nk[0], 1)) / 1e9 / HBM_PEAK_GBS}
             ctx.profile_enable(0)
+            if nk:
+                out["roofline"]["normals"] = dict(out["normals_roofline"], note="the normals kernel of a plain estimate_normals call on the timed cloud")
+            # ---- the secondary figures of SURVEY 8(d): one more registration of the timed pair with the main pass's COUNTING
+            # instantiation (tc_profile_enable(ctx, 3): same results, a few per cent slower, never inside the timed region) ----
+            ctx.profile_enable(3)
+            st_t, st_s = tc.Cloud(ctx, tgt), tc.Cloud(ctx, src)
+            st_t.estimate_normals(K_NORMALS, out=False)
+            rs = st_s.icp_point_to_plane(st_t, None, ICP_ITERS, None, 0.0, correspondences="device")
+            ss = ctx.search_stats()
+            ctx.profile_enable(0)
+            st_t.close(); st_s.close()
+            assert rs.iterations == ICP_ITERS and np.array_equal(rs.transformation, last.transformation) and ss["iterations"] == ICP_ITERS
+            icp_call_s = ti / args.steps                               # one timed 50-iteration call (set-up included)
+            out["search"] = {
+                "source": "one 50-iteration registration of the timed pair with the counting instantiation of the main pass (outside the timed region; same transform bit for bit)",
+                "candidates_per_query": ss["candidates_per_search"],                       # target records read per search (4 per candidate step)
+                "candidates_per_point_iteration": ss["distance_evaluations"] / (n * ICP_ITERS),
+                "searches_per_point_iteration": ss["searches"] / (n * ICP_ITERS),
+                "distance_evals_per_call": ss["distance_evaluations"] + n * ICP_ITERS,      # + the warm-start distance of every point
+                "distance_evals_per_s": (ss["distance_evaluations"] + n * ICP_ITERS) / icp_call_s,
+                "lockstep_ratio": ss["lockstep_ratio"],
+                "steps_per_search_mean": ss["steps_per_search"], "steps_per_searching_trip_slowest_lane": ss["steps_per_searching_trip"],
+                "wave_trips_without_a_search_frac": ss["wave_trips_without_a_search"] / max(ss["wave_trips"], 1),
+                "counters": {k: ss[k] for k in ("iterations", "wave_trips", "wave_trips_without_a_search", "searches", "candidate_steps_needed",
+                                                "candidate_steps_taken_by_slowest_lanes")}}
             out["main_pass_us_moving"] = steady["moving"]["mean_us_without_the_cold_first_pass"]
             out["main_pass_us_converged"] = steady["converged"]["mean_us_without_the_cold_first_pass"]
             out["main_pass_phase_detail"] = steady
@@ -779,6 +804,23 @@ def main():
                 flush_native_stdio()
                 os.dup2(saved_stdout, 1)
                 os.close(saved_stdout)
+        # every fraction of this line in one place (kernel or call, algorithmic bytes of SURVEY 8d, microseconds, fraction of 8 TB/s)
+        table = [{"what": "icp main pass (dominant kernel, in-bench events)", "alg_bytes": ALG_BYTES_ICP * n, "us": avg_s * 1e6, "frac": achieved / HBM_PEAK_GBS},
+                 {"what": "icp iteration (timed calls / iterations)", "alg_bytes": ALG_BYTES_ICP * n, "us": it_us, "frac": out["roofline"]["iteration"]["frac"]}]
+        if "normals_roofline" in out:
+            table.append({"what": "normals kernel, timed cloud", "alg_bytes": ALG_BYTES_NORMALS * n, "us": out["normals_roofline"]["avg_launch_us"], "frac": out["normals_roofline"]["frac"]})
+        tp = out.get("tum_pair", {}).get("roofline") if isinstance(out.get("tum_pair"), dict) else None
+        if tp and tp.get("normals_kernel_us"):
+            npts = out["tum_pair"]["config"]["points"]
+            table.append({"what": "normals kernel, TUM-shaped cloud (configs[2] shape)", "alg_bytes": ALG_BYTES_NORMALS * npts, "us": tp["normals_kernel_us"], "frac": tp["normals_frac"]})
+            table.append({"what": "icp main pass, TUM-shaped pair", "alg_bytes": ALG_BYTES_ICP * npts, "us": tp["main_pass_us"], "frac": tp["main_pass_frac"]})
+        sh = out.get("sharded_10m", {}).get("roofline") if isinstance(out.get("sharded_10m"), dict) else None
+        if sh and sh.get("main_pass_us"):
+            table.append({"what": "icp main pass, 10 M-point sharded entry (one rank)", "alg_bytes": sh["alg_bytes_per_iteration"], "us": sh["main_pass_us"], "frac": sh["main_pass_frac"]})
+        fsr = out.get("frame_stream", {}).get("roofline") if isinstance(out.get("frame_stream"), dict) else None
+        if fsr:
+            table.append({"what": "LiDAR frame (whole pipeline per frame)", "alg_bytes": fsr["alg_bytes_per_frame"], "us": fsr["frame_us"], "frac": fsr["frac"]})
+        out["roofline"]["table"] = table
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(n, tgt_h, src_h, nrm_last.cpu().numpy())
             out["parity"] = cb.pop("parity")

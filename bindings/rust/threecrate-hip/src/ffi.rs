@@ -14,6 +14,12 @@ pub const TC_SHARD_LOCAL: c_int = 1;
 pub const TC_SHARD_INDEX: c_int = 2;
 pub const TC_COUNTER_INDEXED_POINTS: c_int = 0;
 pub const TC_COUNTER_INDEX_BUILDS: c_int = 1;
+pub const TC_COUNTER_ICP_ITERATIONS: c_int = 2;
+pub const TC_COUNTER_ICP_TRIPS: c_int = 3;
+pub const TC_COUNTER_ICP_TRIPS_WITHOUT_SEARCH: c_int = 4;
+pub const TC_COUNTER_ICP_SEARCHES: c_int = 5;
+pub const TC_COUNTER_ICP_STEPS_NEEDED: c_int = 6;
+pub const TC_COUNTER_ICP_STEPS_TAKEN: c_int = 7;
 pub const TC_COLL_SUM_F64: c_int = 0;
 pub const TC_COLL_SUM_U32: c_int = 1;
 pub const TC_COLL_ALLGATHER_U8: c_int = 2;

@@ -347,7 +347,17 @@ tc_status tc_sharded_estimate_normals_local_device(tc_context *ctx, tc_comm *com
 
 /* Diagnostics (tests): work counters of a context since its creation.  TC_COUNTER_INDEXED_POINTS: points that went through an
  * index build (counting sort) -- the per-call set-up work of the sharded entry points, which must shrink with the rank count. */
-typedef enum tc_counter { TC_COUNTER_INDEXED_POINTS = 0, TC_COUNTER_INDEX_BUILDS = 1 } tc_counter;
+typedef enum tc_counter {
+    TC_COUNTER_INDEXED_POINTS = 0, TC_COUNTER_INDEX_BUILDS = 1,
+    /* Search statistics of the ICP main pass (SURVEY 8d's secondary figures), summed over the registrations run while the context
+     * is in profiling mode 3 (tc_profile_enable(ctx, 3) zeroes them and selects the kernel's counting instantiation -- a few per
+     * cent slower, same results; any other mode runs the product's kernel, which carries no counter):
+     * iterations executed | wave trips (64 source points each) | trips in which no lane searched (every previous match was kept) |
+     * searches (lanes that scanned the grid) | candidate steps those searches needed (4 distance evaluations each) | candidate
+     * steps the trips took = the steps of each trip's slowest lane (x 64 / steps needed = the lock-step ratio). */
+    TC_COUNTER_ICP_ITERATIONS = 2, TC_COUNTER_ICP_TRIPS = 3, TC_COUNTER_ICP_TRIPS_WITHOUT_SEARCH = 4, TC_COUNTER_ICP_SEARCHES = 5,
+    TC_COUNTER_ICP_STEPS_NEEDED = 6, TC_COUNTER_ICP_STEPS_TAKEN = 7
+} tc_counter;
 unsigned long long tc_debug_counter(const tc_context *ctx, int which);
 
 /* One registration over the ranks of a communicator (see tc_sharded_icp_point_to_plane_device) against a TARGET HANDLE: every
@@ -521,7 +531,8 @@ tc_status tc_read_kitti_bin(const char *path, float *out_xyz, size_t capacity_po
 
 /* ---- profiling ---- */
 /* on: 0 = off, 1 = hipEvents around every kernel, 2 = only around every 17th launch of the dominant
-   kernel (icp_correspond_reduce): ~1 % overhead (an event is a ~6 us bubble on the stream), used inside bench.py's timed region */
+   kernel (icp_correspond_reduce): ~1 % overhead (an event is a ~6 us bubble on the stream), used inside bench.py's timed region,
+   3 = no events; the ICP main pass counts its searches instead (tc_debug_counter, TC_COUNTER_ICP_*) */
 void   tc_profile_enable(tc_context *ctx, int on);
 void   tc_profile_reset(tc_context *ctx);
 size_t tc_profile_read(tc_context *ctx, tc_kernel_stat *out, size_t cap);

@@ -66,6 +66,8 @@ static int layout(void) {
     VAL(TC_ICP_SUMS_P2PLANE); VAL(TC_ICP_SUMS_P2P); VAL(TC_ICP_SUMS_STRIDE); VAL(TC_COMM_ID_BYTES);
     VAL(TC_COLL_SUM_F64); VAL(TC_COLL_SUM_U32); VAL(TC_COLL_ALLGATHER_U8); VAL(TC_SHARD_SPATIAL); VAL(TC_SHARD_LOCAL); VAL(TC_SHARD_INDEX);
     VAL(TC_COUNTER_INDEXED_POINTS); VAL(TC_COUNTER_INDEX_BUILDS);
+    VAL(TC_COUNTER_ICP_ITERATIONS); VAL(TC_COUNTER_ICP_TRIPS); VAL(TC_COUNTER_ICP_TRIPS_WITHOUT_SEARCH); VAL(TC_COUNTER_ICP_SEARCHES);
+    VAL(TC_COUNTER_ICP_STEPS_NEEDED); VAL(TC_COUNTER_ICP_STEPS_TAKEN);
     /* the library this program is linked against answers for itself (no device needed) */
     printf("call.tc_abi_version %d\n", tc_abi_version());
     return 0;

@@ -70,7 +70,11 @@ def test_compiled_layouts_equal_the_ctypes_mirror(exes):
                        ("TC_COLL_SUM_F64", _lib.TC_COLL_SUM_F64), ("TC_COLL_SUM_U32", _lib.TC_COLL_SUM_U32),
                        ("TC_COLL_ALLGATHER_U8", _lib.TC_COLL_ALLGATHER_U8), ("TC_SHARD_SPATIAL", _lib.TC_SHARD_SPATIAL),
                        ("TC_SHARD_LOCAL", _lib.TC_SHARD_LOCAL), ("TC_SHARD_INDEX", _lib.TC_SHARD_INDEX),
-                       ("TC_COUNTER_INDEXED_POINTS", _lib.TC_COUNTER_INDEXED_POINTS), ("TC_COUNTER_INDEX_BUILDS", _lib.TC_COUNTER_INDEX_BUILDS)):
+                       ("TC_COUNTER_INDEXED_POINTS", _lib.TC_COUNTER_INDEXED_POINTS), ("TC_COUNTER_INDEX_BUILDS", _lib.TC_COUNTER_INDEX_BUILDS),
+                       ("TC_COUNTER_ICP_ITERATIONS", _lib.TC_COUNTER_ICP_ITERATIONS), ("TC_COUNTER_ICP_TRIPS", _lib.TC_COUNTER_ICP_TRIPS),
+                       ("TC_COUNTER_ICP_TRIPS_WITHOUT_SEARCH", _lib.TC_COUNTER_ICP_TRIPS_WITHOUT_SEARCH),
+                       ("TC_COUNTER_ICP_SEARCHES", _lib.TC_COUNTER_ICP_SEARCHES), ("TC_COUNTER_ICP_STEPS_NEEDED", _lib.TC_COUNTER_ICP_STEPS_NEEDED),
+                       ("TC_COUNTER_ICP_STEPS_TAKEN", _lib.TC_COUNTER_ICP_STEPS_TAKEN)):
         assert lay[f"const.{cname}"] == val, cname
     assert lay["call.tc_abi_version"] == lay["const.TC_ABI_VERSION"] == _lib.load().tc_abi_version()
 

@@ -256,3 +256,29 @@ def test_copy_and_synchronise_fallback_of_the_pinned_words(ctx, monkeypatch):
     for a, b in ((a_i, b_i), (a_p, b_p)):
         assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse and a.iterations == b.iterations
         assert np.array_equal(a.correspondences, b.correspondences)
+
+
+def test_search_statistics_mode_counts_without_changing_the_result(ctx):
+    """tc_profile_enable(ctx, 3): the ICP main pass runs its counting instantiation (SURVEY 8d's secondary figures: candidates per
+    query, lock-step ratio); the registration itself must come out bit for bit, and the counters must add up."""
+    n, iters = 200000, 10
+    src, tgt, T = synth.registration_pair(n, seed=4, transform=synth.harness_transform(), noise_sigma=1e-4)
+    nrm = ctx.estimate_normals(tgt, 16)
+    a = ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, iters, None, 0.0)
+    ctx.profile_enable(3)
+    b = ctx.icp_point_to_plane_detailed(src, tgt, nrm, None, iters, None, 0.0)
+    s = ctx.search_stats()
+    c = ctx.icp_detailed(src, tgt, None, 3, None, 0.0)            # the counters sum over the session's calls
+    s2 = ctx.search_stats()
+    ctx.profile_enable(0)
+    assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse and np.array_equal(a.correspondences, b.correspondences)
+    trips_per_it = -(-n // 1024) * 16                                # 4 trips of each of the 4 waves of every 1024-point block
+    assert s["iterations"] == iters and abs(s["wave_trips"] - trips_per_it * iters) <= 16 * iters
+    assert n <= s["searches"] <= n * iters                            # the cold first pass searches every point
+    assert s["candidate_steps_needed"] >= s["searches"] and 1.0 <= s["lockstep_ratio"] < 10.0
+    assert s["candidate_steps_taken_by_slowest_lanes"] * 64 >= s["candidate_steps_needed"]
+    assert 4.0 <= s["candidates_per_search"] <= 200.0
+    assert s2["iterations"] == iters + 3 and s2["searches"] > s["searches"]
+    ctx.profile_enable(3)                                             # a new session starts from zero
+    assert ctx.search_stats()["searches"] == 0
+    ctx.profile_enable(0)

@@ -15,6 +15,8 @@ TC_COMM_ID_BYTES = 128
 TC_COLL_SUM_F64, TC_COLL_SUM_U32, TC_COLL_ALLGATHER_U8 = 0, 1, 2
 TC_SHARD_SPATIAL, TC_SHARD_LOCAL, TC_SHARD_INDEX = 0, 1, 2
 TC_COUNTER_INDEXED_POINTS, TC_COUNTER_INDEX_BUILDS = 0, 1
+(TC_COUNTER_ICP_ITERATIONS, TC_COUNTER_ICP_TRIPS, TC_COUNTER_ICP_TRIPS_WITHOUT_SEARCH, TC_COUNTER_ICP_SEARCHES, TC_COUNTER_ICP_STEPS_NEEDED,
+ TC_COUNTER_ICP_STEPS_TAKEN) = 2, 3, 4, 5, 6, 7
 # int (*tc_host_collective_fn)(void *user, int op, void *host_buf, size_t count)
 HOST_COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 SUMS_P2PLANE, SUMS_P2P, SUMS_STRIDE = 29, 17, 32

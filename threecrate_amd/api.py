@@ -207,7 +207,8 @@ class GpuContext:
 
     # ---- profiling ----
     def profile_enable(self, on=True):
-        """False/0 off, True/1 every kernel, 2 = sampled events on the dominant kernel only."""
+        """False/0 off, True/1 every kernel, 2 = sampled events on the dominant kernel only, 3 = no events: the ICP main pass
+        counts its searches instead (search_stats())."""
         self._L.tc_profile_enable(self._h, int(on))
 
     def profile_reset(self):
@@ -217,6 +218,22 @@ class GpuContext:
         """work counters since the context was created (tc_debug_counter): "indexed_points" = points that went through an index
         build, "index_builds" = the builds"""
         return int(self._L.tc_debug_counter(self._h, {"indexed_points": _lib.TC_COUNTER_INDEXED_POINTS, "index_builds": _lib.TC_COUNTER_INDEX_BUILDS}[which]))
+
+    def search_stats(self):
+        """Search statistics of the ICP main pass over the registrations run since profile_enable(3) (SURVEY 8d's secondary
+        figures; tc_debug_counter TC_COUNTER_ICP_*): raw counters + the derived per-search / lock-step figures.  A candidate step
+        = four consecutive target records = four distance evaluations of one lane."""
+        c = {k: int(self._L.tc_debug_counter(self._h, v)) for k, v in (
+            ("iterations", _lib.TC_COUNTER_ICP_ITERATIONS), ("wave_trips", _lib.TC_COUNTER_ICP_TRIPS),
+            ("wave_trips_without_a_search", _lib.TC_COUNTER_ICP_TRIPS_WITHOUT_SEARCH), ("searches", _lib.TC_COUNTER_ICP_SEARCHES),
+            ("candidate_steps_needed", _lib.TC_COUNTER_ICP_STEPS_NEEDED), ("candidate_steps_taken_by_slowest_lanes", _lib.TC_COUNTER_ICP_STEPS_TAKEN))}
+        s, need, took = max(c["searches"], 1), max(c["candidate_steps_needed"], 1), c["candidate_steps_taken_by_slowest_lanes"]
+        c["candidates_per_search"] = 4.0 * c["candidate_steps_needed"] / s
+        c["distance_evaluations"] = 4 * c["candidate_steps_needed"]
+        c["lockstep_ratio"] = 64.0 * took / need          # lane slots the trips spent per lane step needed
+        c["steps_per_searching_trip"] = took / max(c["wave_trips"] - c["wave_trips_without_a_search"], 1)
+        c["steps_per_search"] = c["candidate_steps_needed"] / s
+        return c
 
     def profile_read(self, minmax=False):
         """{kernel name: (launches, total ms)}; minmax=True: (launches, total ms, shortest launch ms, longest launch ms)"""

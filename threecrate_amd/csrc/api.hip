@@ -106,7 +106,7 @@ tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes) {
 }
 
 ProfScope::ProfScope(tc_context *c, const char *name, bool dominant) : ctx(c) {
-    if (!ctx->profiling) return;
+    if (ctx->profiling != 1 && ctx->profiling != 2) return;          // (3 = search statistics: no events)
     // (mode 2: every 17th launch of the dominant kernel -- a stride coprime to the usual 50 iterations per call, so that the sampled
     // iteration indices walk through all of 0 .. 49 over the calls and the cold first pass is sampled as often as any other.  An event on the stream is a ~5.7 us bubble on either side of the kernel --
     // every 4th launch, as until round 4, was 2.9 us per ICP iteration = 5 % of the timed region, not the 1 % once estimated.)
@@ -646,6 +646,7 @@ tc_status tc_sharded_estimate_normals_local_device(tc_context *ctx, tc_comm *com
 
 unsigned long long tc_debug_counter(const tc_context *ctx, int which) try {
     if (!ctx) return 0;
+    if (which >= TC_COUNTER_ICP_ITERATIONS && which <= TC_COUNTER_ICP_STEPS_TAKEN) return ctx->stat_icp[which - TC_COUNTER_ICP_ITERATIONS];
     return which == TC_COUNTER_INDEXED_POINTS ? ctx->stat_indexed_points : which == TC_COUNTER_INDEX_BUILDS ? ctx->stat_index_builds : 0ull;
 } TC_CATCH_VALUE(0)
 
@@ -1162,7 +1163,12 @@ tc_status tc_voxel_grid_filter(tc_context *ctx, const float *xyz, size_t n, floa
 } TC_CATCH_STATUS(ctx)
 
 // ---- profiling ------------------------------------------------------------------------------
-void tc_profile_enable(tc_context *ctx, int on) { if (ctx) { ctx->profiling = on; ctx->prof_tick = 0; } }
+void tc_profile_enable(tc_context *ctx, int on) {
+    if (!ctx) return;
+    ctx->profiling = on;
+    ctx->prof_tick = 0;
+    if (on == 3) for (auto &v : ctx->stat_icp) v = 0;          // a statistics session starts from zero
+}
 
 static void profile_collect(tc_context *ctx) {
     (void)hipStreamSynchronize(ctx->stream);

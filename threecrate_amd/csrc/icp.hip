@@ -218,12 +218,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *p) {
 #define TC_STAMP_ARGS
 #define TC_STAMP_PASS
 #endif
+template <bool STATS = false>
 __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, float y, float z, float ub2,
                                                  float &best, uint32_t &bestj, bool &refine, float max_dist,
-                                                 uint2 (*spans)[kIcpBlock] TC_STAMP_ARGS
-#ifdef TC_ANCHOR_STATS
-                                                 , float &second_lb
-#endif
+                                                 uint2 (*spans)[kIcpBlock], uint32_t &nsteps TC_STAMP_ARGS
                                                  ) {
     const GridGeom &g = gv.g;
     int cx, cy, cz;
@@ -300,9 +298,6 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     const f32x2 qxy = {x, y};
     best = INFINITY;
     bestj = 0xFFFFFFFFu;
-#ifdef TC_ANCHOR_STATS
-    float m2 = INFINITY, m1s = INFINITY;
-#endif
     // The span change is a select inside ONE divergent loop -- a lane leaves when its last span ends; the next span is fetched
     // from LDS at the top of every step -- instead of two nested exec-mask regions per step (`if (j >= e) { if (!mask) break; .. }`):
     // the loop is a single basic block of 68 instructions, 40.1 -> 39.1 us per pass on average (moving 46.0 -> 44.9, aligned 15.6 -> 15.3).
@@ -334,21 +329,10 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         const float m = bb ? m23 : m01;
         const uint32_t im = bb ? i23 : i01;
         const bool upd = m < best;
-#ifdef TC_ANCHOR_STATS
-        {   // the two smallest squared distances seen so far (statistic only: a plain running pair beside the product's best)
-            const float vs[4] = {v0, v1, v2, v3};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float v = (j + t < e) ? vs[t] : INFINITY;
-                const bool lt1 = v < m1s;
-                m2 = lt1 ? m1s : fminf(m2, v);
-                m1s = lt1 ? v : m1s;
-            }
-        }
-#endif
         best = upd ? m : best;
         bestj = upd ? im : bestj;
         j += 4;
+        if constexpr (STATS) ++nsteps;              // (candidate steps of this lane: only in the counting instantiation of the kernel)
         const bool adv = j >= e && mask != 0u;
         j = adv ? nse.x : j;
         e = adv ? nse.y : e;
@@ -359,11 +343,6 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
                         (cz - 1 <= 0) && (cz + 1 >= g.gz - 1);
     const float bound = (1.0f + mf - 2e-3f) * g.h;
     refine = !(covers || best <= bound * bound + out2 || (max_dist >= 0.0f && bound > max_dist));
-#ifdef TC_ANCHOR_STATS
-    // lower bound of the distance to every target point other than the best one: the runner-up scanned, what the pruning ball left
-    // out (farther than sqrt(ub2)), what ring 1 cannot see (farther than `bound`)
-    second_lb = fminf(fminf(sqrtf(m2), sqrtf(fmaxf(ub2, 0.0f))), covers ? INFINITY : sqrtf(bound * bound + out2));
-#endif
 }
 
 // per-pair terms -> per-lane f32 accumulators (shared by the main and the refine kernel)
@@ -506,7 +485,10 @@ __host__ __device__ __forceinline__ uint4 *refine_entries(uint32_t *rlist) {
 // to 128 VGPRs and must not use more (a 3-wave kernel needs a second round of blocks: +20-40 %).  Measured the other way too:
 // pinned to 5 / 6 waves (96 / 80 VGPRs, 96 / 192 bytes of scratch) with 5 / 6 blocks per CU the pass takes 54.6 / 68.4 us
 // instead of 46.5: the kernel is register limited, spills cost more than the extra waves hide.
-template <int MODE>
+// STATS: the counting instantiation (tc_profile_enable(ctx, 3) / TC_DEBUG & 8): wave trips, trips without a search, searches,
+// candidate steps the lanes needed, candidate steps the trips took (their slowest lane) -> IcpState::refine_ring_hist[2..6].
+// The product's instantiation carries none of it.
+template <int MODE, bool STATS = false>
 __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
@@ -615,46 +597,24 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             float best = INFINITY;
             uint32_t bestg = 0xFFFFFFFFu;
             bool refine = false;
-#ifdef TC_ANCHOR_STATS
-            // 2-NN anchor statistic: would |T s - p| < (runner-up bound of the last search) - (motion since then) have certified the match?
-            float4 *anc = const_cast<float4 *>(src_cov);
-            float4 a_prev = make_float4(0.f, 0.f, 0.f, -1.0f);
-            if (anc && j < end) a_prev = anc[j];
-            const float mot = sqrtf(d2_nc(a_prev.x, a_prev.y, a_prev.z, x, y, z));
-            const bool cert = in && warm && pj != 0xFFFFFFFFu && a_prev.w >= 0.0f && sqrtf(ub2p) < (a_prev.w - mot) * 0.9999f;
-            float second_lb = INFINITY;
-            {
-                IcpState *sw = const_cast<IcpState *>(st);
-                const unsigned long long act = __ballot(in && warm), kv = __ballot(in && warm && keep), kc = __ballot(in && warm && (keep || cert)), co = __ballot(cert);
-                if (lane == 0 && act) {
-                    atomicAdd(&sw->refine_ring_hist[0], (uint32_t)__popcll(act));
-                    atomicAdd(&sw->refine_ring_hist[1], (uint32_t)__popcll(kv));
-                    atomicAdd(&sw->refine_ring_hist[2], (uint32_t)__popcll(co));
-                    atomicAdd(&sw->refine_ring_hist[3], (uint32_t)__popcll(kc));
-                    atomicAdd(&sw->refine_ring_hist[4], 1u);
-                    if (kv == act) atomicAdd(&sw->refine_ring_hist[5], 1u);
-                    if (kc == act) atomicAdd(&sw->refine_ring_hist[6], 1u);
+            uint32_t nst = 0u;
+            const unsigned long long smask = __ballot(in && !keep);
+            if (smask != 0ull) nn_search_pruned<STATS>(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans, nst TC_STAMP_PASS);
+            if constexpr (STATS) {
+                uint32_t mx = nst, sm = (in && !keep) ? nst : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sm += (uint32_t)__shfl_xor((int)sm, o); }
+                if (lane == 0) {
+                    IcpState *sw = const_cast<IcpState *>(st);
+                    atomicAdd(&sw->refine_ring_hist[2], mx);                               // steps the trip took (its slowest lane)
+                    atomicAdd(&sw->refine_ring_hist[3], sm);                               // steps its lanes needed
+                    atomicAdd(&sw->refine_ring_hist[4], (uint32_t)__popcll(smask));        // searches
+                    atomicAdd(&sw->refine_ring_hist[5], 1u);                               // wave trips
+                    if (smask == 0ull) atomicAdd(&sw->refine_ring_hist[6], 1u);            // ... without a search
                 }
             }
-            // (the statistic scans a ball HALF A CELL wider than the warm-start ball: the previous match's own distance bounds nothing
-            // beyond itself -- a runner-up bound worth having needs the wider scan, which is what a real 2-NN pass would pay for)
-            const float ub2w = (sqrtf(ub2) + 0.5f * g.h) * (sqrtf(ub2) + 0.5f * g.h);
-            if (__ballot(in && !keep) != 0ull) nn_search_pruned(tgt, x, y, z, (keep || !in) ? -1.0f : ub2w, best, bestg, refine, max_dist, spans TC_STAMP_PASS, second_lb);
-            if (anc && j < end) {
-                // a searched lane gets a fresh bound; a kept one carries the old bound minus what it moved
-                const float nb = (in && !keep) ? (refine ? -1.0f : second_lb) : (a_prev.w >= 0.0f ? a_prev.w - mot : -1.0f);
-                anc[j] = make_float4(x, y, z, nb);
-            }
-#else
-            if (__ballot(in && !keep) != 0ull) nn_search_pruned(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans TC_STAMP_PASS);
-#endif
             if (keep) { best = ub2p; bestg = pj; }
             refine = refine && in && !keep;
-            if ((dbg & 8) && lane == 0) {          // statistics: wave trips / trips without a search
-                IcpState *sw = const_cast<IcpState *>(st);
-                atomicAdd(&sw->refine_ring_hist[5], 1u);
-                if (__ballot(in && !keep) == 0ull) atomicAdd(&sw->refine_ring_hist[6], 1u);
-            }
             const unsigned long long rmask = __ballot(refine);
             if (refine) {
                 // hand the refine pass the best real point seen so far: previous match or ring-1 best
@@ -1601,12 +1561,13 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
                              double *partials, bool do_sum, bool do_apply, bool do_reduce, const float4 *src_cov = nullptr,
                              const float4 *vor = nullptr, int32_t *done_out = nullptr) {
     hipStream_t s = ctx->stream;
-    const int dbg = debug_flags();
+    const int dbg = debug_flags() | (ctx->profiling == 3 ? 8 : 0);
     double *refine_rows = partials + (size_t)l.nblocks * TC_ICP_SUMS_STRIDE;
     if (do_reduce) {
         {
             ProfScope ps(ctx, mode == 1 ? "icp_correspond_reduce_p2plane" : mode == 2 ? "icp_correspond_reduce_gicp" : "icp_correspond_reduce_p2p", true);
             auto kern = mode == 1 ? icp_correspond_reduce_kernel<1> : mode == 2 ? icp_correspond_reduce_kernel<2> : icp_correspond_reduce_kernel<0>;
+            if (dbg & 8) kern = mode == 1 ? icp_correspond_reduce_kernel<1, true> : mode == 2 ? icp_correspond_reduce_kernel<2, true> : icp_correspond_reduce_kernel<0, true>;
             hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st, corr_pos, rlist, partials, dbg, src_cov,
                                (dbg & 4) ? nullptr : vor, (dbg & 1024) ? (unsigned long long *)ctx->dbg_times.p : nullptr);
         }
@@ -1800,13 +1761,6 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
         src_cov = (const float4 *)ctx->gicp_src_cov.p;
     }
     const float4 *nrm = (const float4 *)(*su.tix).normals.p;
-#ifdef TC_ANCHOR_STATS
-    if (mode != 2) {
-        if (tc_status s = ensure(ctx, ctx->gicp_src_cov, ns * sizeof(float4))) return s;
-        TC_HIP_TRY(ctx, hipMemsetAsync(ctx->gicp_src_cov.p, 0xFF, ns * sizeof(float4), st));      // w = NaN pattern -> "no anchor" (w >= 0 fails)
-        src_cov = (const float4 *)ctx->gicp_src_cov.p;
-    }
-#endif
 
     size_t enq = 0;
     // bounds that already exist (a cloud handle whose normals were estimated here, or that has been a target before) serve from
@@ -1870,12 +1824,16 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
         }
         fprintf(stderr, "\n");
     }
-#ifdef TC_ANCHOR_STATS
-    fprintf(stderr, "[tc] anchor stats over %u iterations: warm lanes %u | kept by the inscribed ball %.2f %% | certified by the 2-NN anchor %.2f %% | either %.2f %% || wave trips %u | all lanes kept (ball) %.2f %% | all lanes kept (ball or anchor) %.2f %%\n",
-            hs->iterations, hs->refine_ring_hist[0], 100.0 * hs->refine_ring_hist[1] / std::max(hs->refine_ring_hist[0], 1u),
-            100.0 * hs->refine_ring_hist[2] / std::max(hs->refine_ring_hist[0], 1u), 100.0 * hs->refine_ring_hist[3] / std::max(hs->refine_ring_hist[0], 1u),
-            hs->refine_ring_hist[4], 100.0 * hs->refine_ring_hist[5] / std::max(hs->refine_ring_hist[4], 1u), 100.0 * hs->refine_ring_hist[6] / std::max(hs->refine_ring_hist[4], 1u));
-#endif
+    if ((debug_flags() & 8) || ctx->profiling == 3) {       // counters of the main pass's counting instantiation, summed over the call's iterations
+        const uint32_t *h = hs->refine_ring_hist;
+        ctx->stat_icp[0] += hs->iterations; ctx->stat_icp[1] += h[5]; ctx->stat_icp[2] += h[6]; ctx->stat_icp[3] += h[4];
+        ctx->stat_icp[4] += h[3]; ctx->stat_icp[5] += h[2];
+        if (debug_flags() & 8)
+            fprintf(stderr, "[tc] icp main pass over %u iterations: wave trips %u, without a search %u (%.1f %%); searches %u, candidate steps needed %u "
+                            "(%.2f per search), steps taken by the trips' slowest lanes %u (%.2f per searching trip): lock-step ratio (lane slots spent / steps needed) %.2f\n",
+                    hs->iterations, h[5], h[6], 100.0 * h[6] / std::max(h[5], 1u), h[4], h[3], (double)h[3] / std::max(h[4], 1u), h[2],
+                    (double)h[2] / std::max(h[5] - h[6], 1u), (double)h[2] * 64.0 / std::max(h[3], 1u));
+    }
     if (debug_flags() & 64)
         fprintf(stderr, "[tc] icp: %u iterations, refine queries total %u max %u  exit ring hist %u %u %u %u %u %u %u %u\n", hs->iterations,
                 hs->refine_total, hs->refine_max, hs->refine_ring_hist[0], hs->refine_ring_hist[1], hs->refine_ring_hist[2], hs->refine_ring_hist[3],

@@ -172,6 +172,9 @@ struct tc_context {
     tc::DevBuf build_tmp;           // index build: the records in arrival order, before the in-cell re-rank (float4 * n)
     tc::DevBuf normals_hard;        // normals: count + positions of the points handed to the wave-per-point kernel
     unsigned long long stat_indexed_points = 0, stat_index_builds = 0;   // tc_debug_counter
+    // search statistics of the ICP main pass, summed over the calls made in profiling mode 3 (tc_profile_enable(ctx, 3)):
+    // iterations, wave trips, trips without a search, searches, candidate steps needed, candidate steps taken (slowest lanes)
+    unsigned long long stat_icp[6] = {0, 0, 0, 0, 0, 0};
     bool normals_hard_clean = false; // its header (count, exit ticket) is known to be zero: the last serving launch went through
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
