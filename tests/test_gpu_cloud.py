@@ -272,8 +272,9 @@ def test_search_statistics_mode_counts_without_changing_the_result(ctx):
     s2 = ctx.search_stats()
     ctx.profile_enable(0)
     assert np.array_equal(a.transformation, b.transformation) and a.mse == b.mse and np.array_equal(a.correspondences, b.correspondences)
-    trips_per_it = -(-n // 1024) * 16                                # 4 trips of each of the 4 waves of every 1024-point block
-    assert s["iterations"] == iters and abs(s["wave_trips"] - trips_per_it * iters) <= 16 * iters
+    # (a block's waves make four trips per group of 1024 points whatever the block's share of the cloud is)
+    assert s["iterations"] == iters and s["wave_trips"] * 64 >= n * iters and s["wave_trips"] % iters == 0
+    assert 0 <= s["wave_trips_without_a_search"] < s["wave_trips"]
     assert n <= s["searches"] <= n * iters                            # the cold first pass searches every point
     assert s["candidate_steps_needed"] >= s["searches"] and 1.0 <= s["lockstep_ratio"] < 10.0
     assert s["candidate_steps_taken_by_slowest_lanes"] * 64 >= s["candidate_steps_needed"]

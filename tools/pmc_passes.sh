@@ -28,7 +28,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         a = agg[k][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
-    if not any(s in k for s in ("icp_correspond", "icp_refine", "normals_knn")): continue
+    if not any(s in k for s in ("icp_correspond", "icp_refine", "normals_knn", "normals_tagged")): continue
     print(k)
     for c, (v, n) in sorted(agg[k].items()):
         print(f"    {c:42s} {v/n/1e6:12.3f} M/launch  ({n} launches)")
