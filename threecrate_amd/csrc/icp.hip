@@ -502,6 +502,10 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     if (hd.done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
     __shared__ uint2 spans[kSpanRows][kIcpBlock];
+#ifdef TC_ICP_LDS_PAD
+    __shared__ uint32_t lds_pad[TC_ICP_LDS_PAD / 4];          // occupancy probe: fewer blocks fit a CU
+    if (hd.iterations == 0xFFFFFFFFu) lds_pad[threadIdx.x] = threadIdx.x;
+#endif
     // Refine entries (source index, best known position) go straight to global memory: every wave owns a region
     // of chunk / 4 entries (it never handles more points than that) and appends in (trip, lane) order by ballot
     // prefix, so the list -- and with it every sum -- is deterministic, without atomics, LDS or barriers.
@@ -1530,7 +1534,10 @@ static IcpLaunch plan_launch(size_t ns) {
     // 1024 points (4 per lane).  Measured alternatives at 1 M points (45 us): 6 blocks per CU x 768 points (80 VGPRs,
     // 6 waves per SIMD, still one round): 48 us -- more waves do not pay for the extra per-block sums; any grid that
     // needs a second round of blocks (e.g. 1303 blocks at 5 per CU): 54-62 us, the tail.
-    constexpr size_t kResidentBlocks = 4 * 256;
+#ifndef TC_ICP_RESIDENT
+#define TC_ICP_RESIDENT 4
+#endif
+    constexpr size_t kResidentBlocks = TC_ICP_RESIDENT * 256;      // (-DTC_ICP_RESIDENT=3 -DTC_ICP_LDS_PAD=..: the occupancy probe of profiles/r05_main_pass_occupancy.txt)
     size_t chunk = (ns + kResidentBlocks - 1) / kResidentBlocks;
     chunk = std::max<size_t>((chunk + kIcpBlock - 1) / kIcpBlock * kIcpBlock, kIcpBlock);
     uint32_t nb = (uint32_t)((ns + chunk - 1) / chunk);
