@@ -237,11 +237,12 @@ float normals_target_ppo(size_t k) {
 }
 
 void recycle_index(tc_context *ctx, DeviceIndex &ix) {
-    for (DevBuf *b : {&ix.pts, &ix.cell_start, &ix.normals, &ix.vor, &ix.cell_of, &ix.slot, &ix.arrival, &ix.fill, &ix.blocksum}) recycle(ctx, *b);
+    for (DevBuf *b : {&ix.pts, &ix.cell_start, &ix.normals, &ix.vor, &ix.pts12, &ix.cell_of, &ix.slot, &ix.arrival, &ix.fill, &ix.blocksum}) recycle(ctx, *b);
+    ix.pts12_valid = false; ix.vor_valid = false;
 }
 
 void free_index(DeviceIndex &ix) {
-    free_buf(ix.pts); free_buf(ix.cell_start); free_buf(ix.normals); free_buf(ix.vor); free_buf(ix.cell_of);
+    free_buf(ix.pts); free_buf(ix.cell_start); free_buf(ix.normals); free_buf(ix.vor); free_buf(ix.pts12); free_buf(ix.cell_of);
     free_buf(ix.slot); free_buf(ix.arrival); free_buf(ix.fill); free_buf(ix.blocksum);
 }
 

@@ -422,6 +422,7 @@ GridView view_of(const DeviceIndex &ix) {
     v.g = ix.geom;
     v.pts = (const float4 *)ix.pts.p;
     v.cell_start = (const uint32_t *)ix.cell_start.p + kCellStartFront;
+    v.pts12 = ix.pts12_valid ? (const float *)ix.pts12.p : nullptr;
     return v;
 }
 
@@ -833,6 +834,7 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     ctx->stat_indexed_points += n;
     ctx->stat_index_builds += 1;
     ix.vor_valid = false;
+    ix.pts12_valid = false;
     ix.occ_host_valid = false;
     hipStream_t st = ctx->stream;
     const uint32_t n32 = (uint32_t)n;

@@ -221,7 +221,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *p) {
 template <bool STATS = false>
 __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, float y, float z, float ub2,
                                                  float &best, uint32_t &bestj, bool &refine, float max_dist,
-                                                 uint2 (*spans)[kIcpBlock], uint32_t &nsteps TC_STAMP_ARGS
+                                                 uint2 (*spans)[kIcpBlock], uint32_t &nsteps, const float *pts12 TC_STAMP_ARGS
                                                  ) {
     const GridGeom &g = gv.g;
     int cx, cy, cz;
@@ -294,7 +294,7 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     // A step may read up to three records past its span: real target points of the next cells (or
     // the +inf padding behind the array), harmless as extra candidates.  Rows are visited in ascending
     // order = ascending position, so the strict '<' keeps the lowest position among equal distances.
-    const __amdgpu_buffer_rsrc_t pt_rsrc = raw_rsrc(gv.pts);
+    const __amdgpu_buffer_rsrc_t pt_rsrc = raw_rsrc(pts12);
     const f32x2 qxy = {x, y};
     best = INFINITY;
     bestj = 0xFFFFFFFFu;
@@ -313,13 +313,18 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     while (j < e) {
         const int kn = mask ? __ffs(mask) - 1 : 0;
         const uint2 nse = spans[kn][threadIdx.x];
-        const uint32_t o = j << 4;                      // byte offset (positions < 2^28, checked by icp_setup)
-        // 12 of the 16 bytes of a record (the texture data path is ~90 % busy: bytes count); (x, y) is
-        // an aligned register pair: packed-f32 difference and square, z scalar
-        const f32x3 c0 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o, 0, 0));
-        const f32x3 c1 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u, 0, 0));
-        const f32x3 c2 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 32u, 0, 0));
-        const f32x3 c3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 48u, 0, 0));
+        // The candidates come from the PACKED copy of the sorted records (12 bytes each, DeviceIndex::pts12): four records = 48
+        // bytes = THREE 16-byte reads (dword aligned) instead of four 12-byte reads of the 16-byte records.  The pass is bound by L1
+        // look-ups -- one per lane and read instruction, whatever its width: round 5, profiles/r05_ab_pack12.txt: 42.9 -> 40.5 us
+        // per moving-phase pass, the cold first pass 57 -> 51 us, whole job +2.9 %.  Same bits (same coordinates, same order).
+        const uint32_t o = j * 12u;                     // (positions < 2^28: below 2^32)
+        const u32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o, 0, 0);
+        const u32x4 rb = __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 16u, 0, 0);
+        const u32x4 rc = __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 32u, 0, 0);
+        const f32x3 c0 = {__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z)};
+        const f32x3 c1 = {__uint_as_float(ra.w), __uint_as_float(rb.x), __uint_as_float(rb.y)};
+        const f32x3 c2 = {__uint_as_float(rb.z), __uint_as_float(rb.w), __uint_as_float(rc.x)};
+        const f32x3 c3 = {__uint_as_float(rc.y), __uint_as_float(rc.z), __uint_as_float(rc.w)};
         const float v0 = d2_packed(c0, qxy, z), v1 = d2_packed(c1, qxy, z);
         const float v2 = d2_packed(c2, qxy, z), v3 = d2_packed(c3, qxy, z);
         const bool b01 = v1 < v0, b23 = v3 < v2;
@@ -493,7 +498,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
     double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov, const float4 *__restrict__ vor,
-    unsigned long long *__restrict__ blk_times) {
+    unsigned long long *__restrict__ blk_times, const float *__restrict__ pts12) {
     constexpr bool P2PLANE = MODE == 1;
     unsigned long long t_begin = 0;
     if (blk_times) t_begin = __builtin_amdgcn_s_memrealtime();          // TC_DEBUG & 1024: per-block start / end stamps (100 MHz)
@@ -603,7 +608,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             bool refine = false;
             uint32_t nst = 0u;
             const unsigned long long smask = __ballot(in && !keep);
-            if (smask != 0ull) nn_search_pruned<STATS>(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans, nst TC_STAMP_PASS);
+            if (smask != 0ull) nn_search_pruned<STATS>(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans, nst, pts12 TC_STAMP_PASS);
             if constexpr (STATS) {
                 uint32_t mx = nst, sm = (in && !keep) ? nst : 0u;
 #pragma unroll
@@ -1576,7 +1581,8 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
             auto kern = mode == 1 ? icp_correspond_reduce_kernel<1> : mode == 2 ? icp_correspond_reduce_kernel<2> : icp_correspond_reduce_kernel<0>;
             if (dbg & 8) kern = mode == 1 ? icp_correspond_reduce_kernel<1, true> : mode == 2 ? icp_correspond_reduce_kernel<2, true> : icp_correspond_reduce_kernel<0, true>;
             hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st, corr_pos, rlist, partials, dbg, src_cov,
-                               (dbg & 4) ? nullptr : vor, (dbg & 1024) ? (unsigned long long *)ctx->dbg_times.p : nullptr);
+                               (dbg & 4) ? nullptr : vor, (dbg & 1024) ? (unsigned long long *)ctx->dbg_times.p : nullptr,
+                               tv.pts12);
         }
         ProfScope ps(ctx, "icp_refine");
         auto kern = mode == 1 ? icp_refine_kernel<1> : mode == 2 ? icp_refine_kernel<2> : icp_refine_kernel<0>;
@@ -1618,6 +1624,16 @@ float icp_cell_factor() {             // (TC_ICP_CELL_FACTOR: tuning experiments
     static const float v = [] { const char *e = getenv("TC_ICP_CELL_FACTOR"); return e ? (float)atof(e) : 1.13f; }();
     return v;
 }   // ~1.45 pts/cell: ring 1 is exact for ~99.8 % of uniform queries
+
+// the target's sorted records again as packed 12-byte x, y, z (the candidate loop's array), padded like the records (+inf-like
+// coordinates behind the last one: a step reads up to three records past its span)
+__global__ void __launch_bounds__(256) icp_pack12_kernel(const float4 *__restrict__ pts, uint32_t n, uint32_t npad, float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    float4 r = make_float4(__uint_as_float(0x7F7F7F7Fu), __uint_as_float(0x7F7F7F7Fu), __uint_as_float(0x7F7F7F7Fu), 0.f);
+    if (i < n) r = pts[i];
+    out[3 * (size_t)i] = r.x; out[3 * (size_t)i + 1] = r.y; out[3 * (size_t)i + 2] = r.z;
+}
 
 struct IcpSetup {
     IcpLaunch l;
@@ -1668,6 +1684,14 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     if (tc_status s = ensure(ctx, ctx->partials, ((size_t)(kMaxPartialBlocks + kRefineBlocks) * TC_ICP_SUMS_STRIDE + 2) * sizeof(double))) return s;
     // corr | corr_pos | refine counts (one per wave of a main block) | refine entries (32 bytes each, chunk / 4 per wave)
     if (tc_status s = ensure(ctx, ctx->corr, (2 * ns + (size_t)kMaxPartialBlocks * (kIcpBlock / 64) + 4 + kRefineEntryWords * (size_t)out.l.nblocks * out.l.chunk) * sizeof(uint32_t))) return s;
+    if (!out.tix->pts12_valid) {          // once per indexed cloud (a handle keeps it for its later registrations)
+        const uint32_t npad = (uint32_t)nt + 16u;
+        if (tc_status s = ensure(ctx, out.tix->pts12, (size_t)npad * 12 + 64)) return s;
+        ProfScope ps(ctx, "icp_pack12");
+        hipLaunchKernelGGL(icp_pack12_kernel, dim3((npad + 255) / 256), dim3(256), 0, ctx->stream, (const float4 *)(*out.tix).pts.p, (uint32_t)nt, npad,
+                           (float *)out.tix->pts12.p);
+        out.tix->pts12_valid = true;
+    }
     out.tv = view_of((*out.tix));
     return TC_OK;
 }

@@ -44,6 +44,7 @@ struct GridView {
     GridGeom g;
     const float4   *pts;        // cell-sorted points: x, y, z, w = bit pattern of the original index
     const uint32_t *cell_start; // ncell + 1 exclusive prefix sums
+    const float    *pts12;      // the same records as packed 12-byte x, y, z (only once the index has served as an ICP target; else null)
 };
 
 // device-side ICP state (one per running registration); mirrors the loop variables of
@@ -122,6 +123,9 @@ struct DeviceIndex {
     DevBuf normals;     // float4 * n   (cell-sorted target normals; optional)
     DevBuf vor;         // float4 * n   (ICP target: x, y, z + inscribed-ball bound, icp_target_nn_bound_kernel; optional)
     bool vor_valid = false;     // vor belongs to the current contents of pts (build_index resets it)
+    DevBuf pts12;       // float * 3 (n + 16): the sorted records again as packed 12-byte x, y, z -- the ICP candidate loop reads four
+                        // of them with THREE 16-byte reads (made by icp_setup when the index first serves as an ICP target)
+    bool pts12_valid = false;   // (build_index resets it)
     uint32_t occ_host = 0;      // occupied cells of the final grid, when the build read them back (edge adaptation: clouds of >= 2^18 points)
     bool occ_host_valid = false;
     DevBuf cell_of;     // u32 * n      (scratch: cell id per original point)
