@@ -362,7 +362,7 @@ void tc_context_destroy(tc_context *ctx) try {
     if (ctx->upload_event) (void)hipEventDestroy(ctx->upload_event);
     free_index(ctx->tgt_index); free_index(ctx->src_index); free_index(ctx->vox_index);
     free_buf(ctx->in_a); free_buf(ctx->in_b); free_buf(ctx->in_c); free_buf(ctx->out_a); free_buf(ctx->bbox);
-    free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->gicp_src_cov); free_buf(ctx->overflow); free_buf(ctx->normals_hard); free_buf(ctx->build_tmp); free_buf(ctx->dbg_times);
+    free_buf(ctx->state); free_buf(ctx->partials); free_buf(ctx->corr); free_buf(ctx->gicp_src_cov); free_buf(ctx->overflow); free_buf(ctx->normals_hard); free_buf(ctx->build_tmp); free_buf(ctx->dbg_times); free_buf(ctx->icp_wsrc);
     for (auto &pb : ctx->pool) (void)hipFree(pb.p);
     for (auto e : ctx->chunk_events) (void)hipEventDestroy(e);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);

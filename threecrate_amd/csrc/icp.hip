@@ -495,8 +495,8 @@ __host__ __device__ __forceinline__ uint4 *refine_entries(uint32_t *rlist) {
 // The product's instantiation carries none of it.
 template <int MODE, bool STATS = false>
 __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) icp_correspond_reduce_kernel(
-    GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src, uint32_t ns, uint32_t chunk,
-    const IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
+    GridView tgt, const float4 *__restrict__ tgt_nrm, float4 *wsrc, uint32_t ns, uint32_t chunk,
+    const IcpState *__restrict__ st, uint32_t *__restrict__ rlist,
     double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov, const float4 *__restrict__ vor,
     unsigned long long *__restrict__ blk_times, const float *__restrict__ pts12) {
     constexpr bool P2PLANE = MODE == 1;
@@ -552,11 +552,12 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             for (int u = 0; u < kIcpGroup; ++u) {
                 const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
                 const bool in = j < end;
-                // (12 of the 16 bytes, here and for the final record and the normal below: the texture data path is the most loaded
-                // unit of the pass -- 40.8 -> 40.3 us)
-                { const f32x3 t3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(raw_rsrc(src), (in ? j : beg) << 4, 0, 0));
-                  sv[u] = make_float4(t3.x, t3.y, t3.z, 0.0f); }
-                uint32_t pj = corr_pos[in ? j : beg];          // (allocated but meaningless before iteration 1)
+                // ONE 16-byte read per point: the source record and, in its w, the position of the previous match (the loop's working
+                // copy of the source, icp_working_source_kernel: round 5 -- a read instruction less per point, 4 of ~23; the pass is
+                // bound by look-ups per lane and read instruction, profiles/r05_ab_pack12.txt)
+                { const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(raw_rsrc(wsrc), (in ? j : beg) << 4, 0, 0);
+                  sv[u] = make_float4(__uint_as_float(t4.x), __uint_as_float(t4.y), __uint_as_float(t4.z), __uint_as_float(t4.w)); }
+                uint32_t pj = __float_as_uint(sv[u].w);        // (0xFFFFFFFF before iteration 1)
                 if (!warm || !in) pj = 0xFFFFFFFFu;
                 pjv[u] = pj;
                 fin[u] = in && sv[u].x < 3.0e38f;              // a non-finite source point (placeholder record, grid.hip) has no match
@@ -639,7 +640,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             bool valid = in && !refine && bestg != 0xFFFFFFFFu;
             if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
             const uint32_t newv = valid ? bestg : 0xFFFFFFFFu;
-            if (j < end && !refine && (!warm || newv != pj)) corr_pos[j] = newv;     // an unchanged match is not written again
+            if (j < end && !refine && (!warm || newv != pj)) reinterpret_cast<uint32_t *>(wsrc)[4 * (size_t)j + 3] = newv;     // an unchanged match is not written again
             mv[u] = (dbg & 16) ? 0xFFFFFFFFu : newv;                             // dbg & 16: timing experiments only (no sums)
             TC_STAMP(3);
         }
@@ -883,7 +884,7 @@ __device__ __forceinline__ unsigned long long refine_ball_scan(const GridView &t
 template <int MODE>
 __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, const float4 *__restrict__ src,
-    IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos, uint32_t *__restrict__ rlist,
+    IcpState *__restrict__ st, uint32_t *__restrict__ corr_pos /* stride 4: the w of the working source records */, uint32_t *__restrict__ rlist,
     const double *__restrict__ main_rows, uint32_t n_main_rows, uint32_t seg_stride, double *__restrict__ partial_rows,
     const float4 *__restrict__ src_cov, int dbg) {
     constexpr bool P2PLANE = MODE == 1;
@@ -1042,7 +1043,7 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
             const uint32_t bestg = (uint32_t)bestkey;
             bool valid = bestkey != ~0ull;
             if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);
-            corr_pos[j] = valid ? bestg : 0xFFFFFFFFu;
+            corr_pos[4 * (size_t)j] = valid ? bestg : 0xFFFFFFFFu;
             if (valid) {
                 const float4 c = tgt.pts[bestg];
                 float a[NACC];
@@ -1086,7 +1087,7 @@ __global__ void __launch_bounds__(256) icp_write_corr_kernel(GridView tgt, const
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ns) return;
     const uint32_t so = __float_as_uint(src[j].w);
-    const uint32_t pj = corr_pos[j];
+    const uint32_t pj = corr_pos[4 * (size_t)j];           // (stride 4: the w of the working source records)
     corr[so] = (pj == 0xFFFFFFFFu) ? 0xFFFFFFFFu : __float_as_uint(tgt.pts[pj].w);
 }
 
@@ -1102,9 +1103,9 @@ __global__ void __launch_bounds__(kIcpBlock) icp_final_mse_kernel(GridView tgt, 
     double acc[2] = {0.0, 0.0};
     const uint32_t beg = blockIdx.x * chunk, end = min(beg + chunk, ns);
     for (uint32_t j = beg + threadIdx.x; j < end; j += kIcpBlock) {
-        const uint32_t bj = corr_pos[j];
+        const float4 s = src[j];                             // (the working source record: x, y, z, match)
+        const uint32_t bj = __float_as_uint(s.w);
         if (bj == 0xFFFFFFFFu) continue;
-        const float4 s = src[j];
         float x, y, z;
         iso_apply(q, t, s.x, s.y, s.z, x, y, z);
         const float4 c = tgt.pts[bj];
@@ -1580,7 +1581,7 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
             ProfScope ps(ctx, mode == 1 ? "icp_correspond_reduce_p2plane" : mode == 2 ? "icp_correspond_reduce_gicp" : "icp_correspond_reduce_p2p", true);
             auto kern = mode == 1 ? icp_correspond_reduce_kernel<1> : mode == 2 ? icp_correspond_reduce_kernel<2> : icp_correspond_reduce_kernel<0>;
             if (dbg & 8) kern = mode == 1 ? icp_correspond_reduce_kernel<1, true> : mode == 2 ? icp_correspond_reduce_kernel<2, true> : icp_correspond_reduce_kernel<0, true>;
-            hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, src, ns, l.chunk, st, corr_pos, rlist, partials, dbg, src_cov,
+            hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, const_cast<float4 *>(src), ns, l.chunk, st, rlist, partials, dbg, src_cov,
                                (dbg & 4) ? nullptr : vor, (dbg & 1024) ? (unsigned long long *)ctx->dbg_times.p : nullptr,
                                tv.pts12);
         }
@@ -1635,13 +1636,25 @@ __global__ void __launch_bounds__(256) icp_pack12_kernel(const float4 *__restric
     out[3 * (size_t)i] = r.x; out[3 * (size_t)i + 1] = r.y; out[3 * (size_t)i + 2] = r.z;
 }
 
+// the loop's working copy of the ordered source: x, y, z and, in w, the position of the point's current match (none yet)
+__global__ void __launch_bounds__(256) icp_working_source_kernel(const float4 *__restrict__ src, uint32_t n, float4 *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 r = src[i];
+    r.w = __uint_as_float(0xFFFFFFFFu);
+    out[i] = r;
+}
+
 struct IcpSetup {
     IcpLaunch l;
     GridView tv;
     TileGeom tg;
     DeviceIndex *tix = nullptr;      // the target's index: ctx->tgt_index, or a cloud handle's
-    const float4 *src = nullptr;     // the source records in the order the loop walks them
+    const float4 *src = nullptr;     // the source records in the order the loop walks them (w = original index)
+    float4 *wsrc = nullptr;          // the loop's working copy of them (w = position of the current match): what the kernels read
 };
+// the matches as the refine / write-out kernels address them: the w of the working records, stride 4
+static inline uint32_t *match_words(float4 *wsrc) { return reinterpret_cast<uint32_t *>(wsrc) + 3; }
 
 static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, size_t ns, const float *d_tgt, size_t nt,
                            const float *d_nrm, size_t nstride, const float init[7], float max_dist, float conv_thr,
@@ -1693,6 +1706,12 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
         out.tix->pts12_valid = true;
     }
     out.tv = view_of((*out.tix));
+    if (tc_status s = ensure(ctx, ctx->icp_wsrc, (ns + 4) * sizeof(float4))) return s;
+    out.wsrc = (float4 *)ctx->icp_wsrc.p;
+    if (ns > 0) {
+        ProfScope ps(ctx, "icp_working_source");
+        hipLaunchKernelGGL(icp_working_source_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, out.src, (uint32_t)ns, out.wsrc);
+    }
     return TC_OK;
 }
 
@@ -1778,7 +1797,7 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
                                 mode == 2 ? nullptr : src_presorted)) return s;
     hipStream_t st = ctx->stream;
     IcpState *dstate = (IcpState *)ctx->state.p;
-    uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + ns;
+    uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = match_words(su.wsrc);
     double *partials = (double *)ctx->partials.p;
     const float4 *src = su.src;
     const float4 *src_cov = nullptr;
@@ -1802,12 +1821,12 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&](int32_t *done_out) -> tc_status {
             if (enq++ == vor_after() && !vor)
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
-            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor, done_out);
+            launch_iteration(ctx, mode, su.tv, nrm, su.wsrc, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor, done_out);
             return TC_OK;
         })) return s;
     if (mode == 0) {
         ProfScope ps(ctx, "icp_final_mse");
-        hipLaunchKernelGGL(icp_final_mse_kernel, dim3(su.l.mse_blocks), dim3(kIcpBlock), 0, st, su.tv, src, (uint32_t)ns,
+        hipLaunchKernelGGL(icp_final_mse_kernel, dim3(su.l.mse_blocks), dim3(kIcpBlock), 0, st, su.tv, (const float4 *)su.wsrc, (uint32_t)ns,
                            su.l.mse_chunk, dstate, corr_pos, partials);
     }
     // (the RESULT block: pinned bytes 640 .. 1008 -- not the block at 256 the initial state was staged in, whose asynchronous upload
@@ -1930,9 +1949,11 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     const size_t nl = hi - lo;
     const IcpLaunch l = plan_launch(nl);
     // corr (n_setup) | corr_pos (nl) | refine counts + entries -- inside the buffer icp_setup sized for the points it was given
-    uint32_t *corr = (uint32_t *)ctx->corr.p, *corr_pos = corr + n_setup, *rlist = corr + 2 * n_setup;
+    uint32_t *corr = (uint32_t *)ctx->corr.p, *rlist = corr + 2 * n_setup;
     double *partials = (double *)ctx->partials.p;
     const float4 *src = su.src + lo;
+    float4 *wsrc = su.wsrc + lo;
+    uint32_t *corr_pos = match_words(wsrc);
     const float4 *nrm = (const float4 *)(*su.tix).normals.p;
     size_t enq = 0;
     // bounds that already exist (a cloud handle whose normals were estimated here, or that has been a target before) serve from
@@ -1941,13 +1962,13 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&](int32_t *done_out) -> tc_status {
             if (enq++ == vor_after() && !vor)
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
-            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, true, false, true, nullptr, vor);
+            launch_iteration(ctx, mode, su.tv, nrm, wsrc, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, true, false, true, nullptr, vor);
             if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;
-            launch_iteration(ctx, mode, su.tv, nrm, src, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, false, true, false, nullptr, nullptr, done_out);
+            launch_iteration(ctx, mode, su.tv, nrm, wsrc, (uint32_t)nl, l, dstate, corr_pos, rlist, partials, false, true, false, nullptr, nullptr, done_out);
             return TC_OK;
         })) return s;
     if (mode == 0) {        // registration.rs:343-361: the post-loop mse of a run that did not converge, summed over the ranks
-        hipLaunchKernelGGL(icp_final_mse_kernel, dim3(l.mse_blocks), dim3(kIcpBlock), 0, st, su.tv, src, (uint32_t)nl, l.mse_chunk, dstate,
+        hipLaunchKernelGGL(icp_final_mse_kernel, dim3(l.mse_blocks), dim3(kIcpBlock), 0, st, su.tv, (const float4 *)wsrc, (uint32_t)nl, l.mse_chunk, dstate,
                            corr_pos, partials);
         hipLaunchKernelGGL(icp_final_mse_fold_kernel, dim3(1), dim3(64), 0, st, dstate, partials, l.mse_blocks);
         if (tc_status s = comm_allreduce_f64(comm, dstate->sums, TC_ICP_SUMS_STRIDE)) return s;
@@ -2053,8 +2074,8 @@ tc_status tc_icp_shard_done(tc_icp_shard *s, int *done) try {
 tc_status tc_icp_shard_reduce(tc_icp_shard *s) try {
     tc_context *ctx = s->ctx;
     uint32_t *corr = (uint32_t *)ctx->corr.p;
-    tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
-                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr + s->ns, corr + 2 * s->ns,
+    tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, s->su.wsrc,
+                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, tc::match_words(s->su.wsrc), corr + 2 * s->ns,
                          (double *)ctx->partials.p, true, false, true);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
@@ -2063,8 +2084,8 @@ tc_status tc_icp_shard_reduce(tc_icp_shard *s) try {
 tc_status tc_icp_shard_apply(tc_icp_shard *s) try {
     tc_context *ctx = s->ctx;
     uint32_t *corr = (uint32_t *)ctx->corr.p;
-    tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, (const float4 *)ctx->src_index.pts.p,
-                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, corr + s->ns, corr + 2 * s->ns,
+    tc::launch_iteration(ctx, s->p2plane, s->su.tv, (const float4 *)ctx->tgt_index.normals.p, s->su.wsrc,
+                         (uint32_t)s->ns, s->su.l, (tc::IcpState *)ctx->state.p, tc::match_words(s->su.wsrc), corr + 2 * s->ns,
                          (double *)ctx->partials.p, false, true, false);
     TC_HIP_TRY(ctx, hipGetLastError());
     return TC_OK;
@@ -2082,7 +2103,7 @@ tc_status tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *
     if (res->corr_target) {
         uint32_t *corr = (uint32_t *)ctx->corr.p;
         hipLaunchKernelGGL(tc::icp_write_corr_kernel, dim3((unsigned)((s->ns + 255) / 256)), dim3(256), 0, st, s->su.tv,
-                           (const float4 *)ctx->src_index.pts.p, (uint32_t)s->ns, corr + s->ns, corr);
+                           (const float4 *)ctx->src_index.pts.p, (uint32_t)s->ns, tc::match_words(s->su.wsrc), corr);
         TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, s->ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     }
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -171,6 +171,8 @@ struct tc_context {
     tc::DevBuf partials;            // double * kMaxPartialBlocks * TC_ICP_SUMS_STRIDE
     tc::DevBuf corr;                // u32 * n_source
     tc::DevBuf gicp_src_cov;        // GICP: source covariances in the sorted source order (2 float4 per point)
+    tc::DevBuf icp_wsrc;            // float4 * n_source: the ICP loop's working copy of the ordered source: x, y, z + the position of the
+                                    // current match in w (one 16-byte read per point and iteration instead of record + match)
     tc::DevBuf dbg_times;           // TC_DEBUG & 1024: per-block stamps of the main pass
     tc::DevBuf overflow;            // scratch (voxel filter: occupied-cell flags / output slots)
     tc::DevBuf build_tmp;           // index build: the records in arrival order, before the in-cell re-rank (float4 * n)
