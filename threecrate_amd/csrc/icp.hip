@@ -638,7 +638,9 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             }
             wcnt += __popcll(rmask);
             bool valid = in && !refine && bestg != 0xFFFFFFFFu;
-            if (valid && max_dist >= 0.0f) valid = !(sqrtf(best) > max_dist);   // registration.rs:100-101
+            // registration.rs:100-101.  A real (scalar) branch on the wave-uniform cut-off: if-converted, the correctly rounded sqrt
+            // -- a dozen instructions per point -- ran in every call without a cut-off (the empty asm keeps it from being speculated)
+            if (max_dist >= 0.0f) { asm volatile(""); if (valid) valid = !(sqrtf(best) > max_dist); }
             const uint32_t newv = valid ? bestg : 0xFFFFFFFFu;
             if (j < end && !refine && (!warm || newv != pj)) reinterpret_cast<uint32_t *>(wsrc)[4 * (size_t)j + 3] = newv;     // an unchanged match is not written again
             mv[u] = (dbg & 16) ? 0xFFFFFFFFu : newv;                             // dbg & 16: timing experiments only (no sums)
