@@ -295,7 +295,8 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     // the +inf padding behind the array), harmless as extra candidates.  Rows are visited in ascending
     // order = ascending position, so the strict '<' keeps the lowest position among equal distances.
     const __amdgpu_buffer_rsrc_t pt_rsrc = raw_rsrc(pts12);
-    const f32x2 qxy = {x, y};
+    // the query as the three register PAIRS the twelve words of a step pair up with (see the loop): (x, y), (z, x), (y, z)
+    const f32x2 qxy = {x, y}, qzx = {z, x}, qyz = {y, z};
     best = INFINITY;
     bestj = 0xFFFFFFFFu;
     // The span change is a select inside ONE divergent loop -- a lane leaves when its last span ends; the next span is fetched
@@ -317,16 +318,23 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         // bytes = THREE 16-byte reads (dword aligned) instead of four 12-byte reads of the 16-byte records.  The pass is bound by L1
         // look-ups -- one per lane and read instruction, whatever its width: round 5, profiles/r05_ab_pack12.txt: 42.9 -> 40.5 us
         // per moving-phase pass, the cold first pass 57 -> 51 us, whole job +2.9 %.  Same bits (same coordinates, same order).
-        const uint32_t o = j * 12u;                     // (positions < 2^28: below 2^32)
-        const u32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o, 0, 0);
-        const u32x4 rb = __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 16u, 0, 0);
-        const u32x4 rc = __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 32u, 0, 0);
-        const f32x3 c0 = {__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z)};
-        const f32x3 c1 = {__uint_as_float(ra.w), __uint_as_float(rb.x), __uint_as_float(rb.y)};
-        const f32x3 c2 = {__uint_as_float(rb.z), __uint_as_float(rb.w), __uint_as_float(rc.x)};
-        const f32x3 c3 = {__uint_as_float(rc.y), __uint_as_float(rc.z), __uint_as_float(rc.w)};
-        const float v0 = d2_packed(c0, qxy, z), v1 = d2_packed(c1, qxy, z);
-        const float v2 = d2_packed(c2, qxy, z), v3 = d2_packed(c3, qxy, z);
+        // 12 j by two full-rate instructions (v_mul_lo_u32 is quarter rate, and the compiler re-forms it from shifts); j < 2^28
+        uint32_t o;
+        asm("v_lshlrev_b32 %0, 2, %1\n\tv_lshl_add_u32 %0, %1, 3, %0" : "=&v"(o) : "v"(j));
+        const f32x4 ra = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o, 0, 0));
+        const f32x4 rb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 16u, 0, 0));
+        const f32x4 rc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 32u, 0, 0));
+        // The twelve words x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3 arrive in six aligned register pairs: (x0, y0) (z0, x1) (y1, z1)
+        // (x2, y2) (z2, x3) (y3, z3).  Differences and squares are taken on THOSE pairs (packed f32 against the matching query pair),
+        // the sums are scalar: no register moves to line candidates up (the compiler's own pairing of the per-candidate form cost 13
+        // v_mov per step).  Per candidate the operations and their order are d2_nc's: (dx*dx + dy*dy) + dz*dz, no contraction.
+        const f32x2 d0 = ra.xy - qxy, d1 = ra.zw - qzx, d2 = rb.xy - qyz, d3 = rb.zw - qxy, d4 = rc.xy - qzx, d5 = rc.zw - qyz;
+        const f32x2 s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3, s4 = d4 * d4, s5 = d5 * d5;
+        // (scalar adds spelled as instructions: left to itself the SLP vectoriser packs these eight adds into four v_pk_add_f32 and
+        // pays nine v_mov to pair their operands up)
+        auto add = [](float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+        const float v0 = add(add(s0.x, s0.y), s1.x), v1 = add(add(s1.y, s2.x), s2.y);
+        const float v2 = add(add(s3.x, s3.y), s4.x), v3 = add(add(s4.y, s5.x), s5.y);
         const bool b01 = v1 < v0, b23 = v3 < v2;
         const float m01 = b01 ? v1 : v0, m23 = b23 ? v3 : v2;
         const uint32_t i01 = b01 ? j + 1 : j, i23 = b23 ? j + 3 : j + 2;

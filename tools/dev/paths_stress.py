@@ -92,7 +92,11 @@ def main():
                     # another grid: an exact distance tie between points of different cells is broken by position, i.e. by the grid
                     # (the reference's own tie order is its heap's); a handful of rows per million may pick the other neighbour
                     if what == "T": ok = np.allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=0, atol=1e-6 * max(1.0, ext))
-                    elif what == "mse": ok = abs(float(a) - float(b)) <= 1e-4 * max(float(a), 1e-30) + 1e-10 * ext * ext      # (a converged noise-free pair: mse ~ rounding)
+                    # (a converged noise-free pair: mse ~ rounding.  A run stopped WHILE it converges -- the mse falling 10-50x per
+                    # iteration -- returns the mse measured under the previous iteration's transform, and the two roads' transforms
+                    # differ by up to ~2e-5 there (another grid = another tie order = another trajectory; they meet again at 1e-7):
+                    # d mse ~ 2 sqrt(mse) |dT| extent.  tools/dev/paths_case.py replays a case iteration by iteration; campaign 501.)
+                    elif what == "mse": ok = abs(float(a) - float(b)) <= 1e-4 * max(float(a), 1e-30) + 1e-10 * ext * ext + 2.0 * float(a) ** 0.5 * 3e-5 * ext
                     else:
                         rows = (np.asarray(a) != np.asarray(b)).reshape(len(a), -1).any(1).sum()
                         ties += int(rows)
