@@ -225,7 +225,7 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
                                                  ) {
     const GridGeom &g = gv.g;
     int cx, cy, cz;
-    float mf, out2;
+    float out2;
     const float qx = fminf(fmaxf(x, g.minx), g.maxx), qy = fminf(fmaxf(y, g.miny), g.maxy),
                 qz = fminf(fmaxf(z, g.minz), g.maxz);
     cx = cell_coord(qx, g.minx, g.inv_h, g.gx);
@@ -233,17 +233,6 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
     cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
     const float fx = (qx - g.minx) * g.inv_h - (float)cx, fy = (qy - g.miny) * g.inv_h - (float)cy,
                 fz = (qz - g.minz) * g.inv_h - (float)cz;
-    // clearance of q' to the ring-1 block's faces, in cell edges: only a face with cells BEYOND it counts (where the grid ends at or
-    // before the block's face nothing unscanned lies on that side -- a query outside the target's box sits ON the box face:
-    // counting that face made its clearance 0 and sent most of the 6 % of the benchmark's source points that are outside the
-    // target's box to the refine pass)
-    {
-        const float big = 1.0e30f;
-        const float lx = cx >= 2 ? fx : big, hx = cx <= g.gx - 3 ? 1.0f - fx : big;
-        const float ly = cy >= 2 ? fy : big, hy = cy <= g.gy - 3 ? 1.0f - fy : big;
-        const float lz = cz >= 2 ? fz : big, hz = cz <= g.gz - 3 ? 1.0f - fz : big;
-        mf = fmaxf(fminf(fminf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz)), 0.0f);
-    }
     out2 = outside_d2(x, y, z, qx, qy, qz, g.clamped);
     // squared distance (shaved by the cell-assignment fuzz) from q' to the neighbouring slabs
     const float lo_x = fmaxf(fx - 2e-3f, 0.0f) * g.h, hi_x = fmaxf(1.0f - fx - 2e-3f, 0.0f) * g.h;
@@ -352,10 +341,26 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         mask = adv ? (mask & (mask - 1u)) : mask;
     }
     TC_STAMP(2);
-    const bool covers = (cx - 1 <= 0) && (cx + 1 >= g.gx - 1) && (cy - 1 <= 0) && (cy + 1 >= g.gy - 1) &&
-                        (cz - 1 <= 0) && (cz + 1 >= g.gz - 1);
-    const float bound = (1.0f + mf - 2e-3f) * g.h;
-    refine = !(covers || best <= bound * bound + out2 || (max_dist >= 0.0f && bound > max_dist));
+    // Ring-1 exactness rule: best <= ((1 + m_f - 2e-3) h)^2 + |q - q'|^2, m_f >= 0 the clearance of q' to the block's faces.  Nearly
+    // every lane passes it with m_f = 0 already (the nearest neighbour lies within one cell edge): only the others form the
+    // clearance -- a real branch, skipped by the whole wave in most trips (~35 instructions of selects and minima per trip).
+    const float h0 = (1.0f - 2e-3f) * g.h;
+    refine = false;
+    if (!(best <= h0 * h0 + out2) && !(ub2 < 0.0f)) {          // (ub2 < 0: a lane that does not search -- its flag is ignored anyway)
+        // clearance of q' to the ring-1 block's faces, in cell edges: only a face with cells BEYOND it counts (where the grid ends at
+        // or before the block's face nothing unscanned lies on that side -- a query outside the target's box sits ON the box face:
+        // counting that face made its clearance 0 and sent most of the 6 % of the benchmark's source points that are outside the
+        // target's box to the refine pass)
+        const float big = 1.0e30f;
+        const float lx = cx >= 2 ? fx : big, hx = cx <= g.gx - 3 ? 1.0f - fx : big;
+        const float ly = cy >= 2 ? fy : big, hy = cy <= g.gy - 3 ? 1.0f - fy : big;
+        const float lz = cz >= 2 ? fz : big, hz = cz <= g.gz - 3 ? 1.0f - fz : big;
+        const float mf = fmaxf(fminf(fminf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz)), 0.0f);
+        const bool covers = (cx - 1 <= 0) && (cx + 1 >= g.gx - 1) && (cy - 1 <= 0) && (cy + 1 >= g.gy - 1) &&
+                            (cz - 1 <= 0) && (cz + 1 >= g.gz - 1);
+        const float bound = (1.0f + mf - 2e-3f) * g.h;
+        refine = !(covers || best <= bound * bound + out2 || (max_dist >= 0.0f && bound > max_dist));
+    }
 }
 
 // per-pair terms -> per-lane f32 accumulators (shared by the main and the refine kernel)
