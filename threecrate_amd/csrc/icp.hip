@@ -368,7 +368,10 @@ template <bool P2PLANE, int NACC>
 __device__ __forceinline__ void accumulate_pair(const GridGeom &g, float (&acc)[NACC], float x, float y, float z,
                                                 const float4 &c, const float4 &n) {
     if (P2PLANE) {
-        // registration.rs:417-427 in f32: c = s x n ; a = [c, n] ; b = n . (d - s)
+        // registration.rs:417-427 in f32: c = s x n ; a = [c, n] ; b = n . (d - s) -- the pair's terms as the reference forms them.
+        // Their products go into the lane's sums by FMA (round 5): the reference adds its pairs one after the other in f32, these
+        // sums are per lane, then f64 -- another order either way --, so a product that is not rounded on its own is one rounding
+        // less, not a departure; 28 instructions per pair instead of 56.
         const float a[6] = {y * n.z - z * n.y, z * n.x - x * n.z, x * n.y - y * n.x, n.x, n.y, n.z};
         const float dx = c.x - x, dy = c.y - y, dz = c.z - z;
         const float b = n.x * dx + n.y * dy + n.z * dz;
@@ -376,10 +379,10 @@ __device__ __forceinline__ void accumulate_pair(const GridGeom &g, float (&acc)[
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int cc = r; cc < 6; ++cc) { acc[o] += a[r] * a[cc]; ++o; }
+            for (int cc = r; cc < 6; ++cc) { acc[o] = __builtin_fmaf(a[r], a[cc], acc[o]); ++o; }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * b;
-        acc[27] += b * b;
+        for (int r = 0; r < 6; ++r) acc[21 + r] = __builtin_fmaf(a[r], b, acc[21 + r]);
+        acc[27] = __builtin_fmaf(b, b, acc[27]);
         acc[28] += 1.0f;
     } else {
         // shifted by the target bbox centre so that H = sum s q^T - n ms mq^T does not cancel
@@ -387,9 +390,9 @@ __device__ __forceinline__ void accumulate_pair(const GridGeom &g, float (&acc)[
         const float tx = c.x - g.cx, ty = c.y - g.cy, tz = c.z - g.cz;
         acc[0] += sx; acc[1] += sy; acc[2] += sz;
         acc[3] += tx; acc[4] += ty; acc[5] += tz;
-        acc[6] += sx * tx;  acc[7] += sx * ty;  acc[8] += sx * tz;
-        acc[9] += sy * tx;  acc[10] += sy * ty; acc[11] += sy * tz;
-        acc[12] += sz * tx; acc[13] += sz * ty; acc[14] += sz * tz;
+        acc[6] = __builtin_fmaf(sx, tx, acc[6]);   acc[7] = __builtin_fmaf(sx, ty, acc[7]);   acc[8] = __builtin_fmaf(sx, tz, acc[8]);
+        acc[9] = __builtin_fmaf(sy, tx, acc[9]);   acc[10] = __builtin_fmaf(sy, ty, acc[10]); acc[11] = __builtin_fmaf(sy, tz, acc[11]);
+        acc[12] = __builtin_fmaf(sz, tx, acc[12]); acc[13] = __builtin_fmaf(sz, ty, acc[13]); acc[14] = __builtin_fmaf(sz, tz, acc[14]);
         const float ex = x - c.x, ey = y - c.y, ez = z - c.z;          // registration.rs:214
         acc[15] += ex * ex + ey * ey + ez * ez;
         acc[16] += 1.0f;
