@@ -1,0 +1,7 @@
+cd "$GRAFT_REPO_ROOT"
+for rep in 1 2; do
+for v in default noslpall; do
+  lib=""; [ "$v" != default ] && lib="$GRAFT_REPO_ROOT/threecrate_amd/variants/libthreecrate_hip_$v.so"
+  TC_HIP_LIB=$lib timeout 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-copy-probe 2>/dev/null | tail -1 | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$v', 'it/s %.0f' % d['value'], 'icp-only %.0f' % d['icp_only_it_per_s'], 'normals Mpts/s %.0f' % d['normals_mpts_per_s'], 'normals kernel us', d['normals_roofline']['avg_launch_us'], 'tum', d['tum_pair']['value'], d['tum_pair']['roofline']['normals_kernel_us'], 'stream', d['frame_stream']['value'], 'sharded', d['sharded_10m']['value'])"
+done; done

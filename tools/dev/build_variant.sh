@@ -15,7 +15,7 @@ pids=()
 for spec in $FILES; do
   # "icp" compiles csrc/icp.hip; "icp=/some/other/icp.hip" compiles that file in its place (e.g. an older revision: git show REV:path > file)
   f=${spec%%=*}; src="$SRC/$f.hip"; [ "$spec" != "$f" ] && src=${spec#*=}
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result -I"$SRC" $EXTRA -c "$src" -o "$OBJ/$f.o" &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -Wall -Wno-unused-result -I"$SRC" $EXTRA -c "$src" -o "$OBJ/$f.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
