@@ -1577,6 +1577,10 @@ static TileGeom plan_tiles(const GridGeom &g, size_t ns) {
     const double want = 256.0 / std::max(rho, 1e-6);      // cells per tile
     static const int cand[][3] = {{8, 2, 2}, {8, 3, 2}, {8, 3, 3}, {8, 4, 3}, {8, 4, 4}, {8, 5, 4}, {8, 5, 5}, {8, 6, 5},
                                   {8, 6, 6}, {10, 6, 6}, {12, 6, 6}, {16, 6, 6}, {16, 8, 8}, {4, 2, 2}, {4, 2, 1}, {2, 2, 1}};
+    if (const char *e = getenv("TC_ICP_TILE")) {          // experiments: "tx,ty,tz"
+        int a = 0, b = 0, c = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) return make_tiles(g, a, b, c);
+    }
     int best = 0; double bd = 1e300;
     for (int i = 0; i < (int)(sizeof(cand) / sizeof(cand[0])); ++i) {
         const double c = (double)cand[i][0] * cand[i][1] * cand[i][2];
