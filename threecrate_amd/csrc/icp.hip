@@ -672,7 +672,9 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             for (int u = 0; u < kIcpGroup; ++u) {
                 const uint32_t m = mv[u] != 0xFFFFFFFFu ? mv[u] : 0u;
                 cv[u] = pv[u];
-                if (mv[u] != pjv[u]) { const f32x3 t3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(raw_rsrc(tgt.pts), m << 4, 0, 0));
+                // (a changed match's record comes from the PACKED copy the candidate loop has just read it from -- a line that is in L1 --
+                // not from the 16-byte records, which the pass then does not touch at all: one array less in the caches)
+                if (mv[u] != pjv[u]) { const f32x3 t3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(raw_rsrc(pts12), (m << 3) + (m << 2), 0, 0));
                                        cv[u] = make_float4(t3.x, t3.y, t3.z, 0.0f); }
                 nv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (MODE == 1) { const f32x3 t3 = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(raw_rsrc(tgt_nrm), m << 4, 0, 0));
