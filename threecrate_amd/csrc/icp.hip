@@ -218,6 +218,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *p) {
 #define TC_STAMP_ARGS
 #define TC_STAMP_PASS
 #endif
+#ifndef TC_ICP_STEP
+#define TC_ICP_STEP 4          // records per candidate step
+#endif
 template <bool STATS = false>
 __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, float y, float z, float ub2,
                                                  float &best, uint32_t &bestj, bool &refine, float max_dist,
@@ -310,30 +313,37 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         // 12 j by two full-rate instructions (v_mul_lo_u32 is quarter rate, and the compiler re-forms it from shifts); j < 2^28
         uint32_t o;
         asm("v_lshlrev_b32 %0, 2, %1\n\tv_lshl_add_u32 %0, %1, 3, %0" : "=&v"(o) : "v"(j));
+        auto add = [](float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+        // four records = three 16-byte registers -> the smallest of their four distances and its position (lowest on ties)
+        auto quad = [&](const f32x4 &ra, const f32x4 &rb, const f32x4 &rc, uint32_t jb, float &m, uint32_t &im) {
+            const f32x2 d0 = ra.xy - qxy, d1 = ra.zw - qzx, d2 = rb.xy - qyz, d3 = rb.zw - qxy, d4 = rc.xy - qzx, d5 = rc.zw - qyz;
+            const f32x2 s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3, s4 = d4 * d4, s5 = d5 * d5;
+            const float v0 = add(add(s0.x, s0.y), s1.x), v1 = add(add(s1.y, s2.x), s2.y);
+            const float v2 = add(add(s3.x, s3.y), s4.x), v3 = add(add(s4.y, s5.x), s5.y);
+            const bool b01 = v1 < v0, b23 = v3 < v2;
+            const float m01 = b01 ? v1 : v0, m23 = b23 ? v3 : v2;
+            const uint32_t i01 = b01 ? jb + 1 : jb, i23 = b23 ? jb + 3 : jb + 2;
+            const bool bb = m23 < m01;
+            m = bb ? m23 : m01;
+            im = bb ? i23 : i01;
+        };
         const f32x4 ra = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o, 0, 0));
         const f32x4 rb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 16u, 0, 0));
         const f32x4 rc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 32u, 0, 0));
-        // The twelve words x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3 arrive in six aligned register pairs: (x0, y0) (z0, x1) (y1, z1)
-        // (x2, y2) (z2, x3) (y3, z3).  Differences and squares are taken on THOSE pairs (packed f32 against the matching query pair),
-        // the sums are scalar: no register moves to line candidates up (the compiler's own pairing of the per-candidate form cost 13
-        // v_mov per step).  Per candidate the operations and their order are d2_nc's: (dx*dx + dy*dy) + dz*dz, no contraction.
-        const f32x2 d0 = ra.xy - qxy, d1 = ra.zw - qzx, d2 = rb.xy - qyz, d3 = rb.zw - qxy, d4 = rc.xy - qzx, d5 = rc.zw - qyz;
-        const f32x2 s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3, s4 = d4 * d4, s5 = d5 * d5;
-        // (scalar adds spelled as instructions: left to itself the SLP vectoriser packs these eight adds into four v_pk_add_f32 and
-        // pays nine v_mov to pair their operands up)
-        auto add = [](float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-        const float v0 = add(add(s0.x, s0.y), s1.x), v1 = add(add(s1.y, s2.x), s2.y);
-        const float v2 = add(add(s3.x, s3.y), s4.x), v3 = add(add(s4.y, s5.x), s5.y);
-        const bool b01 = v1 < v0, b23 = v3 < v2;
-        const float m01 = b01 ? v1 : v0, m23 = b23 ? v3 : v2;
-        const uint32_t i01 = b01 ? j + 1 : j, i23 = b23 ? j + 3 : j + 2;
-        const bool bb = m23 < m01;
-        const float m = bb ? m23 : m01;
-        const uint32_t im = bb ? i23 : i01;
+#if TC_ICP_STEP == 8
+        const f32x4 rd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 48u, 0, 0));
+        const f32x4 re = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 64u, 0, 0));
+        const f32x4 rf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 80u, 0, 0));
+#endif
+        float m; uint32_t im;
+        quad(ra, rb, rc, j, m, im);
+#if TC_ICP_STEP == 8
+        { float m2; uint32_t im2; quad(rd, re, rf, j + 4, m2, im2); const bool b2 = m2 < m; m = b2 ? m2 : m; im = b2 ? im2 : im; }
+#endif
         const bool upd = m < best;
         best = upd ? m : best;
         bestj = upd ? im : bestj;
-        j += 4;
+        j += TC_ICP_STEP;
         if constexpr (STATS) ++nsteps;              // (candidate steps of this lane: only in the counting instantiation of the kernel)
         const bool adv = j >= e && mask != 0u;
         j = adv ? nse.x : j;
@@ -519,6 +529,20 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     unsigned long long t_begin = 0;
     if (blk_times) t_begin = __builtin_amdgcn_s_memrealtime();          // TC_DEBUG & 1024: per-block start / end stamps (100 MHz)
     constexpr int NACC = MODE == 0 ? TC_ICP_SUMS_P2P : TC_ICP_SUMS_P2PLANE;
+    // The block's first group of source records is REQUESTED before the state header is waited for (round 5): the header was
+    // written by the previous launch's one-block solve, its read is served from beyond this XCD's L2 like the records' -- two
+    // round trips in a row at the head of every block of a 32 us launch.  (A finished registration's launches read 16 KB per block
+    // for nothing: they are not on any timed path.)
+    const uint32_t lb = xcd_remap_icp(blockIdx.x, gridDim.x);
+    const uint32_t beg = lb * chunk;
+    const uint32_t end = min(beg + chunk, ns);
+    u32x4 first[kIcpGroup];
+#pragma unroll
+    for (int u = 0; u < kIcpGroup; ++u) {
+        const uint32_t j = beg + u * kIcpBlock + threadIdx.x;
+        first[u] = __builtin_amdgcn_raw_buffer_load_b128(raw_rsrc(wsrc), (j < end ? j : min(beg, ns - 1)) << 4, 0, 0);
+    }
+    asm volatile("" ::: "memory");          // (the compiler otherwise sinks the four reads below the header's wait and the early return)
     const IcpHeader hd = load_header(st);
     if (hd.done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
@@ -547,9 +571,6 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     // NOT the work: spreading every block's four 256-point sub-chunks over its XCD's whole slab left it unchanged (p10 / p50 / max
     // 39.8 / 42.9 / 49.2 us), the eight XCDs finish within 2 us of each other; it is how blocks share a CU.  Smaller blocks in
     // several rounds lose more than the tail gives back (512 points per block: 48.7 us, 256: 55.6 us vs 46.9 us).
-    const uint32_t lb = xcd_remap_icp(blockIdx.x, gridDim.x);
-    const uint32_t beg = lb * chunk;
-    const uint32_t end = min(beg + chunk, ns);
 #ifdef TC_PHASE_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
 #endif
@@ -571,7 +592,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
                 // ONE 16-byte read per point: the source record and, in its w, the position of the previous match (the loop's working
                 // copy of the source, icp_working_source_kernel: round 5 -- a read instruction less per point, 4 of ~23; the pass is
                 // bound by look-ups per lane and read instruction, profiles/r05_ab_pack12.txt)
-                { const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(raw_rsrc(wsrc), (in ? j : beg) << 4, 0, 0);
+                { const u32x4 t4 = first[u];
                   sv[u] = make_float4(__uint_as_float(t4.x), __uint_as_float(t4.y), __uint_as_float(t4.z), __uint_as_float(t4.w)); }
                 uint32_t pj = __float_as_uint(sv[u].w);        // (0xFFFFFFFF before iteration 1)
                 if (!warm || !in) pj = 0xFFFFFFFFu;
@@ -701,6 +722,14 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
         // per-group fold: transposing wave reduction (f32, fixed tree) -> this wave's f64 row
         wave_fold_transposed<NACC>(acc, red[w], lane);
         TC_STAMP(5);
+        // the next group's source records (blocks of more than one group: the 10 M-point loop), requested where nothing else is live
+        if (gb + kIcpGroup * kIcpBlock < end) {
+#pragma unroll
+            for (int u = 0; u < kIcpGroup; ++u) {
+                const uint32_t j = gb + (kIcpGroup + u) * kIcpBlock + threadIdx.x;
+                first[u] = __builtin_amdgcn_raw_buffer_load_b128(raw_rsrc(wsrc), (j < end ? j : beg) << 4, 0, 0);
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
@@ -731,7 +760,10 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
 // and the shell enumeration of ring 2 is compile-time.  Per-block sums go to the partial rows after
 // the main pass's rows.
 constexpr int kRefineThreads = 1024;
-constexpr int kRG = 32;                     // lanes per query (measured on the benchmark: 16 lanes 15.0 us, 64 lanes 13.0 us, 32: 11.8 us)
+#ifndef TC_REFINE_LANES
+#define TC_REFINE_LANES 32
+#endif
+constexpr int kRG = TC_REFINE_LANES;                     // lanes per query (measured on the benchmark: 16 lanes 15.0 us, 64 lanes 13.0 us, 32: 11.8 us)
 constexpr int kRB = 4;                      // shell cells per lane and batch
 
 __device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v) {
@@ -1029,6 +1061,16 @@ __global__ void __launch_bounds__(kRefineThreads) icp_refine_kernel(
         // start: the best real point the main pass knows (previous match or its ring-1 result, with its distance); ring 1 is done
         unsigned long long bestkey = ~0ull;
         if (pj != 0xFFFFFFFFu) bestkey = ((unsigned long long)e1.x << 32) | pj;
+        // A query that arrives WITH a candidate (its previous match or ring-1 best: all but the first iteration's) goes straight to
+        // the ball of that distance (round 5): entry -> row windows -> records -> winner, four dependent round trips, where ring 2
+        // first and then the ball took six.  The ball includes rings 0 and 1 again -- the same points, the same (distance, position)
+        // keys -- which costs reads on an idle chip, not time: the pass 10.0 -> 9.0 us on average (moving phase 11.7 -> 10.4),
+        // profiles/r05_refine_pass.txt.  -DTC_REFINE_SHELLS_FIRST: the former order (A/B).
+#ifndef TC_REFINE_SHELLS_FIRST
+        if (bestkey != ~0ull && !dbg_shells)
+            bestkey = refine_ball_scan(tgt, cs_rsrc, pt_rsrc, lg, x, y, z, bestkey, max_dist >= 0.0f ? max_dist * max_dist * 1.0001f : INFINITY);
+        else
+#endif
         for (int R = 2;; ++R) {
             bool touched;
             const unsigned long long lk = (R == 2) ? refine_shell<2>(tgt, cs_rsrc, pt_rsrc, 2, lg, x, y, z, cx, cy, cz, bestkey, touched)
