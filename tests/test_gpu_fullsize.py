@@ -195,16 +195,27 @@ def test_config3_ten_million_points_through_the_sharded_entry(ctx):
         sample = rng.choice(n, 3000, replace=False)
         idx, dist, cnt = O.knn_batch(tgt, tgt[sample], k + 1)
         assert (cnt == k + 1).all()
-        worst = 0.0
+        worst, identical = 0.0, 0
         for row, i in enumerate(sample):
             nb = [int(j) for j in idx[row] if int(j) != i][:k] + [int(i)]                # normals.rs:147-153, :338-340
             P = tgt[nb].astype(np.float32)
+            # the oracle's OWN arithmetic on this neighbourhood: the k + 1 points as a cloud of their own, the query first -- its k
+            # nearest there are the same points in the same ascending order, so its row is normals.rs:158-222 on that list (f32
+            # centroid, covariance, nalgebra's symmetric_eigen order); the sign is the small cloud's viewpoint rule, not compared
+            on = O.estimate_normals(np.ascontiguousarray(tgt[[int(i)] + nb[:k]]), k=k)[0, 3:]
+            same = np.array_equal(on, g[i, 3:]) or np.array_equal(-on, g[i, 3:])
+            identical += int(same)
+            if same:
+                continue
             c = P.mean(0, dtype=np.float64)
             ev, q = np.linalg.eigh(np.cov((P - c).T.astype(np.float64), bias=True))
             cs = abs(float(np.dot(q[:, 0], g[i, 3:].astype(np.float64))))
             gap = (ev[1] - ev[0]) / max(ev[2], 1e-300)
             if gap > h1.EIGEN_GAP_BOUND:
                 worst = max(worst, 1.0 - cs)
+        # bit for bit the oracle's normal on (nearly) the whole sample -- a tie in the neighbour order may part a row, which then has
+        # to agree with the f64 eigenvector of its neighbourhood
+        assert identical >= 0.995 * len(sample), identical
         assert worst <= 1e-4, worst
         # the registration: 50 iterations through tc_sharded_icp_point_to_plane_device, correspondences gathered
         a = D.sharded_icp_point_to_plane(ctx, ds, dt, nrm, None, 50, None, 0.0, comm=comm, correspondences=True)
