@@ -237,5 +237,15 @@ def test_config3_ten_million_points_through_the_sharded_entry(ctx):
         bf = D.HipShardBackend(ctx, ds, dt, nrm, O.IDENTITY, None, 0.0)
         sf = bf.reduce().clone(); bf.finish(1)
         assert float(sf[28]) == n and float((s1 + s2 - sf).abs().max()) <= 1e-7 * float(sf.abs().max())
+        # ... and it is the ORACLE's system: 200 000 source points of this pair against the kd-tree of all 10 M target points
+        # (registration.rs:395-428 through tco_p2plane_partial), first iteration, the device's normals -- every pair found, the 29
+        # sums equal up to the order of the f32 additions
+        tree = O.KdTree(tgt)
+        j0, j1 = 4_000_000, 4_200_000
+        so, _ = O.p2plane_partial(src, j0, j1, tree, np.ascontiguousarray(g[:, 3:]), O.IDENTITY)
+        bs = D.HipShardBackend(ctx, ds[j0:j1], dt, nrm, O.IDENTITY, None, 0.0)
+        sd = bs.reduce().clone().cpu().numpy(); bs.finish(1)
+        assert sd[28] == so[28] == j1 - j0
+        assert np.abs(sd[:29] - so).max() <= 1e-5 * np.abs(so).max(), (sd[:29], so)
     finally:
         comm.close()
