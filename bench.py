@@ -728,10 +728,13 @@ def main():
             ss = ctx.search_stats()
             ctx.profile_enable(0)
             st_t.close(); st_s.close()
-            assert rs.iterations == ICP_ITERS and np.array_equal(rs.transformation, last.transformation) and ss["iterations"] == ICP_ITERS
+            # (the timed calls of --plain-calls build their own index -- another cell edge than the handles' shared one: exact distance
+            # ties between points of different cells may resolve the other way there, the transform agrees to 1e-6, not bit for bit)
+            same = np.allclose(rs.transformation, last.transformation, atol=1e-5) if args.plain_calls else np.array_equal(rs.transformation, last.transformation)
+            assert rs.iterations == ICP_ITERS and same and ss["iterations"] == ICP_ITERS
             icp_call_s = ti / args.steps                               # one timed 50-iteration call (set-up included)
             out["search"] = {
-                "source": "one 50-iteration registration of the timed pair with the counting instantiation of the main pass (outside the timed region; same transform bit for bit)",
+                "source": "one 50-iteration registration of the timed pair with the counting instantiation of the main pass (outside the timed region; " + ("the transform of the timed plain calls to 1e-5: another index" if args.plain_calls else "same transform bit for bit") + ")",
                 "candidates_per_query": ss["candidates_per_search"],                       # target records read per search (4 per candidate step)
                 "candidates_per_point_iteration": ss["distance_evaluations"] / (n * ICP_ITERS),
                 "searches_per_point_iteration": ss["searches"] / (n * ICP_ITERS),
