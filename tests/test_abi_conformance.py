@@ -130,6 +130,52 @@ def test_rust_shim_covers_the_header_and_the_reference_names():
     assert sorted(c_decl) == sorted(_lib.EXPORTS)
     assert sorted(r_decl) == sorted(c_decl), sorted(set(c_decl) ^ set(r_decl))
     assert r_decl == c_decl, {k: (c_decl[k], r_decl[k]) for k in c_decl if c_decl[k] != r_decl[k]}
+    # ... and with the same TYPES, parameter by parameter and for the return value: what a `bindgen` run + a Rust compile would check
+    # (a C type maps to exactly one Rust spelling below; pointers to the opaque / repr(C) structs keep their names)
+    hdr_nc = re.sub(r"//[^\n]*", "", hdr)
+
+    def c2r(t):
+        toks = t.replace("*", " * ").split()
+        base_const = toks[0] == "const"
+        toks = toks[1:] if base_const else toks
+        cut = toks.index("*") if "*" in toks else len(toks)
+        base, ptrs = " ".join(toks[:cut]), toks[cut:]
+        prim = {"float": "f32", "double": "f64", "int": "c_int", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8",
+                "size_t": "usize", "char": "c_char", "void": "c_void", "unsigned long long": "u64", "tc_status": "c_int",
+                "tc_host_collective_fn": "tc_host_collective_fn"}
+        r = prim.get(base, base)                     # tc_* struct names are spelled alike on both sides
+        pointee_const = base_const
+        i = 0
+        while i < len(ptrs):                         # `*` [const]: a pointer whose Rust mutability is its POINTEE's constness
+            assert ptrs[i] == "*", t
+            r = ("*const " if pointee_const else "*mut ") + r
+            pointee_const = i + 1 < len(ptrs) and ptrs[i + 1] == "const"
+            i += 2 if pointee_const else 1
+        return r
+
+    def c_sig(ret, args):
+        out = []
+        args = args.strip()
+        for prm in ([] if args in ("", "void") else args.split(",")):
+            prm = " ".join(prm.split())
+            m = re.match(r"^(.*?)([A-Za-z_][A-Za-z0-9_]*)(\[[A-Za-z0-9_]*\])?$", prm)
+            ty = m.group(1).strip() + (" *" if m.group(3) else "")       # an array parameter is a pointer
+            out.append(c2r(ty))
+        ret = " ".join(ret.split())
+        return out, ("" if ret == "void" else c2r(ret))
+
+    def r_sig(args, ret):
+        norm = lambda t: " ".join(t.split()).replace("std::os::raw::", "")
+        prms = [norm(x.split(":", 1)[1]) for x in args.split(",") if x.strip()]
+        return prms, norm((ret or "").replace("->", ""))
+
+    c_full = {m.group(2): c_sig(m.group(1), m.group(3))
+              for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(tc_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", hdr_nc)}
+    r_full = {m.group(1): r_sig(m.group(2), m.group(3))
+              for m in re.finditer(r"pub fn (tc_[a-z0-9_]+)\s*\(([^()]*)\)\s*(->\s*[^;]+)?;", ffi)}
+    assert sorted(c_full) == sorted(r_full) == sorted(c_decl)
+    bad = {k: (c_full[k], r_full[k]) for k in c_full if c_full[k] != r_full[k]}
+    assert not bad, bad
     # the reference's names on this path: threecrate-algorithms normals.rs:238-380, registration.rs:232-789, gicp.rs:100, kiss_icp.rs:183,
     # filtering.rs:38; threecrate-gpu lib.rs re-exports (normals.rs:443, icp.rs:977-1036, filtering.rs:908, nearest_neighbor.rs:332-367)
     wanted = ["estimate_normals", "estimate_normals_with_config", "estimate_normals_radius", "icp", "icp_detailed", "icp_point_to_point",
