@@ -121,11 +121,12 @@ ProfScope::ProfScope(tc_context *c, const char *name, bool dominant) : ctx(c) {
         return e;
     };
     e0 = get(); e1 = get();
-    (void)hipEventRecord(e0, ctx->stream);
+    ext = dominant;                                   // (the launch records both events itself: see the struct)
+    if (!ext) (void)hipEventRecord(e0, ctx->stream);
 }
 ProfScope::~ProfScope() {
     if (idx < 0) return;
-    (void)hipEventRecord(e1, ctx->stream);
+    if (!ext) (void)hipEventRecord(e1, ctx->stream);
     ctx->timers[idx].pending.emplace_back(e0, e1);
 }
 

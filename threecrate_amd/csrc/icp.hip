@@ -18,6 +18,7 @@
 // Algorithmic HBM bytes per source point and iteration: 12 src + 12 matched target
 // + 12 matched normal + 4 index out = 40 B (p2plane), 28 B (p2point).
 #include "tc_internal.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1647,9 +1648,14 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
             ProfScope ps(ctx, mode == 1 ? "icp_correspond_reduce_p2plane" : mode == 2 ? "icp_correspond_reduce_gicp" : "icp_correspond_reduce_p2p", true);
             auto kern = mode == 1 ? icp_correspond_reduce_kernel<1> : mode == 2 ? icp_correspond_reduce_kernel<2> : icp_correspond_reduce_kernel<0>;
             if (dbg & 8) kern = mode == 1 ? icp_correspond_reduce_kernel<1, true> : mode == 2 ? icp_correspond_reduce_kernel<2, true> : icp_correspond_reduce_kernel<0, true>;
-            hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, const_cast<float4 *>(src), ns, l.chunk, st, rlist, partials, dbg, src_cov,
-                               (dbg & 4) ? nullptr : vor, (dbg & 1024) ? (unsigned long long *)ctx->dbg_times.p : nullptr,
-                               tv.pts12);
+            const float4 *vor_arg = (dbg & 4) ? nullptr : vor;
+            unsigned long long *times_arg = (dbg & 1024) ? (unsigned long long *)ctx->dbg_times.p : nullptr;
+            if (ps.active())          // a timed launch: the events carry the kernel's own start / end stamps (ProfScope)
+                hipExtLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, ps.e0, ps.e1, 0, tv, nrm, const_cast<float4 *>(src), ns, l.chunk,
+                                      (const IcpState *)st, rlist, partials, dbg, src_cov, vor_arg, times_arg, tv.pts12);
+            else
+                hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, const_cast<float4 *>(src), ns, l.chunk, st, rlist, partials, dbg, src_cov,
+                                   vor_arg, times_arg, tv.pts12);
         }
         ProfScope ps(ctx, "icp_refine");
         auto kern = mode == 1 ? icp_refine_kernel<1> : mode == 2 ? icp_refine_kernel<2> : icp_refine_kernel<0>;

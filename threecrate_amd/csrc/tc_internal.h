@@ -235,11 +235,16 @@ tc_status wait_pinned_word(tc_context *ctx, volatile uint32_t *word, const char 
 // hand a block back to the context's pool (the caller has made sure no work in flight uses it)
 void recycle(tc_context *ctx, DevBuf &b);
 
-// profiling scope: records hipEvents around one kernel launch on ctx->stream
+// profiling scope: records hipEvents around one kernel launch on ctx->stream.
+// A `dominant` scope (the ICP main pass: the kernel of the bench line's roofline) hands its two events to the launch itself
+// (hipExtLaunchKernelGGL(.., e0, e1, ..): they take the kernel's own start and end stamps, no marker packets on the stream -- what
+// rocprofv3's kernel trace reads; events recorded AROUND the launch measured 2.3 us more than the kernel ran and put a bubble on
+// either side of it): the launch site tests active() and launches through launch_timed().
 struct ProfScope {
-    tc_context *ctx; int idx = -1; hipEvent_t e0 = nullptr, e1 = nullptr;
+    tc_context *ctx; int idx = -1; hipEvent_t e0 = nullptr, e1 = nullptr; bool ext = false;
     ProfScope(tc_context *c, const char *name, bool dominant = false);
     ~ProfScope();
+    bool active() const { return idx >= 0; }
 };
 
 // grid.hip

@@ -39,10 +39,13 @@ c = h1.cos_abs(g[:, 3:], r[:, 3:])
 off = np.nonzero(~(c >= 1 - 1e-4))[0]
 tree = O.KdTree(p)
 print(len(off), "offenders")
-shown = 0
+shown = explained_n = 0
 for i in off:
-    ok, why = explain_offender(p, int(i), k, radius, tree)
-    if ok: continue
+    ok, why = explain_offender(p, int(i), k, radius, tree, float(1 - c[i]), g[i, 3:])
+    if ok:
+        explained_n += 1
+        if explained_n <= 2: print(f"explained: point {i}: {why}")
+        continue
     shown += 1
     if shown > 3: break
     print(f"--- point {i} {p[i]} 1-|cos| {1 - c[i]:.3g}: {why}")

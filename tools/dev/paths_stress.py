@@ -91,7 +91,12 @@ def main():
                 if road == "handles" and what in ("T", "mse", "normals", "pairs"):
                     # another grid: an exact distance tie between points of different cells is broken by position, i.e. by the grid
                     # (the reference's own tie order is its heap's); a handful of rows per million may pick the other neighbour
-                    if what == "T": ok = np.allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=0, atol=1e-6 * max(1.0, ext))
+                    # (T: 1e-6 when the two roads chose the same pairs throughout the last iteration; where tie rows differ the roads are
+                    # on two trajectories, a few 1e-6 apart while the registration is still descending -- campaign 504 case 1115: 46 of
+                    # 300 000 rows, |dT| 2.1e-6 after 10 of 10 iterations, tools/dev/paths_case.py prints it iteration by iteration)
+                    if what == "T":
+                        tie_rows = int((np.asarray(ref[4]) != np.asarray(got[4])).reshape(len(ref[4]), -1).any(1).sum()) if len(ref[4]) == len(got[4]) else 0
+                        ok = np.allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=0, atol=(5e-6 if tie_rows else 1e-6) * max(1.0, ext))
                     # (a converged noise-free pair: mse ~ rounding.  A run stopped WHILE it converges -- the mse falling 10-50x per
                     # iteration -- returns the mse measured under the previous iteration's transform, and the two roads' transforms
                     # differ by up to ~2e-5 there (another grid = another tie order = another trajectory; they meet again at 1e-7):

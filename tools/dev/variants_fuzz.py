@@ -83,9 +83,43 @@ def build_case(seed, cases, ctx):
     return dict(tag=tag, src=src, tgt=tgt, init=init, which=which, ext=ext, spacing=spacing, grun=grun, orun=orun, oexact=oexact, kiss_seeded=kiss_seeded, params=params, cfg=cfg)
 
 
+def kiss_parting(cs, ctx):
+    """KISS-ICP case: the first iteration count k at which the device's and the oracle's correspondences differ, and whether
+    every differing row there is a NEAR-TIE -- the source point's distances to the two targets, under the oracle's transform after
+    k - 1 iterations, differ by less than the two sides' transforms moved it apart (they agree to ~1e-6 up to there).  From such a
+    step on the two are different, equally valid trajectories of the same iteration (on a few hundred voxel centroids in a flat
+    valley of the objective they drift apart by 1e-2 within twenty iterations: campaign 504, case 28357).
+    -> (k, rows differing, True) or None when the runs do not part like that."""
+    src, tgt, init, P = cs["src"], cs["tgt"], cs["init"], cs["params"]
+    vs, mx, mn, it = P["vs"], P["mx"], P["mn"], P["it"]
+    d = np.linalg.norm(src.astype(np.float32), axis=1)
+    sd = O.voxel_grid_filter(np.ascontiguousarray(src[(d >= np.float32(mn)) & (d <= np.float32(mx))]), vs)      # kiss_icp.rs:196-214
+    td = tgt                    # (the pairs' target indices address the target as given: kiss_icp.rs matches against the whole map)
+    prevT, prev_gap = (O.IDENTITY if init is None else np.asarray(init, np.float32)), 0.0
+    for k in range(1, it + 1):
+        g = ctx.kiss_icp(src, tgt, init, tc.KissIcpConfig(voxel_size=vs, max_range=mx, min_range=mn, max_iterations=k))
+        r, nd = O.kiss_icp(src, tgt, init, vs, mx, mn, k)
+        if len(g.correspondences) != len(r.correspondences) or nd != len(sd): return None
+        rows = np.nonzero((np.asarray(g.correspondences) != np.asarray(r.correspondences)).any(axis=1))[0]
+        if len(rows):
+            if len(rows) > 3: return None
+            # the pairs of iteration k were chosen under the transform after k - 1 iterations, which the two sides hold prev_gap apart
+            q = O.isometry_apply(prevT, sd).astype(np.float64)
+            slack = 4.0 * (prev_gap + 1e-6) * max(cs["ext"], 1.0)
+            for row in rows:
+                si, tg_, to_ = int(r.correspondences[row][0]), int(g.correspondences[row][1]), int(r.correspondences[row][1])
+                if int(g.correspondences[row][0]) != si or max(tg_, to_) >= len(td) or si >= len(sd): return None
+                dg, do = np.linalg.norm(q[si] - td[tg_]), np.linalg.norm(q[si] - td[to_])
+                if abs(dg - do) > slack: return None
+            return k, len(rows), True
+        if r.converged and g.converged: return None
+        prevT, prev_gap = np.asarray(r.transformation, np.float32), frob(g.transformation, r.transformation)
+    return None
+
+
 def run(budget, seed, ctx, log=print, only_case=None):
     t_end = time.time() + budget
-    cases = bad = noisy = exact = illcond = margin = tiny = 0
+    cases = bad = noisy = exact = illcond = margin = tiny = parted = 0
     while time.time() < t_end:
         cases += 1
         if only_case is not None:
@@ -147,6 +181,12 @@ def run(budget, seed, ctx, log=print, only_case=None):
                 continue
             # what is left, by the size of the smallest cloud a level registers: a handful of voxel centroids (three in a row on a
             # slab) is not a registration problem, the variants' hosts pass it to the same kernels all the same
+            if which == 1:
+                try: part = kiss_parting(cs, ctx)
+                except Exception: part = None
+                if part is not None:
+                    parted += 1
+                    continue
             small = None
             if which == 0: small = min(min(len(O.voxel_grid_filter(src, l[0])), len(O.voxel_grid_filter(tgt, l[0]))) for l in cs["params"]["levels"])
             if which == 1: small = len(O.voxel_grid_filter(src, cs["params"]["vs"]))
@@ -161,7 +201,8 @@ def run(budget, seed, ctx, log=print, only_case=None):
             bad += 1; log("EXCEPTION", tag, type(e).__name__, str(e)[:200])
     log(f"variants fuzz: {cases} cases, {bad} to look at, {noisy} within the oracle's own sensitivity to the order of its input, "
         f"{exact} equal to the oracle with its f32 sums kept in f64, {illcond} with the same stop and a residual no worse than the oracle's (flat direction: near-collinear pairs), "
-        f"{margin} stopping one iteration apart with an equal transform, {tiny} on levels of <= 12 points")
+        f"{margin} stopping one iteration apart with an equal transform, {parted} KISS-ICP runs parted from the oracle at a near-tie pair "
+        f"(identical up to that iteration), {tiny} on levels of <= 12 points")
     return cases, bad
 
 
