@@ -16,7 +16,7 @@ def test_randomized_differential_run(ctx):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     lines = []
-    cases, bad = fuzz.run(15.0, 7, ctx, fuzz.SMALL, log=lambda *a: lines.append(" ".join(map(str, a))))
+    cases, bad = fuzz.run(15.0, 7, ctx, fuzz.SMALL, log=lambda *a: lines.append(" ".join(map(str, a))), min_cases=101)
     assert cases > 100 and bad == 0, "\n".join(lines[-40:])
 
 
@@ -29,7 +29,7 @@ def test_inscribed_ball_test_never_changes_a_result():
     spec = importlib.util.spec_from_file_location("vor_fuzz", os.path.join(os.path.dirname(__file__), "..", "tools", "dev", "vor_fuzz.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    n, bad = mod.compare(12.0, 5)
+    n, bad = mod.compare(12.0, 5, min_cases=10)          # (at least ten registrations however slow the box: up to eight budgets)
     assert n >= 10 and bad == 0
 
 
@@ -45,7 +45,7 @@ def test_loop_control_differential_run(ctx):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     lines = []
-    cases, bad = mod.run(15.0, 11, ctx, log=lambda *a: lines.append(" ".join(map(str, a))))
+    cases, bad = mod.run(15.0, 11, ctx, log=lambda *a: lines.append(" ".join(map(str, a))), min_cases=301)
     assert cases > 300 and bad == 0, "\n".join(lines[-40:])
 
 
@@ -60,5 +60,5 @@ def test_normals_parameter_space_differential_run(ctx):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     lines = []
-    cases, bad = mod.run(15.0, 13, ctx, log=lambda *a: lines.append(" ".join(map(str, a))))
+    cases, bad = mod.run(15.0, 13, ctx, log=lambda *a: lines.append(" ".join(map(str, a))), min_cases=301)
     assert cases > 300 and bad == 0, "\n".join(lines[-40:])

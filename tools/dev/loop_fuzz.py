@@ -131,11 +131,12 @@ def explain_by_replay(grun, orun, src, tgt, init, iters, thr, ext, nrm_t=None):
     return True, "agree at every iteration count"
 
 
-def run(budget, seed, ctx, log=print, only_case=None, max_cases=None):
+def run(budget, seed, ctx, log=print, only_case=None, max_cases=None, min_cases=0):
     """every case draws from its own generator (seed, case number): `only_case` replays one"""
     t_end = time.time() + budget
+    t_hard = t_end + 7 * budget          # (min_cases: a slow or cold box goes on past the budget until it has that many cases)
     cases = bad = borderline = 0
-    while time.time() < t_end and (max_cases is None or cases < max_cases):
+    while (time.time() < t_end or (cases < min_cases and time.time() < t_hard)) and (max_cases is None or cases < max_cases):
         cases += 1
         if only_case is not None:
             if cases > 1: break
