@@ -1467,7 +1467,11 @@ __global__ void __launch_bounds__(kCoopThreads) knn_coop_kernel(GridView gv, con
 // one contiguous eighth of the cell-sorted array (its L2 then holds a contiguous slab + halo).
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
     const uint32_t per = (nb + 7) / 8;
+#ifdef TC_NORMALS_REVERSE
+    const uint32_t lb = (b & 7u) * per + (per - 1u - (b >> 3));          // (A/B: each XCD walks its slab from the far end)
+#else
     const uint32_t lb = (b & 7u) * per + (b >> 3);
+#endif
     return lb;
 }
 
