@@ -31,6 +31,21 @@ while wanted:
     print(f"case {case}: kind {kind} n {len(p)} m {len(src)} k {k} iters {iters} md {md} p2plane {p2plane} ext {ext:.3f}")
     print(f"   plain: mse {float(a[2]):.9e} iterations {a[3]} pairs {len(a[4])} | handles: mse {float(b[2]):.9e} iterations {b[3]} pairs {len(b[4])}")
     print(f"   |dT|max {dT:.3e}  rel mse diff {abs(float(a[2]) - float(b[2])) / max(float(a[2]), 1e-30):.3e}  pair rows differing {rows}  normals rows differing {int((a[0] != b[0]).any(1).sum())}")
+    if rows > 0:            # the rows the two roads resolved differently: the source point's distance to either target under the plain road's transform of the last search
+        from oracle import oracle as O_
+        A, B = np.asarray(a[4]), np.asarray(b[4])
+        idx = np.nonzero((A != B).reshape(len(A), -1).any(1))[0]
+        # (under the transform the last iteration SEARCHED with: the same call stopped one iteration earlier)
+        Tprev = O_.IDENTITY
+        if iters > 1:
+            d_, ds_ = torch.from_numpy(p).cuda(), torch.from_numpy(src).cuda()
+            Tprev = (ctx.icp_point_to_plane_detailed(ds_, d_, ctx.estimate_normals(d_, k), None, iters - 1, md, 0.0, correspondences=False) if p2plane
+                     else ctx.icp_detailed(ds_, d_, None, iters - 1, md, 0.0, correspondences=False)).transformation
+        q = O_.isometry_apply(Tprev, src[A[idx, 0]]).astype(np.float64)
+        da = np.linalg.norm(q - p[A[idx, 1]].astype(np.float64), axis=1); db = np.linalg.norm(q - p[B[idx, 1]].astype(np.float64), axis=1)
+        print("   differing rows: source, target (plain), target (handles), distance to either, difference:")
+        for r_, i_ in enumerate(idx[:24]):
+            print(f"      {int(A[i_, 0]):8d} {int(A[i_, 1]):8d} {int(B[i_, 1]):8d}  {da[r_]:.9e} {db[r_]:.9e}  {abs(da[r_] - db[r_]):.2e}   same source row: {bool(A[i_, 0] == B[i_, 0])}")
     for it in range(1, iters + 1):          # where the two roads part: the same registration stopped after 1 .. iters iterations
         d, ds = torch.from_numpy(p).cuda(), torch.from_numpy(src).cuda()
         nrm = ctx.estimate_normals(d, k)

@@ -106,6 +106,26 @@ def main():
                         rows = (np.asarray(a) != np.asarray(b)).reshape(len(a), -1).any(1).sum()
                         ties += int(rows)
                         ok = rows <= max(8, len(a) // 5_000)          # (+ near-tie pairs that flip with the 1e-7 the transforms differ by)
+                        if not ok and what == "pairs" and rows <= max(8, len(a) // 500):
+                            # more rows than that (campaign 506 case 296: 19 of 78 643, twelve p2p iterations into a descent): accepted
+                            # when every one of them IS a near-tie -- the source point's distances to the two targets, under the
+                            # transform the LAST iteration searched with (the same call stopped one iteration earlier), differ by less
+                            # than the two roads' transforms move it apart
+                            from oracle import oracle as O_
+                            import torch as torch_
+                            A, B = np.asarray(a), np.asarray(b)
+                            idx = np.nonzero((A != B).reshape(len(A), -1).any(1))[0]
+                            Tprev = O_.IDENTITY
+                            if iters > 1:
+                                dd, dss = torch_.from_numpy(p).cuda(), torch_.from_numpy(src).cuda()
+                                rp = (ctx.icp_point_to_plane_detailed(dss, dd, ctx.estimate_normals(dd, k), None, iters - 1, md, 0.0, correspondences=False) if p2plane
+                                      else ctx.icp_detailed(dss, dd, None, iters - 1, md, 0.0, correspondences=False))
+                                Tprev = rp.transformation
+                            q = O_.isometry_apply(Tprev, src[A[idx, 0]]).astype(np.float64)
+                            da = np.linalg.norm(q - p[A[idx, 1]].astype(np.float64), axis=1)
+                            db = np.linalg.norm(q - p[B[idx, 1]].astype(np.float64), axis=1)
+                            dT = float(np.abs(np.asarray(ref[1], np.float64) - np.asarray(got[1], np.float64)).max())
+                            ok = bool((A[idx, 0] == B[idx, 0]).all() and (np.abs(da - db) <= 4.0 * (dT + 1e-7) * max(1.0, ext)).all())
                 else:
                     ok = same(a, b)
                 if not ok:
