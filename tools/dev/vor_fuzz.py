@@ -60,10 +60,13 @@ def child(budget, seed, min_cases=0):
     print("RESULT " + json.dumps(out))
 
 
-def compare(budget, seed, log=print, min_cases=0):
+def compare(budget, seed, log=print, min_cases=0, what="ball"):
+    """what = "ball": the inscribed-ball test from the first iteration on against none; "second": the second-neighbour certificate
+    (default build) against TC_DEBUG=4096 (off)"""
     me = os.path.abspath(__file__)
     res = {}
-    for name, env in (("with", {"TC_VOR_AFTER": "1"}), ("without", {"TC_DEBUG": "4"})):
+    envs = (("with", {"TC_VOR_AFTER": "1"}), ("without", {"TC_DEBUG": "4"})) if what == "ball" else (("with", {}), ("without", {"TC_DEBUG": "4096"}))
+    for name, env in envs:
         p = subprocess.run([sys.executable, me, "--child", str(budget), str(seed), str(min_cases)], env=dict(os.environ, **env), capture_output=True, text=True)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
         assert line, p.stderr[-3000:]
@@ -74,7 +77,7 @@ def compare(budget, seed, log=print, min_cases=0):
         if a != b:
             bad += 1
             log("MISMATCH", a, b)
-    log(f"inscribed-ball A/B: {n} registrations compared, {bad} differ")
+    log(f"{'inscribed-ball' if what == 'ball' else 'second-neighbour certificate'} A/B: {n} registrations compared, {bad} differ")
     return n, bad
 
 
@@ -82,5 +85,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child(float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     else:
-        n, bad = compare(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+        n, bad = compare(float(sys.argv[1]) if len(sys.argv) > 1 else 40.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                         what=sys.argv[3] if len(sys.argv) > 3 else "ball")
         sys.exit(1 if bad else 0)
