@@ -868,6 +868,8 @@ tc_status build_index(tc_context *ctx, DeviceIndex &ix, const float *d_xyz, size
     // Only for clouds of >= 2^18 points: the check costs a host synchronisation at the end of the build
     // (~15 us of launch bubble), which a 24 k-point LiDAR frame pipeline feels (-14 % frames/s) and a
     // 1 M-point cloud does not (-0.5 %), while the gain scales with the cloud (TUM-shaped 1 M: 2-3x).
+    // (TC_SURFACE_PPO_MULT: tuning experiments -- the points per occupied cell an adapted surface grid aims for, times this)
+    if (const char *e = getenv("TC_SURFACE_PPO_MULT")) { const double m = atof(e); if (m > 0.0) target_ppo = (float)(target_ppo * m); }
     const bool adapt = target_ppo > 0.0f && !reuse_geom && !tile_major && n >= kAdaptMinPoints && !(dbg & 512);
     uint32_t nkeys_final = 0;
     const uint32_t *cs_final = nullptr;
