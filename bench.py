@@ -415,9 +415,12 @@ def measure_stream(ctx, steps, warmup):
             "max_queue_depth_seen": m.max_depth_seen}
 
 
-def measure_tum_pair(ctx, dev, steps, warmup):
+def measure_tum_pair(ctx, dev, steps, warmup, oracle_check=False):
     """BASELINE configs[2] shape on one GPU: a ~1 M-point TUM-RGB-D-shaped depth-map surface pair, k = 16 normals + 50-iteration
-    point-to-plane ICP through the tc_cloud handles (the step of the judged line on another cloud)."""
+    point-to-plane ICP through the tc_cloud handles (the step of the judged line on another cloud).  oracle_check (the default
+    run, together with the cpu_baseline leg): the timed call's transform and correspondences against the oracle's run of the SAME
+    call -- 50 iterations, threshold 0, no cut-off, from the identity, the handle's normals on both sides (registration.rs:508-602)
+    -- after the timing, as the checker."""
     import numpy as np
     import torch
     import threecrate_amd as tc
@@ -456,12 +459,38 @@ def measure_tum_pair(ctx, dev, steps, warmup):
     main_us = kern.get("icp_correspond_reduce_p2plane")
     nk_us = kern.get("normals_knn_pca")
     it_us = 1e6 * ti / (ICP_ITERS * steps)
+    parity = None
+    if oracle_check:
+        from oracle import oracle as O            # the checker: after the timed region, never inside it
+        tc_t = tc.Cloud(ctx, tgt); tc_t.estimate_normals(K_NORMALS, out=False)
+        tc_s = tc.Cloud(ctx, src)
+        g = tc_s.icp_point_to_plane(tc_t, None, ICP_ITERS, None, 0.0, correspondences=True)
+        gn = tc_t.normals()
+        tc_t.close(); tc_s.close()
+        assert np.array_equal(np.asarray(g.transformation), np.asarray(r.transformation))         # the call that was timed, again
+        nrm = np.ascontiguousarray(gn[:, 3:])
+        t0 = time.perf_counter()
+        o = O.icp_point_to_plane_detailed(src_h, tgt_h, nrm, None, ICP_ITERS, None, 0.0)
+        t_or = time.perf_counter() - t0
+        frob = lambda a, b: float(np.linalg.norm(O.isometry_to_matrix(a).astype(np.float64) - O.isometry_to_matrix(b).astype(np.float64)))
+        parity = {"icp_T_frobenius_vs_oracle_50it": frob(g.transformation, o.transformation),
+                  "icp_correspondences_differing_from_oracle": int((g.correspondences != o.correspondences).any(axis=1).sum())
+                  if len(g.correspondences) == len(o.correspondences) else -1,
+                  "iterations": [int(g.iterations), int(o.iterations)], "mse": [float(g.mse), float(o.mse)],
+                  "oracle_call_s": t_or,
+                  "note": "same normals on both sides (the target handle's); tests/test_gpu_fullsize.py::test_config2_the_benchmarked_call_"
+                          "fifty_iterations_against_the_oracle is the full check (parting report, exact-sums comparison)"}
+        if parity["icp_T_frobenius_vs_oracle_50it"] > 1e-5:
+            # the reference adds 10^6 per-pair terms one after the other in f32; the same f32 terms added in f64 = what its formula defines
+            e = O.icp_point_to_plane_detailed(src_h, tgt_h, nrm, None, ICP_ITERS, None, 0.0, exact_sums=True)
+            parity["icp_T_frobenius_vs_oracle_exact_sums"] = frob(g.transformation, e.transformation)
+            parity["reference_accumulation_error"] = frob(o.transformation, e.transformation)
     return {"metric": "ICP iterations/sec (whole job: k=16 normals + 50-iter point-to-plane ICP per pair; tc_cloud handles)",
             "value": ICP_ITERS * steps / wall, "unit": "it/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall / steps,
             "config": {"workload": f"{n}-pt TUM-RGB-D-shaped depth-map surface, 1 mm noise on both scans, k={K_NORMALS} normals + {ICP_ITERS}-iter "
                                    "point-to-plane ICP (BASELINE configs[2] shape, one pair)", "points": n},
             "normals_mpts_per_s": n * steps / tn / 1e6, "icp_only_it_per_s": ICP_ITERS * steps / ti, "final_mse": r.mse,
-            "kernels_us_avg": kern,
+            "kernels_us_avg": kern, "parity": parity,
             "roofline": {"bound": "hbm", "alg_bytes_per_iteration": ALG_BYTES_ICP * n, "main_pass_us": main_us,
                          "main_pass_frac": (ALG_BYTES_ICP * n / (main_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if main_us else None,
                          "iteration_us": it_us, "iteration_frac": ALG_BYTES_ICP * n / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -793,7 +822,7 @@ def main():
             os.dup2(2, 1)
             try:
                 for key, fn in (("frame_stream", lambda: measure_stream(ctx, 50, 2)),
-                                ("tum_pair", lambda: measure_tum_pair(ctx, dev, 3, 1)),
+                                ("tum_pair", lambda: measure_tum_pair(ctx, dev, 3, 1, oracle_check=not args.no_cpu_baseline)),
                                 ("sharded_10m", lambda: measure_sharded(ctx, dev, 10_000_000, 3, 1))):
                     try:
                         ctx.trim()            # (the blocks the previous workload parked in the context's pool: each line starts from a clean pool)

@@ -292,6 +292,9 @@ pub fn find_k_nearest_batch(ctx: &HipContext, points: &[Point3f], queries: &[Poi
     Ok((0..nq).map(|q| (0..cnt[q] as usize).map(|j| (idx[q * kk + j] as usize, dist[q * kk + j])).collect()).collect())
 }
 
+/// longest neighbour list of the device k-NN kernels (threecrate_hip.h, "Limits of this backend")
+pub const KNN_MAX_K: usize = 2047;
+
 /// The `KdTree` of this backend: built once, queried many times (`KdTree::new`, nearest_neighbor.rs:37-58).
 /// Implements `threecrate_core::NearestNeighborSearch` (core/traits.rs:6-12), so it drops into code that is generic
 /// over the trait.  Borrows the context: destroy order is enforced by the lifetime.
@@ -327,11 +330,30 @@ impl<'a> HipKdTree<'a> {
 }
 
 impl NearestNeighborSearch for HipKdTree<'_> {
-    /// `KdTree::find_k_nearest` (nearest_neighbor.rs:177-251): at most `len()` neighbours.  The device list holds up to 2047
-    /// entries (`TC_KNN_MAX_K`; a larger k is TC_UNSUPPORTED at the ABI): the trait returns a plain Vec, so such a request comes
-    /// back EMPTY rather than silently shortened -- use `find_k_nearest_batch`, which returns the error.
+    /// `KdTree::find_k_nearest` (nearest_neighbor.rs:177-251): the `min(k, len())` nearest, ascending.  The device list holds up to
+    /// `KNN_MAX_K` = 2047 entries (threecrate_hip.h "Limits of this backend"; a larger k is TC_UNSUPPORTED at the ABI).  The trait
+    /// returns a plain Vec and the reference's tree has no cap, so a larger k is served from radius sets: the k nearest are the
+    /// first k of any ball that holds at least k records -- the radius starts at the 2047th neighbour's distance scaled by
+    /// cbrt(k / 2047) and doubles until the count reaches k (at most a few rounds; `f32::MAX` covers every finite cloud).
     fn find_k_nearest(&self, query: &Point3f, k: usize) -> Vec<(usize, f32)> {
-        self.query(std::slice::from_ref(query), k.min(self.len()), -1.0).map(|mut v| v.remove(0)).unwrap_or_default()
+        let k = k.min(self.len());
+        if k == 0 { return Vec::new(); }
+        if k <= KNN_MAX_K {
+            return self.query(std::slice::from_ref(query), k, -1.0).map(|mut v| v.remove(0)).unwrap_or_default();
+        }
+        let seed = match self.query(std::slice::from_ref(query), KNN_MAX_K, -1.0) { Ok(mut v) => v.remove(0), Err(_) => return Vec::new() };
+        let r0 = seed.last().map(|e| e.1).unwrap_or(0.0);
+        let mut r = if r0 > 0.0 && r0.is_finite() { r0 * (k as f32 / KNN_MAX_K as f32).cbrt() * 1.05 } else { 1.0e-6 };
+        let q = query as *const Point3f as *const f32;
+        loop {
+            let mut count = 0u32;
+            if self.ctx.check(unsafe { ffi::tc_search_index_radius_count(self.raw, q, 1, r, &mut count) }).is_err() { return Vec::new(); }
+            if count as usize >= k || r >= f32::MAX { break; }
+            r = if r < f32::MAX / 2.0 { r * 2.0 } else { f32::MAX };
+        }
+        let mut out = self.find_radius_neighbors(query, r);          // ascending by distance
+        out.truncate(k);
+        out
     }
 
     /// every neighbour within `radius`, nearest first (nearest_neighbor.rs:254-298): count, then fill

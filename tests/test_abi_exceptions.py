@@ -58,9 +58,41 @@ def test_thread_bodies_catch_for_themselves():
     assert "catch (...)" in batch and "for (size_t c = started; c < n_ctx; ++c) worker(c);" in batch and "t.join()" in batch
 
 
-def _run(code, fault):
+# TC_FAULT exists only in the development build (api.hip compiled -DTC_DEV, every other object shared with the shipped library:
+# csrc/Makefile `dev`); the shipped library ignores the variable (test_shipped_library_ignores_fault_injection)
+DEV_LIB = os.path.join(ROOT, "threecrate_amd", "variants", "libthreecrate_hip_dev.so")
+
+
+def _run(code, fault, lib=DEV_LIB):
     env = dict(os.environ, TC_FAULT=fault, PYTHONPATH=ROOT)
+    if lib:
+        assert os.path.exists(lib), "run `make -C threecrate_amd/csrc` (or __graft_entry__.build()) first"
+        env["TC_HIP_LIB"] = lib
+    else:
+        env.pop("TC_HIP_LIB", None)
     return subprocess.run([sys.executable, "-c", textwrap.dedent(code)], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_shipped_library_ignores_fault_injection():
+    """the hook must not be live in the product -- an inherited TC_FAULT would turn every error return into a throw."""
+    r = _run("""
+        import ctypes as C, os, tempfile
+        import numpy as np
+        from threecrate_amd import _lib
+        L = _lib.load()
+        assert _lib.LIB_PATH.endswith(os.path.join("threecrate_amd", "libthreecrate_hip.so")), _lib.LIB_PATH
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            np.arange(16, dtype=np.float32).tofile(f)
+        n = C.c_size_t(77)
+        L.tc_read_kitti_bin.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        rc = L.tc_read_kitti_bin(f.name.encode(), None, 0, C.byref(n))        # site "kitti": not armed in this build
+        os.unlink(f.name)
+        assert rc == 0 and n.value == 4, (rc, n.value)
+        rc = L.tc_read_kitti_bin(b"/nonexistent/x.bin", None, 0, C.byref(n))   # an error return (site "fail"): its own status, no throw
+        assert rc != 0
+        print("alive")
+    """, "fail,context,kitti", lib=None)
+    assert r.returncode == 0 and "alive" in r.stdout, r.stdout + r.stderr
 
 
 def test_injected_bad_alloc_in_device_free_entry_points_returns_a_status():

@@ -14,8 +14,23 @@
 
 namespace tc {
 
+// TC_DEBUG in the SHIPPED library: only the bits that print or count (8 the counting instantiation of the main pass, 64 refine
+// statistics, 256 the grid decisions, 1024 block stamps) -- none of them changes a result or the road to it.  The bits that do
+// (1 no warm start, 4 no inscribed-ball test, 16 no sums, 32 transform frozen, 512 no edge adaptation, 2048 exact box only, 8192 shells
+// only: timing experiments and A/B switches) exist only in the development build, `make dev` ->
+// variants/libthreecrate_hip_dev.so (this file compiled with -DTC_DEV, every other object shared with the shipped library): an
+// inherited environment variable cannot turn the product into a wrong-answer build (tests/test_debug_bits.py).
+[[maybe_unused]] constexpr int kDebugPrintOnlyBits = 8 | 64 | 256 | 1024;
 int debug_flags() {
-    static const int flags = [] { const char *e = getenv("TC_DEBUG"); return e ? atoi(e) : 0; }();
+    static const int flags = [] {
+        const char *e = getenv("TC_DEBUG");
+        const int f = e ? atoi(e) : 0;
+#ifdef TC_DEV
+        return f;
+#else
+        return f & kDebugPrintOnlyBits;
+#endif
+    }();
     return flags;
 }
 
@@ -37,8 +52,11 @@ tc_status fail_nothrow(tc_context *ctx, tc_status st, const char *msg) noexcept 
 // Fault injection for the tests of those handlers (tests/test_abi_exceptions.py): TC_FAULT=<site>[,<site>...] makes the named sites
 // throw std::bad_alloc -- "fail" (every error return that builds a message), "context" (tc_context_create), "batch_thread" (the
 // second worker of tc_batch_icp fails to start), "stream_worker" (the frame streamer's thread body), "kitti" (tc_read_kitti_bin).
-// Read per call: a test sets it after the library has been loaded.
+// Read per call: a test sets it after the library has been loaded.  DEVELOPMENT BUILD ONLY (-DTC_DEV, `make dev`): in the shipped
+// library this is an empty function -- an inherited TC_FAULT cannot turn error returns into throws, and no worker thread calls
+// getenv next to a host that may be changing its environment.
 void fault_point(const char *site) {
+#ifdef TC_DEV
     const char *e = getenv("TC_FAULT");
     if (!e || !*e) return;
     const size_t n = std::strlen(site);
@@ -48,6 +66,9 @@ void fault_point(const char *site) {
         if (len == n && std::strncmp(p, site, n) == 0) throw std::bad_alloc();
         p = q ? q + 1 : p + len;
     }
+#else
+    (void)site;            // the shipped library never reads TC_FAULT (no getenv on worker threads, no injected throw)
+#endif
 }
 
 // The pool parks what destroyed handles give back so that a handle per frame costs no hipMalloc.  Its cap follows the blocks it has
@@ -163,7 +184,9 @@ tc_status wait_pinned_word(tc_context *ctx, volatile uint32_t *word, const char 
     struct timespec t0 = {0, 0};
     bool sleeping = false;
     for (unsigned spins = 0; *word == 0u; ++spins) {
-        if ((spins & 1023u) == 1023u) {
+        // spinning / yielding: one stream query per 1024 looks; sleeping: one per look (a look is 50 us by then, so a faulted stream
+        // or one that drained without writing the word is noticed within a look, not after 50 ms -- ADVICE r5)
+        if (sleeping || (spins & 1023u) == 1023u) {
             const hipError_t q = hipStreamQuery(ctx->stream);
             if (q == hipSuccess) { if (*word == 0u) return fail(ctx, TC_GPU, std::string("internal error: ") + what + ": the stream drained without the word being written"); break; }
             if (q != hipErrorNotReady) return fail(ctx, TC_GPU, std::string(what) + ": " + hipGetErrorString(q));

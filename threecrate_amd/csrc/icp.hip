@@ -659,8 +659,10 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
                 if (lane == 0) {
                     IcpState *sw = const_cast<IcpState *>(st);
                     atomicAdd(&sw->refine_ring_hist[2], mx);                               // steps the trip took (its slowest lane)
-                    atomicAdd(&sw->refine_ring_hist[3], sm);                               // steps its lanes needed
-                    atomicAdd(&sw->refine_ring_hist[4], (uint32_t)__popcll(smask));        // searches
+                    // steps its lanes needed: the one counter that can pass 2^32 inside a call (10 M points x 50 iterations x ~5
+                    // steps: ADVICE r5) -> a 64-bit add on the aligned pair [3..4]; the searches moved to [7]
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&sw->refine_ring_hist[3]), (unsigned long long)sm);
+                    atomicAdd(&sw->refine_ring_hist[7], (uint32_t)__popcll(smask));        // searches (<= points x iterations / call: checked on the host)
                     atomicAdd(&sw->refine_ring_hist[5], 1u);                               // wave trips
                     if (smask == 0ull) atomicAdd(&sw->refine_ring_hist[6], 1u);            // ... without a search
                 }
@@ -1823,6 +1825,25 @@ tc_status icp_run_gicp(tc_context *ctx, const float *d_src, size_t ns, const flo
 }
 
 // A run that did not converge has executed exactly max_iters iterations (registration.rs:278 / :533): the device counts them
+// Counters of the main pass's counting instantiation (tc_profile_enable(ctx, 3) / TC_DEBUG & 8), summed over the call's iterations, into
+// the context's 64-bit session totals.  Called by every road that runs the main pass: plain / handle calls, the sharded loop, the
+// shard handles (the sharded roads used to drop them).  Slots of IcpState::refine_ring_hist: [2] steps the trips took,
+// [3..4] steps the lanes needed (one 64-bit word), [5] wave trips, [6] trips without a search, [7] searches.  (A -DTC_REFINE_STATS
+// build uses the same array as its exit-ring histogram and -DTC_PHASE_STAMPS words 0 / 1: development builds, never together with mode 3.)
+static void fold_search_stats(tc_context *ctx, const IcpState *hs) {
+    if (!((debug_flags() & 8) || ctx->profiling == 3)) return;
+    const uint32_t *h = hs->refine_ring_hist;
+    unsigned long long needed;
+    std::memcpy(&needed, &h[3], sizeof(needed));
+    ctx->stat_icp[0] += hs->iterations; ctx->stat_icp[1] += h[5]; ctx->stat_icp[2] += h[6]; ctx->stat_icp[3] += h[7];
+    ctx->stat_icp[4] += needed; ctx->stat_icp[5] += h[2];
+    if (debug_flags() & 8)
+        fprintf(stderr, "[tc] icp main pass over %u iterations: wave trips %u, without a search %u (%.1f %%); searches %u, candidate steps needed %llu "
+                        "(%.2f per search), steps taken by the trips' slowest lanes %u (%.2f per searching trip): lock-step ratio (lane slots spent / steps needed) %.2f\n",
+                hs->iterations, h[5], h[6], 100.0 * h[6] / std::max(h[5], 1u), h[7], needed, (double)needed / std::max(h[7], 1u), h[2],
+                (double)h[2] / std::max(h[5] - h[6], 1u), (double)h[2] * 64.0 / std::max<double>((double)needed, 1.0));
+}
+
 static tc_status check_iteration_count(tc_context *ctx, const IcpState *hs, size_t max_iters) {
     if (hs->status == TC_OK && !hs->converged && hs->iterations != max_iters)
         return fail(ctx, TC_GPU, "internal error: the ICP loop executed " + std::to_string(hs->iterations) + " of " + std::to_string(max_iters) + " iterations");
@@ -1950,16 +1971,7 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
         }
         fprintf(stderr, "\n");
     }
-    if ((debug_flags() & 8) || ctx->profiling == 3) {       // counters of the main pass's counting instantiation, summed over the call's iterations
-        const uint32_t *h = hs->refine_ring_hist;
-        ctx->stat_icp[0] += hs->iterations; ctx->stat_icp[1] += h[5]; ctx->stat_icp[2] += h[6]; ctx->stat_icp[3] += h[4];
-        ctx->stat_icp[4] += h[3]; ctx->stat_icp[5] += h[2];
-        if (debug_flags() & 8)
-            fprintf(stderr, "[tc] icp main pass over %u iterations: wave trips %u, without a search %u (%.1f %%); searches %u, candidate steps needed %u "
-                            "(%.2f per search), steps taken by the trips' slowest lanes %u (%.2f per searching trip): lock-step ratio (lane slots spent / steps needed) %.2f\n",
-                    hs->iterations, h[5], h[6], 100.0 * h[6] / std::max(h[5], 1u), h[4], h[3], (double)h[3] / std::max(h[4], 1u), h[2],
-                    (double)h[2] / std::max(h[5] - h[6], 1u), (double)h[2] * 64.0 / std::max(h[3], 1u));
-    }
+    fold_search_stats(ctx, hs);
     if (debug_flags() & 64)
         fprintf(stderr, "[tc] icp: %u iterations, refine queries total %u max %u  exit ring hist %u %u %u %u %u %u %u %u\n", hs->iterations,
                 hs->refine_total, hs->refine_max, hs->refine_ring_hist[0], hs->refine_ring_hist[1], hs->refine_ring_hist[2], hs->refine_ring_hist[3],
@@ -2080,6 +2092,7 @@ tc_status icp_run_sharded(tc_context *ctx, tc_comm *comm, int shard_mode, bool p
     }
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
     TC_HIP_TRY(ctx, hipGetLastError());
+    fold_search_stats(ctx, hs);
     if (hs->status != TC_OK)
         return fail(ctx, (tc_status)hs->status, p2plane ? "Insufficient correspondences for point-to-plane ICP (need >= 6) or ill-conditioned system"
                                                         : "Insufficient correspondences found");
@@ -2183,6 +2196,7 @@ tc_status tc_icp_shard_finish(tc_icp_shard *s, size_t max_iters, tc_icp_result *
         TC_HIP_TRY(ctx, hipMemcpyAsync(res->corr_target, corr, s->ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     }
     TC_HIP_TRY(ctx, hipStreamSynchronize(st));
+    tc::fold_search_stats(ctx, hs);
     if (hs->status != TC_OK) return tc::fail(ctx, (tc_status)hs->status, "ICP failed (insufficient correspondences / singular system)");
     for (int i = 0; i < 4; ++i) res->transformation[i] = hs->q[i];
     for (int i = 0; i < 3; ++i) res->transformation[4 + i] = hs->t[i];

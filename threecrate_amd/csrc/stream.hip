@@ -177,7 +177,9 @@ tc_status enqueue(tc_frame_stream *s, const float *frame, size_t n, size_t strid
                 return TC_OK;
             }
             s->cv_free.wait(lk, [&] { return !s->free_slots.empty() || s->closed; });
-            if (s->free_slots.empty()) return TC_INVALID_DATA;             // closed while waiting (finished, or the worker failed)
+            // closed while waiting (finished, or the worker failed): no worker will look at the queue again, so a frame must not be
+            // accepted even when a slot happens to be free at this moment
+            if (s->closed || s->free_slots.empty()) return TC_INVALID_DATA;
         }
         slot = s->free_slots.front(); s->free_slots.pop_front();
     }
@@ -213,8 +215,12 @@ tc_status tc_frame_stream_create(tc_context *ctx, const tc_frame_stream_config *
     tc_frame_stream *s = new tc_frame_stream();
     s->ctx = ctx;
     s->cfg = *cfg;
+    // ONE owner of the half-built stream: bail destroys it and forgets it before it builds the message -- tc::fail can throw
+    // (std::string), and the catch below must not destroy the stream a second time (use after free + double hipHostFree)
     auto bail = [&](const char *what) {
-        tc_frame_stream_destroy(s);
+        tc_frame_stream *dead = s;
+        s = nullptr;
+        tc_frame_stream_destroy(dead);
         return tc::fail(ctx, TC_GPU, std::string("tc_frame_stream_create: ") + what);
     };
     const size_t bytes = cfg->max_points * 3 * sizeof(float);
@@ -231,7 +237,7 @@ tc_status tc_frame_stream_create(tc_context *ctx, const tc_frame_stream_config *
         if (hipMalloc((void **)&s->d_frame[b], bytes) != hipSuccess) return bail("device frame");
     }
     s->worker = std::thread(worker_main, s);
-    } catch (...) { tc_frame_stream_destroy(s); throw; }
+    } catch (...) { if (s) tc_frame_stream_destroy(s); throw; }
     *out = s;
     return TC_OK;
 } TC_CATCH_STATUS(ctx)

@@ -1,5 +1,6 @@
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-"""dev: far queries -- outliers at 30 / 100 extents, partially overlapping scans -- timing + results saved for an A/B of the
+"""(TC_DEBUG bits that change the road -- 32, 8192 ... -- need TC_HIP_LIB=threecrate_amd/variants/libthreecrate_hip_dev.so since round 6.)
+dev: far queries -- outliers at 30 / 100 extents, partially overlapping scans -- timing + results saved for an A/B of the
 refine pass's ball scan (default) against shells only (TC_DEBUG=8192).  usage: farq.py <tag>; farq.py cmp <a> <b>"""
 import time, numpy as np
 

@@ -21,7 +21,7 @@ print(json.dumps(out))
 for label, dbg, extra in (("default", 0, {}), ("vor from it 0", 0, {"TC_VOR_AFTER": "0"}), ("no vor", 4, {}),
                           # no phase A = no sums = the solve fails: freeze the transform instead (every pass then is COLD: no warm start)
                           ("cold", 32, {}), ("cold, no phase A", 32 + 16, {})):
-    env = dict(os.environ, TC_DEBUG=str(dbg), **extra)
+    env = dict(os.environ, TC_DEBUG=str(dbg), **extra); env.setdefault("TC_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "threecrate_amd", "variants", "libthreecrate_hip_dev.so"))    # the altering bits exist in the dev build only
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     print(f"{label:22s}", line[0] if line else p.stderr[-1500:])

@@ -1,5 +1,6 @@
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-"""dev: a few ICP iterations for PMC collection (TC_DEBUG=32 keeps the transform fixed = cold phase)."""
+"""(TC_DEBUG bits that change the road -- 32, 8192 ... -- need TC_HIP_LIB=threecrate_amd/variants/libthreecrate_hip_dev.so since round 6.)
+dev: a few ICP iterations for PMC collection (TC_DEBUG=32 keeps the transform fixed = cold phase)."""
 import numpy as np, torch, threecrate_amd as tc
 from threecrate_amd import synth
 n = 1000000

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Run ON THE GPU BOX: bash tools/dev/r6_nprobe.sh <variant>... -- round 6 item 1: (a) the VALU issue price microbenchmark, (b) kernel
+# times of the 1 M-point k = 16 normals call with the default library and each variant, (c) SQ / TCP counters of the normals kernel per arm
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r6
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/dev/micro/valu_price.hip -o /tmp/valu_price && timeout 300 /tmp/valu_price | tee gpurun_out/r6/valu_price.txt
+bash tools/dev/ab_normals.sh "$@" 2>&1 | tee gpurun_out/r6/ab_normals.txt
+for v in "$@"; do TC_HIP_LIB="$GRAFT_REPO_ROOT/threecrate_amd/variants/libthreecrate_hip_$v.so" timeout 300 python3 tools/dev/nprof.py 2>&1 | tail -5 > gpurun_out/r6/err_$v.txt; done
+for v in default "$@"; do
+  lib=""; [ "$v" != default ] && lib="$GRAFT_REPO_ROOT/threecrate_amd/variants/libthreecrate_hip_$v.so"
+  export TC_HIP_LIB=$lib
+  i=0; mkdir -p gpurun_out/r6/pmc_$v
+  for line in "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY" \
+              "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
+              "TD_TD_BUSY_sum TD_TC_STALL_sum TA_TA_BUSY_sum TA_BUSY_max" \
+              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $line --output-format csv -d gpurun_out/r6/pmc_$v/p$i -- python3 tools/dev/npmc.py > gpurun_out/r6/pmc_$v/log$i.txt 2>&1
+  done
+done
+python3 - <<'PY' | tee gpurun_out/r6/counters.txt
+import glob, csv, collections, os
+for d in sorted(glob.glob("gpurun_out/r6/pmc_*")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(d + "/p*/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void tc::", "").replace("tc::", "")
+            a = agg[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+    for k in agg:
+        if "normals_tagged" not in k and "normals_knn" not in k: continue
+        print(os.path.basename(d), k)
+        for c, (v, n) in sorted(agg[k].items()): print(f"    {c:42s} {v/n/1e6:12.3f} M/launch  ({n} launches)")
+PY

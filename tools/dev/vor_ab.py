@@ -24,7 +24,7 @@ print(json.dumps(out))
 ''' % ROOT
 res = {}
 for dbg in ("0", "4"):
-    env = dict(os.environ, TC_DEBUG=dbg)
+    env = dict(os.environ, TC_DEBUG=dbg); env.setdefault("TC_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "threecrate_amd", "variants", "libthreecrate_hip_dev.so"))    # the altering bits exist in the dev build only
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if not line:

@@ -60,12 +60,18 @@ def child(budget, seed, min_cases=0):
     print("RESULT " + json.dumps(out))
 
 
+DEV_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "threecrate_amd", "variants", "libthreecrate_hip_dev.so")
+
+
 def compare(budget, seed, log=print, min_cases=0, what="ball"):
     """what = "ball": the inscribed-ball test from the first iteration on against none; "second": the second-neighbour certificate
     (default build) against TC_DEBUG=4096 (off)"""
     me = os.path.abspath(__file__)
     res = {}
-    envs = (("with", {"TC_VOR_AFTER": "1"}), ("without", {"TC_DEBUG": "4"})) if what == "ball" else (("with", {}), ("without", {"TC_DEBUG": "4096"}))
+    # the switches that change the road live in the development build only (csrc/Makefile `dev`); unless the caller names a library
+    # (TC_HIP_LIB = a variant under test) the arm that needs a switch loads that build
+    dev = {} if os.environ.get("TC_HIP_LIB") else {"TC_HIP_LIB": DEV_LIB}
+    envs = (("with", {"TC_VOR_AFTER": "1"}), ("without", dict(dev, TC_DEBUG="4"))) if what == "ball" else (("with", {}), ("without", dict(dev, TC_DEBUG="4096")))
     for name, env in envs:
         p = subprocess.run([sys.executable, me, "--child", str(budget), str(seed), str(min_cases)], env=dict(os.environ, **env), capture_output=True, text=True)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
