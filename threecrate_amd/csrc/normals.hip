@@ -497,12 +497,28 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { 
     const uint32_t t = mx < c ? mx : c;
     return mn > t ? mn : t;
 }
+// (Round 6: the same chain on v_med3_f32 -- the keys are bit patterns of non-negative floats, which order like their bits; needs +inf
+// instead of 0xFFFFFFFF as the no-op key and f32 denormals kept -- is bit-identical and NOT faster: 273.4 vs 272.2 us.  On gfx950
+// v_med3_f32 / v_min_f32 / v_max_f32 issue at the same half rate as v_med3_u32, ~4 cycles per wave64 instruction at any occupancy;
+// only f32 add / mul / fma and integer add / and / or / xor run at ~2.5: profiles/r06_valu_issue_price.txt.  -DTC_KEYS_F32 keeps the A/B.)
+#ifdef TC_KEYS_F32
+constexpr uint32_t kKeyNop = 0x7f800000u;
+template <int L>
+__device__ __forceinline__ void list_insert_u(uint32_t (&d)[L], uint32_t v) {
+    const float fv = __uint_as_float(v);
+#pragma unroll
+    for (int t = L - 1; t >= 1; --t) d[t] = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(d[t - 1]), fv, __uint_as_float(d[t])));
+    d[0] = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(d[0]), fv, 0.0f));      // min(a, v) = med3(a, v, 0) for a, v >= 0
+}
+#else
+constexpr uint32_t kKeyNop = 0xFFFFFFFFu;
 template <int L>
 __device__ __forceinline__ void list_insert_u(uint32_t (&d)[L], uint32_t v) {
 #pragma unroll
     for (int t = L - 1; t >= 1; --t) d[t] = umed3(d[t - 1], v, d[t]);
     d[0] = d[0] < v ? d[0] : v;
 }
+#endif
 
 // FLAT (round 3, third form): the lockstep row walk -- a row costs the wave its longest span, ~214 candidate slots per lane for a mean
 // need of 80 at k = 16 -- becomes three groups of rows (the central 3 x 3, then the outer 16 in two halves, nearest first): the
@@ -510,22 +526,46 @@ __device__ __forceinline__ void list_insert_u(uint32_t (&d)[L], uint32_t v) {
 // cell_start pairs of all its rows in flight together), the non-empty spans go to a per-lane LDS list, and ONE flattened loop
 // walks them -- a lane moves to its next span when its current one ends, so a group costs the wave the longest SUM of spans
 // (simulated on the uniform cloud: ~155 slots).  The loop body is branch-free: a slot beyond its span inserts the key
-// 0xFFFFFFFF (a no-op for the list), the next span is prefetched from LDS at the top of every step.
+// 0xFFFFFFFF (kKeyNop: a no-op for the list), the next span is prefetched from LDS at the top of every step.
 // records per step of the flattened walk: 2 since round 4 (4 before: 304 -> 291 us at 1 M points / k = 16, 227 -> 218 at k = 10;
 // 3: 292 / 223).  Build with -DTC_FLAT_W=<n> for an A/B (tools/dev/build_variant.sh).
 #ifndef TC_FLAT_W
 #define TC_FLAT_W 2
 #endif
-struct FlatRows { int8_t dz[9], dy[9]; int n; };
+// Round 6, measured and NOT kept as the default: two groups -- the central 3 x 3, then all sixteen outer rows in ONE flattened walk
+// (-DTC_FLAT_GROUPS=2).  The statistics (-DTC_NSTATS, profiles/r06_normals_lockstep.txt) said a lane needs 25.4 + 6.8 + 2.8 steps of two
+// records where its wave takes 32.5 + 16.4 + 8.4, and one walk over both outer halves should cost one maximum instead of the sum of two.
+// It does not: the merged walk takes 25.0 steps (16.4 + 8.4 = 24.8 before) for a need of 10.1 (9.6) -- the lane that is slowest in the
+// first half (a sparse neighbourhood, a large 17th distance) is the slowest in the second half too, so the maximum of the sums IS the sum
+// of the maxima, the second half loses the limit the first one tightens, and the span list doubles (9.4 instead of 6.1 KB of LDS per
+// wave: 17 instead of 20 waves per CU): 281 - 284 us against 267 for three groups with the same row logic.
+#ifndef TC_FLAT_GROUPS
+#define TC_FLAT_GROUPS 3
+#endif
+constexpr int kFlatMaxRows = TC_FLAT_GROUPS == 2 ? 16 : 9;
+struct FlatRows { int8_t dz[kFlatMaxRows], dy[kFlatMaxRows]; int n; };
+#if TC_FLAT_GROUPS == 2
+__device__ constexpr FlatRows kFlatRows[2] = {
+    {{0, 0, 0, -1, 1, -1, -1, 1, 1}, {0, -1, 1, 0, 0, -1, 1, -1, 1}, 9},
+    {{0, 0, -2, 2, -1, -1, 1, 1, -2, -2, 2, 2, -2, -2, 2, 2}, {-2, 2, 0, 0, -2, 2, -2, 2, -1, 1, -1, 1, -2, 2, -2, 2}, 16},
+};
+#else
 __device__ constexpr FlatRows kFlatRows[3] = {
     {{0, 0, 0, -1, 1, -1, -1, 1, 1}, {0, -1, 1, 0, 0, -1, 1, -1, 1}, 9},
     {{0, 0, -2, 2, -1, -1, 1, 1, 0}, {-2, 2, 0, 0, -2, 2, -2, 2, 0}, 8},
     {{-2, -2, 2, 2, -2, -2, 2, 2, 0}, {-1, 1, -1, 1, -2, 2, -2, 2, 0}, 8},
 };
+#endif
+// words of LDS per lane the flattened walk parks its spans in (two per row of the largest group)
+constexpr int kFlatSpanWords = 2 * kFlatMaxRows;
 
 template <int L, int BLOCK, bool EXT, bool FLAT = false>
 __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParams &prm, uint32_t p, const float4 &q, int cx, int cy, int cz,
-                                           float mf, uint32_t *ldsA, uint8_t *ldsB, uint32_t &cnt, int &self_r, float &d1_out) {
+                                           float mf, uint32_t *ldsA, uint8_t *ldsB, uint32_t &cnt, int &self_r, float &d1_out
+#ifdef TC_PHASE_STAMPS
+                                           , unsigned long long (&ph)[8], unsigned long long &tl
+#endif
+                                           ) {
     const GridGeom &g = gv.g;
     const uint32_t K1 = prm.k + 1;               // <= L - 2 (launch_normals)
     uint32_t d[L];
@@ -546,9 +586,26 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
     if constexpr (FLAT) {
         float live0 = INFINITY;
         bool fail = false;
+        // Once per point (round 6; the row logic was 20 % of a wave's time, profiles/r06_normals_phases.txt): the squared gaps of the five
+        // z and the five y offsets -- a row's rg is the sum of two of them, the same two products and the same sum as before --, the
+        // point's own row, and the unpruned x window.  A row outside the grid keeps the point's own row for its (unused) reads.
+        float gz2[5], gy2[5];
+        bool zin[5], yin[5];
 #pragma unroll
-        for (int grp = 0; grp < 3; ++grp) {
-            constexpr int NR = 9;
+        for (int d = 0; d < 5; ++d) {
+            const int z = cz + d - 2, y = cy + d - 2;
+            zin[d] = z >= 0 && z < g.gz;
+            yin[d] = y >= 0 && y < g.gy;
+            const float gzv = axis_gap_n<EXT>(q.z, g.minz, g.h, zin[d] ? z : cz, g.gz - 1);
+            const float gyv = axis_gap_n<EXT>(q.y, g.miny, g.h, yin[d] ? y : cy, g.gy - 1);
+            gz2[d] = gzv * gzv;
+            gy2[d] = gyv * gyv;
+        }
+        const uint32_t row0 = ((uint32_t)cz * g.gy + cy) * g.gx;
+        const int xlo = max(cx - 2, 0), xhi = min(cx + 2, g.gx - 1);
+#pragma unroll
+        for (int grp = 0; grp < TC_FLAT_GROUPS; ++grp) {
+            constexpr int NR = kFlatMaxRows;
             uint32_t ss[NR], ee[NR];
             bool ok[NR];
 #pragma unroll
@@ -556,21 +613,23 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
                 ok[i] = false; ss[i] = 0; ee[i] = 0;
                 if (i >= kFlatRows[grp].n) continue;
                 const int dz = kFlatRows[grp].dz[i], dy = kFlatRows[grp].dy[i];
-                const int z = cz + dz, y = cy + dy;
-                const bool inb = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
-                const int zc = inb ? z : cz, yc = inb ? y : cy;
-                const float gzv = axis_gap_n<EXT>(q.z, g.minz, g.h, zc, g.gz - 1);
-                const float gyv = axis_gap_n<EXT>(q.y, g.miny, g.h, yc, g.gy - 1);
-                const float rg = gyv * gyv + gzv * gzv;
-                int xa = max(cx - 2, 0), xb = min(cx + 2, g.gx - 1);
-                const float r = TC_FAST_SQRT(fmaxf(live0 - rg, 0.0f)) + 4e-3f * g.h;
-                const float fa = fminf(fmaxf((q.x - r - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
-                const float fb = fmaxf(fminf((q.x + r - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
-                xa = max(xa, (int)fa);
-                xb = min(xb, (int)fb);
-                ok[i] = inb && !(rg > live0) && xa <= xb;
-                xb = max(xb, xa);
-                const uint32_t row = ((uint32_t)zc * g.gy + yc) * g.gx;
+                const bool inb = zin[dz + 2] && yin[dy + 2];
+                int xa = xlo, xb = xhi;
+                if (grp == 0) {
+                    // (no limit yet: the whole window of every row inside the grid)
+                    ok[i] = inb;
+                } else {
+                    const float rg = gy2[dy + 2] + gz2[dz + 2];
+                    const float r = TC_FAST_SQRT(fmaxf(live0 - rg, 0.0f)) + 4e-3f * g.h;
+                    const float fa = fminf(fmaxf((q.x - r - g.minx) * g.inv_h, 0.0f), (float)(g.gx - 1));
+                    const float fb = fmaxf(fminf((q.x + r - g.minx) * g.inv_h, (float)(g.gx - 1)), 0.0f);
+                    xa = max(xa, (int)fa);
+                    xb = min(xb, (int)fb);
+                    ok[i] = inb && !(rg > live0) && xa <= xb;
+                    xb = max(xb, xa);
+                }
+                const int roff = (dz * g.gy + dy) * g.gx;               // (wave-uniform)
+                const uint32_t row = inb ? row0 + (uint32_t)roff : row0;
                 ss[i] = gv.cell_start[row + xa];
                 ee[i] = gv.cell_start[row + xb + 1];
             }
@@ -585,6 +644,20 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
                 ldsA[(2u * ns + 1u) * BLOCK] = (len & 0xFFFFu) | (rowtag << 16);
                 ns += len ? 1u : 0u;
             }
+            { uint32_t sink_ = ns; asm volatile("" :: "v"(sink_)); }
+            TC_NSTAMP(2);          // (tagged path) row logic of the group: windows, cell_start pairs, spans parked
+#ifdef TC_NSTATS
+            {   // lock-step statistics of the flattened walk: steps this lane needs in the group, summed / squared / maximum over the wave
+                uint32_t need = 0;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) { if (i >= kFlatRows[grp].n) continue; const uint32_t len = ok[i] ? ee[i] - ss[i] : 0u; need += (len + TC_FLAT_W - 1u) / TC_FLAT_W; }
+                uint32_t mx = need;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+                TC_NSTAT(8 + grp, need);                              // steps needed, per group
+                if ((threadIdx.x & 63) == 0) TC_NSTAT(11 + grp, mx);  // steps the wave takes (its slowest lane), per group
+            }
+#endif
             uint32_t k = 0;
             uint32_t j = 0, e = 0, tag = 0;
             {
@@ -605,7 +678,7 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
                 for (int w = 0; w < TC_FLAT_W; ++w) {
                     const nf32x3 cw = __builtin_bit_cast(nf32x3, __builtin_amdgcn_raw_buffer_load_b96(pt_rsrc, o + 16u * (uint32_t)w, 0, 0));
                     const uint32_t kw = tag_key(cw, q, tag, j + (uint32_t)w);
-                    list_insert_u<L>(d, j + (uint32_t)w < e ? kw : 0xFFFFFFFFu);
+                    list_insert_u<L>(d, j + (uint32_t)w < e ? kw : kKeyNop);
                 }
                 j += (uint32_t)TC_FLAT_W;
                 const bool adv = j >= e;
@@ -615,6 +688,8 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
                 tag = adv ? (n2 >> 16) : tag;
                 e = adv ? (more ? n1 + (n2 & 0xFFFFu) : 0u) : e;
             } while (__any((int)(j < e)));
+            { uint32_t sink_ = d[L - 1]; asm volatile("" :: "v"(sink_)); }
+            TC_NSTAMP(3);          // (tagged path) the flattened walk of the group
             // (three times per lane: the (k+1)-th key by a select over the list is affordable here whatever k is)
             {
                 uint32_t kk = d[0];
@@ -683,6 +758,8 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
         }, &live_lim, &rowtag);
         if (!touched) break;
     }
+    { uint32_t sink_ = d[L - 1]; asm volatile("" :: "v"(sink_)); }
+    TC_NSTAMP(1);                  // (tagged path) exactness rule + ring-3 continuation
     // ---- the keys name their records ----
     bool bad = false;
 #pragma unroll
@@ -765,6 +842,8 @@ __device__ __forceinline__ bool knn_tagged(const GridView &gv, const NormalParam
     push(INFINITY, 0xFFFFFFFFu, 0xFFu); push(INFINITY, 0xFFFFFFFFu, 0xFFu); push(INFINITY, 0xFFFFFFFFu, 0xFFu);
     // every record outside the list has a truncated distance >= the last key's
     if (full) bad |= !(vk < __uint_as_float(last_floor));
+    { float sink_ = vk + v1; asm volatile("" :: "v"(sink_)); }
+    TC_NSTAMP(4);                  // (tagged path) decode: keys -> records -> exact order + certificate
     d1_out = v1;
     if (bad) TC_NSTAT(3, 1); else TC_NSTAT(1, 1);
     TC_NSTAT(0, 1);
@@ -839,7 +918,11 @@ __device__ __forceinline__ void normals_point(const GridView &gv, const NormalPa
         }
         if (try_tag) {
             float d1 = INFINITY;
-            have = knn_tagged<L, BLOCK, EXT, (CAP < -1)>(gv, prm, p, q, cx, cy, cz, mf, ldsA, ldsB, cnt, self_r, d1);
+            have = knn_tagged<L, BLOCK, EXT, (CAP < -1)>(gv, prm, p, q, cx, cy, cz, mf, ldsA, ldsB, cnt, self_r, d1
+#ifdef TC_PHASE_STAMPS
+                                                         , ph, tl
+#endif
+                                                         );
             if (have) d[1] = d1;
             TC_NSTAMP(1);
         }
@@ -1505,7 +1588,7 @@ __global__ void __launch_bounds__(BLOCK) normals_knn_pca_kernel(GridView gv, Nor
 #endif
 template <int L, int BLOCK, bool EXT, int CAP>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(L >= 19 ? TC_TAG_WAVES - 1 : TC_TAG_WAVES, L >= 19 ? TC_TAG_WAVES - 1 : TC_TAG_WAVES))) normals_tagged_kernel(GridView gv, NormalParams prm, float *__restrict__ out6) {
-    __shared__ uint32_t ldsA[(L > 18 ? L : 18) * BLOCK];        // (the flattened walk parks up to nine spans of two words here)
+    __shared__ uint32_t ldsA[(L > kFlatSpanWords ? L : kFlatSpanWords) * BLOCK];        // (the flattened walk parks the spans of a group here, two words each)
     __shared__ uint8_t ldsB[L * BLOCK];
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t p = prm.p_begin + lb * BLOCK + threadIdx.x;
@@ -1783,7 +1866,7 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
                     fprintf(stderr, "\n");
                 }
             }
-            fprintf(stderr, "[tc] normals wave 0 phases, mean s_memtime ticks over %zu blocks: setup %.0f  block scan + list (tagged path: everything up to the neighbour list) %.0f  continuation %.0f  collect %.0f  rank %.0f  centroid + covariance %.0f  eigen + orient %.0f  store %.0f\n",
+            fprintf(stderr, "[tc] normals wave 0 phases, mean s_memtime ticks over %zu blocks: setup %.0f  block scan + list (tagged path: exactness rule + ring-3 continuation) %.0f  continuation (tagged: row logic of the three groups) %.0f  collect (tagged: the flattened walks) %.0f  rank (tagged: decode + certificate) %.0f  centroid + covariance %.0f  eigen + orient %.0f  store %.0f\n",
                     cnt, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
         }
     } stamp_dump{ctx, stamp_blocks, prm.stamps != nullptr};
@@ -1839,6 +1922,10 @@ tc_status launch_normals(tc_context *ctx, const DeviceIndex &ix, const float *d_
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nstats), sizeof h);
             fprintf(stderr, "[tc] normals tagged path: lanes %llu served %llu | beyond ring 3 / oversized span %llu | a check failed %llu | waves %llu with a fallback lane %llu\n",
                     h[0] + h[2], h[1], h[2], h[3], h[6], h[7]);
+            const double lanes = (double)std::max<unsigned long long>(h[0] + h[2], 1ull), waves = (double)std::max<unsigned long long>(h[6], 1ull);
+            fprintf(stderr, "[tc] normals flattened walk, steps of %d records: a lane needs %.1f + %.1f + %.1f = %.1f per point (groups 0 / 1 / 2), its wave takes %.1f + %.1f + %.1f = %.1f: lock-step ratio %.2f\n",
+                    TC_FLAT_W, h[8] / lanes, h[9] / lanes, h[10] / lanes, (h[8] + h[9] + h[10]) / lanes, h[11] / waves, h[12] / waves, h[13] / waves,
+                    (h[11] + h[12] + h[13]) / waves, ((h[11] + h[12] + h[13]) / waves) / std::max((h[8] + h[9] + h[10]) / lanes, 1e-9));
         }
     } stat_dump{ctx->stream};
 #endif
