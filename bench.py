@@ -846,6 +846,29 @@ def main():
             npts = out["tum_pair"]["config"]["points"]
             table.append({"what": "normals kernel, TUM-shaped cloud (configs[2] shape)", "alg_bytes": ALG_BYTES_NORMALS * npts, "us": tp["normals_kernel_us"], "frac": tp["normals_frac"]})
             table.append({"what": "icp main pass, TUM-shaped pair", "alg_bytes": ALG_BYTES_ICP * npts, "us": tp["main_pass_us"], "frac": tp["main_pass_frac"]})
+        # the unit counters behind each kernel's bound claim: from the committed PMC summary (profiles/pmc_traffic.json,
+        # separate rocprofv3 --pmc passes of this bench: tools/collect_profiles.sh), per launch, like `traffic` -- never measured in here
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            def unit_counters(sub, points):
+                kk = next((v for k_, v in pj["kernels"].items() if sub in k_ and "SQ_BUSY_CU_CYCLES" in v), None)
+                if not kk:
+                    return None
+                valu = kk.get("SQ_INSTS_VALU", kk.get("SQ_ACTIVE_INST_VALU"))
+                return {"valu_wave_insts": valu, "busy_cu_cycles": kk.get("SQ_BUSY_CU_CYCLES"),
+                        "valu_wave_insts_per_simd": (valu / 1024.0) if valu else None,
+                        "busy_cycles_per_cu": kk["SQ_BUSY_CU_CYCLES"] / 256.0,
+                        "tcp_lookups_per_point": (kk["TCP_TOTAL_CACHE_ACCESSES_sum"] / points) if "TCP_TOTAL_CACHE_ACCESSES_sum" in kk else None,
+                        "lds_bank_conflict_rate": kk.get("lds_bank_conflict_rate"), "achieved_waves_per_simd": kk.get("achieved_waves_per_simd"),
+                        "profiled_avg_us": kk.get("avg_us"), "source": pj.get("source")}
+            if n == N_POINTS and args.cloud == "uniform":
+                for row, sub in ((table[0], "icp_correspond_reduce_kernel<1>"), (table[2] if len(table) > 2 and "normals kernel, timed" in table[2]["what"] else None, "normals_tagged_kernel")):
+                    if row is not None:
+                        uc = unit_counters(sub, n)
+                        if uc:
+                            row["counters"] = uc
+        except Exception:
+            pass
         sh = out.get("sharded_10m", {}).get("roofline") if isinstance(out.get("sharded_10m"), dict) else None
         if sh and sh.get("main_pass_us"):
             table.append({"what": "icp main pass, 10 M-point sharded entry (one rank)", "alg_bytes": sh["alg_bytes_per_iteration"], "us": sh["main_pass_us"], "frac": sh["main_pass_frac"]})

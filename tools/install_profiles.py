@@ -13,7 +13,9 @@ shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, f"{name}_summar
 ks = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
 if ks: shutil.copy(ks[-1], os.path.join(dst, f"{name}_kernel_stats.csv"))
 summ = json.load(open(os.path.join(src, "summary.json")))
-kernels = {k: {kk: vv for kk, vv in v.items() if "SIZE" in kk or "traffic" in kk} for k, v in summ.items() if "traffic_bytes_raw" in v}
+UNIT = ("SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCP_TOTAL_CACHE_ACCESSES_sum",
+        "TCP_PENDING_STALL_CYCLES_sum", "achieved_waves_per_simd", "lds_bank_conflict_rate", "avg_us")
+kernels = {k: {kk: vv for kk, vv in v.items() if "SIZE" in kk or "traffic" in kk or kk in UNIT} for k, v in summ.items() if "traffic_bytes_raw" in v}
 json.dump({"source": f"profiles/{name}_summary.json (tools/collect_profiles.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                      "`python3 bench.py --steps 2 --warmup 1 --no-extras`)",
            "note": "FETCH_SIZE / WRITE_SIZE in KiB per launch averaged over the launches of the run; traffic_bytes_corrected doubles the fetch "

@@ -32,7 +32,7 @@ def short(name):
               "icp_refine_kernel<1>", "icp_refine_kernel<0>", "icp_refine_kernel<2>", "icp_finalize_kernel", "knn_kernel",
               "bin_count_kernel", "bin_offsets_kernel", "bin_scatter_kernel", "bin_place_kernel", "bbox_state_init_kernel", "vox_hist_kernel", "vox_scatter_kernel",
               "vox_rank_kernel", "vox_flag_kernel", "vox_centroid_kernel",
-              "normals_knn_pca_kernel", "normals_coop_kernel", "normals_overflow_kernel", "cell_hist_kernel", "place_kernel", "rerank_kernel", "scatter_kernel",
+              "normals_tagged_kernel", "normals_knn_pca_kernel", "normals_coop_kernel", "normals_overflow_kernel", "cell_hist_kernel", "place_kernel", "rerank_kernel", "scatter_kernel",
               "rank_gather_kernel", "scan_apply_kernel", "scan_top_kernel", "scan_reduce_kernel", "bbox_kernel",
               "gather_normals_kernel", "icp_finish_kernel", "icp_write_corr_kernel", "icp_final_mse_kernel"]:
         if k.split("<")[0] in name and (("<" not in k) or (k[k.index("<"):] in name)):
@@ -57,8 +57,9 @@ for sub, cname in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
         res.setdefault(k, {})[cname + "_KiB_per_launch"] = sum(v) / len(v)
 
 sq = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in load("pmc_sq", "counter_collection"):
-    sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for sub in ("pmc_sq", "pmc_sq2", "pmc_tcp"):
+    for r in load(sub, "counter_collection"):
+        sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sq.items():
     for c, v in d.items():
         res.setdefault(k, {})[c] = sum(v) / len(v)
@@ -76,4 +77,14 @@ print("\n== SQ counters per launch (millions) ==")
 for k, d in res.items():
     if "SQ_INSTS_VALU" in d:
         print(f"{k:46s} " + " ".join(f"{c.replace('SQ_','')}={d[c]/1e6:.2f}" for c in sorted(d) if c.startswith("SQ_")))
+# derived per launch (round 6, SURVEY 8d secondary figures): achieved waves per SIMD = wave-cycles / busy CU-cycles (SQ_WAVE_CYCLES counts
+# quad-cycles per wave, a CU has four SIMDs: the factors cancel), LDS bank-conflict rate = conflict cycles / LDS-array cycles
+print("\n== unit counters per launch ==")
+for k, d in res.items():
+    if "SQ_BUSY_CU_CYCLES" in d and d["SQ_BUSY_CU_CYCLES"] > 0:
+        if "SQ_WAVE_CYCLES" in d: d["achieved_waves_per_simd"] = d["SQ_WAVE_CYCLES"] / d["SQ_BUSY_CU_CYCLES"]
+        if d.get("SQ_LDS_IDX_ACTIVE", 0) > 0: d["lds_bank_conflict_rate"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
+        print(f"{k:46s} busy_cu_cycles={d['SQ_BUSY_CU_CYCLES']/1e6:.2f}M valu={d.get('SQ_INSTS_VALU', d.get('SQ_ACTIVE_INST_VALU', 0))/1e6:.2f}M "
+              f"tcp_lookups={d.get('TCP_TOTAL_CACHE_ACCESSES_sum', 0)/1e6:.2f}M waves/SIMD={d.get('achieved_waves_per_simd', float('nan')):.2f} "
+              f"lds_conflict_rate={d.get('lds_bank_conflict_rate', float('nan')):.3f}")
 json.dump(res, open(f"{out}/summary.json", "w"), indent=1)
