@@ -21,6 +21,21 @@ def test_randomized_differential_run(ctx):
 
 
 @pytest.mark.gpu
+def test_second_neighbour_certificate_and_dense_trips_never_change_a_result():
+    """Round 6: the main pass keeps a match whose distance is below (a lower bound of the distance to every OTHER target point, measured
+    where the point last searched) - (how far the point has moved since), and packs the lanes that still search into dense trips.
+    tools/dev/vor_fuzz.py "second": the same seeded registrations (odd clouds, 3 - 25 iterations, noisy pairs that switch the certificate
+    on) with the certificate and with TC_DEBUG=4096 (off; the development build of the same objects): bit-identical transforms, mse,
+    iteration counts and correspondences (registration.rs:87-107: the nearest neighbour is the nearest neighbour)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vor_fuzz", os.path.join(os.path.dirname(__file__), "..", "tools", "dev", "vor_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, bad = mod.compare(12.0, 7, min_cases=10, what="second")
+    assert n >= 10 and bad == 0
+
+
+@pytest.mark.gpu
 def test_inscribed_ball_test_never_changes_a_result():
     """tools/dev/vor_fuzz.py: the same seeded sequence of registrations on odd clouds (slabs, surfaces, lattices, duplicates,
     non-finite points, handles and plain calls, 3-25 iterations) with the inscribed-ball bounds from the first iteration on and

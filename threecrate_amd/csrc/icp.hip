@@ -21,6 +21,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -51,6 +52,8 @@ struct IcpHeader {
     float prev_mse, conv_thr, max_dist;
     uint32_t iterations;
     int32_t done;
+    float d_ang, d_t;          // (words 17 .. 19: a second scalar load, issued with the first)
+    uint32_t d_run;
 };
 static_assert(offsetof(IcpState, done) == 48 && offsetof(IcpState, max_dist) == 60 && offsetof(IcpState, iterations) == 36 &&
               offsetof(IcpState, prev_mse) == 28 && offsetof(IcpState, conv_thr) == 56, "IcpState header layout");
@@ -64,6 +67,7 @@ __device__ __forceinline__ IcpHeader load_header(const IcpState *st) {
     o.done = (int32_t)h[12];
     o.conv_thr = __uint_as_float(h[14]);
     o.max_dist = __uint_as_float(h[15]);
+    o.d_ang = st->d_ang; o.d_t = st->d_t; o.d_run = st->d_run;
     return o;
 }
 
@@ -222,10 +226,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *p) {
 #ifndef TC_ICP_STEP
 #define TC_ICP_STEP 4          // records per candidate step
 #endif
-template <bool STATS = false>
+// track2 (wave-uniform): the candidate loop also keeps the SECOND smallest distance, and low2 returns a lower bound of the squared
+// distance from the query to every target point other than the one found (the second-neighbour certificate of the main pass).
+template <bool STATS = false, bool T2 = false>
 __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, float y, float z, float ub2,
                                                  float &best, uint32_t &bestj, bool &refine, float max_dist,
-                                                 uint2 (*spans)[kIcpBlock], uint32_t &nsteps, const float *pts12 TC_STAMP_ARGS
+                                                 uint2 (*spans)[kIcpBlock], uint32_t &nsteps, const float *pts12, bool track2, float &low2 TC_STAMP_ARGS
                                                  ) {
     const GridGeom &g = gv.g;
     int cx, cy, cz;
@@ -308,7 +314,10 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         j = mask ? se.x : 0u; e = mask ? se.y : 0u;
         mask &= mask - 1u;
     }
-    while (j < e) {
+    float second = INFINITY;          // (track2) the second smallest distance seen, a record met twice counting twice (the safe side)
+    // (the step as a generic lambda instantiated twice: with the second minimum as a wave-uniform `if` INSIDE one loop, the plain
+    // loop -- a single basic block, and measurably sensitive to that -- would be cut in two by a branch per step)
+    auto step = [&](auto with_second) {
         const int kn = mask ? __ffs(mask) - 1 : 0;
         const uint2 nse = spans[kn][threadIdx.x];
         // The candidates come from the PACKED copy of the sorted records (12 bytes each, DeviceIndex::pts12): four records = 48
@@ -320,6 +329,7 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         asm("v_lshlrev_b32 %0, 2, %1\n\tv_lshl_add_u32 %0, %1, 3, %0" : "=&v"(o) : "v"(j));
         auto add = [](float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
         // four records = three 16-byte registers -> the smallest of their four distances and its position (lowest on ties)
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;          // (the step's four distances, for the second smallest of track2)
         auto quad = [&](const f32x4 &ra, const f32x4 &rb, const f32x4 &rc, uint32_t jb, float &m, uint32_t &im) {
             const f32x2 d0 = ra.xy - qxy, d1 = ra.zw - qzx, d2 = rb.xy - qyz, d3 = rb.zw - qxy, d4 = rc.xy - qzx, d5 = rc.zw - qyz;
             const f32x2 s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3, s4 = d4 * d4, s5 = d5 * d5;
@@ -331,6 +341,7 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
             const bool bb = m23 < m01;
             m = bb ? m23 : m01;
             im = bb ? i23 : i01;
+            w0 = v0; w1 = v1; w2 = v2; w3 = v3;
         };
         const f32x4 ra = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o, 0, 0));
         const f32x4 rb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 16u, 0, 0));
@@ -345,6 +356,14 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
 #if TC_ICP_STEP == 8
         { float m2; uint32_t im2; quad(rd, re, rf, j + 4, m2, im2); const bool b2 = m2 < m; m = b2 ? m2 : m; im = b2 ? im2 : im; }
 #endif
+        if constexpr (decltype(with_second)::value) {
+            // the step's own second smallest (of v0 .. v3 the loser of the final, or the smaller loser of the semi-finals), then the two
+            // smallest of {best, second, m, that}: ~8 instructions, only in the instantiation the certificate's passes run
+            auto mn = [](float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };      // (as instructions:
+            auto mx = [](float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };      //  no canonicalising v_max x, x)
+            const float m2 = mn(mx(mn(w0, w1), mn(w2, w3)), mn(mx(w0, w1), mx(w2, w3)));
+            second = mn(mx(best, m), mn(second, m2));
+        }
         const bool upd = m < best;
         best = upd ? m : best;
         bestj = upd ? im : bestj;
@@ -354,12 +373,23 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         j = adv ? nse.x : j;
         e = adv ? nse.y : e;
         mask = adv ? (mask & (mask - 1u)) : mask;
+    };
+    // (T2: only the certificate's instantiation of the main pass holds the second loop at all -- compiled into the plain kernel, the
+    // inactive branch and its registers cost the benchmark pair 1.5 % of the whole job: profiles/r06_dense_trips_certificate.txt)
+    if constexpr (T2) {
+        if (track2) { while (j < e) step(std::true_type{}); }
+        else { while (j < e) step(std::false_type{}); }
+    } else {
+        while (j < e) step(std::false_type{});
     }
     TC_STAMP(2);
     // Ring-1 exactness rule: best <= ((1 + m_f - 2e-3) h)^2 + |q - q'|^2, m_f >= 0 the clearance of q' to the block's faces.  Nearly
     // every lane passes it with m_f = 0 already (the nearest neighbour lies within one cell edge): only the others form the
     // clearance -- a real branch, skipped by the whole wave in most trips (~35 instructions of selects and minima per trip).
     const float h0 = (1.0f - 2e-3f) * g.h;
+    // (track2) every target point other than the one found is at least this far (squared): the second smallest distance scanned; a
+    // point in a pruned row or cell lies beyond the budget ub2; a point outside ring 1 beyond a cell edge (the bound of the rule below)
+    low2 = (T2 && track2) ? fminf(fminf(second, ub2), h0 * h0 + out2) : 0.0f;
     refine = false;
     if (!(best <= h0 * h0 + out2) && !(ub2 < 0.0f)) {          // (ub2 < 0: a lane that does not search -- its flag is ignored anyway)
         // clearance of q' to the ring-1 block's faces, in cell edges: only a face with cells BEYOND it counts (where the grid ends at
@@ -505,6 +535,13 @@ __device__ __forceinline__ void accumulate_gicp(float (&acc)[TC_ICP_SUMS_P2PLANE
 //      (independent loads, one round trip) and folded into the f32 per-lane sums, which are then
 //      wave-reduced into the block's f64 LDS row, so that nothing but that row survives the group.
 constexpr int kIcpGroup = 4;
+constexpr int kSearchersCol = TC_ICP_SUMS_STRIDE - 1;          // spare column of the per-block rows: lanes that searched (icp_correspond_reduce_kernel)
+static_assert(kSearchersCol >= TC_ICP_SUMS_P2PLANE && kSearchersCol >= TC_ICP_SUMS_P2P, "the searcher count needs a column the sums do not use");
+// Dense search trips (round 6, the certificate's instantiation): the lanes of a wave that have to search -- scattered over the group's
+// four trips, each trip a chain of dependent reads that the wave walks for one searching lane as for sixty-four -- are packed through
+// LDS into ceil(S / 64) trips of 64 whenever that halves the number of trips.  Same queries, same searches, same results handed back
+// in the same (trip, lane) order: same bits.  With the second-neighbour certificate a converged TUM-shaped pair has ~2 searching lanes
+// per wave: ONE trip instead of up to four (profiles/r06_dense_trips_certificate.txt).
 constexpr int kRefineBlocks = 256;          // blocks of the refine pass = rows handed to the finalize step
 // The refine list: one count per wave of a main block (kMaxPartialBlocks x 4 words), then the entries, 32 bytes each:
 //   {x, y, z (the transformed query), source index} {best known d2, its position, -, -}
@@ -524,12 +561,14 @@ __host__ __device__ __forceinline__ uint4 *refine_entries(uint32_t *rlist) {
 // STATS: the counting instantiation (tc_profile_enable(ctx, 3) / TC_DEBUG & 8): wave trips, trips without a search, searches,
 // candidate steps the lanes needed, candidate steps the trips took (their slowest lane) -> IcpState::refine_ring_hist[2..6].
 // The product's instantiation carries none of it.
-template <int MODE, bool STATS = false>
+// CERT: the instantiation that maintains and uses the second-neighbour certificate (round 6; chosen by the host per chunk of
+// iterations from the word the finalize launch leaves in the pinned block: run_chunked).  The plain instantiation holds none of it.
+template <int MODE, bool STATS = false, bool CERT = false>
 __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, float4 *wsrc, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ rlist,
     double *__restrict__ partials, int dbg, const float4 *__restrict__ src_cov, const float4 *__restrict__ vor,
-    unsigned long long *__restrict__ blk_times, const float *__restrict__ pts12) {
+    unsigned long long *__restrict__ blk_times, const float *__restrict__ pts12, float4 *__restrict__ wl) {
     constexpr bool P2PLANE = MODE == 1;
     unsigned long long t_begin = 0;
     if (blk_times) t_begin = __builtin_amdgcn_s_memrealtime();          // TC_DEBUG & 1024: per-block start / end stamps (100 MHz)
@@ -552,6 +591,9 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     if (hd.done) return;
     __shared__ double red[kIcpBlock / 64][TC_ICP_SUMS_STRIDE];
     __shared__ uint2 spans[kSpanRows][kIcpBlock];
+    // the searching lanes of a wave's group, packed (dense trips below): {x, y, z, budget} in, {best, position, refine flag, bound} back
+    // (the certificate's instantiation only: 16 KB per block)
+    __shared__ float4 qbuf[CERT ? kIcpBlock / 64 : 1][CERT ? kIcpGroup * 64 : 1];
 #ifdef TC_ICP_LDS_PAD
     __shared__ uint32_t lds_pad[TC_ICP_LDS_PAD / 4];          // occupancy probe: fewer blocks fit a CU
     if (hd.iterations == 0xFFFFFFFFu) lds_pad[threadIdx.x] = threadIdx.x;
@@ -563,11 +605,26 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     const uint32_t wave_cap = chunk / kWavesPerBlock;
     uint4 *__restrict__ const wseg = refine_entries(rlist) + 2 * ((size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * wave_cap;
     uint32_t wcnt = 0;                                     // this wave's entries so far (wave-uniform)
+    uint32_t wsearch = 0;                                  // lanes of this wave that had to search (wave-uniform): the rows' spare column
     const GridGeom &g = tgt.g;
     const float q[4] = {hd.q[0], hd.q[1], hd.q[2], hd.q[3]};
     const float t[3] = {hd.t[0], hd.t[1], hd.t[2]};
     const float max_dist = hd.max_dist;
     const bool warm = hd.iterations > 0 && !(dbg & 1);
+    // The second-neighbour certificate (round 5).  wl[j] = (x_ref, L): where source point j stood when it last searched, and a lower
+    // bound L of the distance from THERE to every target point other than the match it found.  Wherever the point stands now,
+    // every other target point is at least L - |x - x_ref| away: a match closer than that is THE nearest neighbour, strictly -- no
+    // search.  (The displacement is measured, not accumulated from per-update bounds: a converged transform still wobbles by ~1e-5
+    // per update, and a bound eroded by that every pass sends a few per cent of the lanes back to search in every pass.)  The inscribed-ball test needs |T s - p| < d_nn(p) / 2, which sensor noise of the order of the
+    // point spacing defeats for good (TUM-shaped pair: 85 % of the points searched in every iteration, converged or not); this one
+    // needs |T s - p| < (distance to the runner-up) - delta, which holds for every point that is not an exact tie once the
+    // transform has stopped.  Off (d_ang < 0) while the update is large; TC_DEBUG & 4096 switches it off altogether (A/B).
+    const bool track = CERT && TC_ICP_STEP == 4 && warm && wl != nullptr && hd.d_ang >= 0.0f && hd.d_run >= 1u && !(dbg & 4096);
+    // (the bounds in wl are the previous pass's only if that pass maintained them too: the switch may flip on and off while the
+    // registration hovers around the threshold, and a bound that slept through a large update is no bound)
+    const bool use_bounds = track && hd.d_run >= 2u;
+    // what the roundings of two passes' query positions can differ by, on top of the update itself: a few ulps of |x| + |t| each
+    const float t_norm = sqrtf(hd.t[0] * hd.t[0] + hd.t[1] * hd.t[1] + hd.t[2] * hd.t[2]);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane < TC_ICP_SUMS_STRIDE) red[w][lane] = 0.0;          // each wave owns one row
 
@@ -610,6 +667,12 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             const float4 *__restrict__ prec = vor != nullptr ? vor : tgt.pts;
 #pragma unroll
             for (int u = 0; u < kIcpGroup; ++u) pv[u] = prec[pjv[u] != 0xFFFFFFFFu ? pjv[u] : 0u];
+            float4 lw[kIcpGroup];              // (track) the points' reference positions and bounds: one coalesced 16-byte read each
+#pragma unroll
+            for (int u = 0; u < kIcpGroup; ++u) {
+                lw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (use_bounds) { const uint32_t j = gb + u * kIcpBlock + threadIdx.x; lw[u] = wl[j < end ? j : beg]; }
+            }
 #pragma unroll
             for (int u = 0; u < kIcpGroup; ++u) {
                 iso_apply(q, t, sv[u].x, sv[u].y, sv[u].z, px[u], py[u], pz[u]);
@@ -620,7 +683,22 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
                 // target point (shaved).  |T s - p| < d_nn(p) / 2 puts every other target point t at |T s - t| >= d_nn(p) - |T s - p|
                 // > |T s - p|: the previous match is still THE nearest neighbour, nothing has to be searched.  The flag travels
                 // in the sign bit of the (non-negative) bound.
-                ubp[u] = (d < vr) ? -d : d;
+                bool kept = d < vr;
+                if (track) {
+                    // how far the point stands from where its bound was measured, plus what the roundings of the two positions can
+                    // differ by (a few ulps of |x| + |t| each); the comparison is made on squares with a relative margin of 2e-5
+                    const float ex = px[u] - lw[u].x, ey = py[u] - lw[u].y, ez = pz[u] - lw[u].z;
+                    const float r = __builtin_amdgcn_sqrtf(px[u] * px[u] + py[u] * py[u] + pz[u] * pz[u]);
+                    const float moved = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.00001f + 3e-6f * (r + t_norm);
+                    const float lm = lw[u].w - moved;
+                    const bool cert = use_bounds && lm > 0.0f && d * 1.00002f < lm * lm;
+                    // the first pass after the switch came on: whatever the record held is void (matches may have changed while nobody
+                    // kept it); a lane that goes on to search writes a fresh one behind its search
+                    const uint32_t j = gb + u * kIcpBlock + threadIdx.x;
+                    if (!use_bounds && j < end) wl[j] = make_float4(px[u], py[u], pz[u], 0.0f);
+                    kept = kept || cert;
+                }
+                ubp[u] = kept ? -d : d;
             }
         }
         // ---- stage 3 ----
@@ -628,6 +706,72 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
         { float sink = px[0] + py[1] + pz[2] + ubp[3] + ubp[0] + ubp[1] + ubp[2]; asm volatile("" :: "v"(sink)); }
 #endif
         TC_STAMP(0);
+        // ---- stage 3: the searches of the group.  Which lanes search is known for all four trips at once; when packing them halves
+        // the number of trips (dense form, below) the wave searches in dense trips through LDS, else trip by trip in place ----
+        // (the plain instantiation computes none of this: it ballots trip by trip, as before)
+        [[maybe_unused]] unsigned long long smv[kIcpGroup] = {0ull, 0ull, 0ull, 0ull};
+        [[maybe_unused]] uint32_t sbase[kIcpGroup + 1] = {0u, 0u, 0u, 0u, 0u};
+        [[maybe_unused]] uint32_t nsearch = 0u;
+        [[maybe_unused]] bool dense = false;
+        [[maybe_unused]] const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        if constexpr (CERT) {
+            uint32_t trips_in_place = 0u;
+#pragma unroll
+            for (int u = 0; u < kIcpGroup; ++u) {
+                const bool keep = __float_as_uint(ubp[u]) >> 31;
+                smv[u] = __ballot(fin[u] && !keep);
+                sbase[u + 1] = sbase[u] + (uint32_t)__popcll(smv[u]);
+                trips_in_place += smv[u] != 0ull ? 1u : 0u;
+            }
+            nsearch = sbase[kIcpGroup];
+            dense = 2u * ((nsearch + 63u) / 64u) <= trips_in_place;
+        }
+        if constexpr (CERT) if (dense) {
+#pragma unroll
+            for (int u = 0; u < kIcpGroup; ++u) {
+                const bool keep = __float_as_uint(ubp[u]) >> 31;
+                float ub2 = fabsf(ubp[u]);
+                if (track) ub2 *= 6.25f;          // (a search that is to MEASURE the second-neighbour bound looks 2.5 times as far: see the in-place form)
+                if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f);
+                if (fin[u] && !keep) qbuf[w][sbase[u] + (uint32_t)__popcll(smv[u] & lt_mask)] = make_float4(px[u], py[u], pz[u], ub2);
+            }
+            // (a wave's own LDS traffic is served in order: its lanes read what other lanes of the same wave wrote, no block barrier)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+            for (uint32_t tb = 0; tb < nsearch; tb += 64u) {
+                const uint32_t qi = tb + (uint32_t)lane;
+                const bool act = qi < nsearch;
+                const float4 qv = qbuf[w][act ? qi : tb];
+                float best = INFINITY;
+                uint32_t bestg = 0xFFFFFFFFu;
+                bool refine = false;
+                uint32_t nst = 0u;
+                float low2 = 0.0f;
+                nn_search_pruned<STATS, CERT>(tgt, qv.x, qv.y, qv.z, act ? qv.w : -1.0f, best, bestg, refine, max_dist, spans, nst, pts12, track, low2 TC_STAMP_PASS);
+                if (act) qbuf[w][qi] = make_float4(best, __uint_as_float(bestg), __uint_as_float(refine ? 1u : 0u), low2);
+                if constexpr (STATS) {
+                    uint32_t mx = act ? nst : 0u, sm = act ? nst : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sm += (uint32_t)__shfl_xor((int)sm, o); }
+                    if (lane == 0) {
+                        IcpState *sw = const_cast<IcpState *>(st);
+                        atomicAdd(&sw->refine_ring_hist[2], mx);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&sw->refine_ring_hist[3]), (unsigned long long)sm);
+                        atomicAdd(&sw->refine_ring_hist[7], min(nsearch - tb, 64u));
+                        atomicAdd(&sw->refine_ring_hist[5], 1u);
+                    }
+                }
+            }
+            if constexpr (STATS) {          // (the group's trips that did not have to be taken count as trips without a search)
+                const uint32_t taken = (nsearch + 63u) / 64u;
+                if (lane == 0 && taken < (uint32_t)kIcpGroup) {
+                    IcpState *sw = const_cast<IcpState *>(st);
+                    atomicAdd(&sw->refine_ring_hist[5], (uint32_t)kIcpGroup - taken);
+                    atomicAdd(&sw->refine_ring_hist[6], (uint32_t)kIcpGroup - taken);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 #pragma unroll
         for (int u = 0; u < kIcpGroup; ++u) {
             // Wave priority by progress inside the group (round 4; s_setprio takes an immediate: u is a constant after unrolling).
@@ -650,23 +794,38 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             uint32_t bestg = 0xFFFFFFFFu;
             bool refine = false;
             uint32_t nst = 0u;
-            const unsigned long long smask = __ballot(in && !keep);
-            if (smask != 0ull) nn_search_pruned<STATS>(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans, nst, pts12 TC_STAMP_PASS);
-            if constexpr (STATS) {
-                uint32_t mx = nst, sm = (in && !keep) ? nst : 0u;
+            // (track) a search that is to MEASURE the bound looks 2.5 times as far as the previous match: what it does not scan could
+            // be anywhere beyond its budget, and a budget of exactly the match's distance would cap the bound at that distance --
+            // the certificate could never fire.  The superset it scans holds the same nearest neighbour.
+            if (track) { ub2 = ub2p * 6.25f; if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f); }
+            const unsigned long long smask = CERT ? smv[u] : __ballot(in && !keep);
+            wsearch += (uint32_t)__popcll(smask);
+            float low2 = 0.0f;
+            if (CERT && dense) {
+                if (in && !keep) {          // the dense trips' result of this lane's query
+                    const float4 rv = qbuf[CERT ? w : 0][CERT ? sbase[u] + (uint32_t)__popcll(smask & lt_mask) : 0u];
+                    best = rv.x; bestg = __float_as_uint(rv.y); refine = __float_as_uint(rv.z) != 0u; low2 = rv.w;
+                }
+            } else {
+                if (smask != 0ull) nn_search_pruned<STATS, CERT>(tgt, x, y, z, (keep || !in) ? -1.0f : ub2, best, bestg, refine, max_dist, spans, nst, pts12, track, low2 TC_STAMP_PASS);
+                if constexpr (STATS) {
+                    uint32_t mx = nst, sm = (in && !keep) ? nst : 0u;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sm += (uint32_t)__shfl_xor((int)sm, o); }
-                if (lane == 0) {
-                    IcpState *sw = const_cast<IcpState *>(st);
-                    atomicAdd(&sw->refine_ring_hist[2], mx);                               // steps the trip took (its slowest lane)
-                    // steps its lanes needed: the one counter that can pass 2^32 inside a call (10 M points x 50 iterations x ~5
-                    // steps: ADVICE r5) -> a 64-bit add on the aligned pair [3..4]; the searches moved to [7]
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&sw->refine_ring_hist[3]), (unsigned long long)sm);
-                    atomicAdd(&sw->refine_ring_hist[7], (uint32_t)__popcll(smask));        // searches (<= points x iterations / call: checked on the host)
-                    atomicAdd(&sw->refine_ring_hist[5], 1u);                               // wave trips
-                    if (smask == 0ull) atomicAdd(&sw->refine_ring_hist[6], 1u);            // ... without a search
+                    for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sm += (uint32_t)__shfl_xor((int)sm, o); }
+                    if (lane == 0) {
+                        IcpState *sw = const_cast<IcpState *>(st);
+                        atomicAdd(&sw->refine_ring_hist[2], mx);                               // steps the trip took (its slowest lane)
+                        // steps its lanes needed: the one counter that can pass 2^32 inside a call (10 M points x 50 iterations x ~5
+                        // steps: ADVICE r5) -> a 64-bit add on the aligned pair [3..4]; the searches moved to [7]
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&sw->refine_ring_hist[3]), (unsigned long long)sm);
+                        atomicAdd(&sw->refine_ring_hist[7], (uint32_t)__popcll(smask));        // searches (<= points x iterations / call: checked on the host)
+                        atomicAdd(&sw->refine_ring_hist[5], 1u);                               // wave trips
+                        if (smask == 0ull) atomicAdd(&sw->refine_ring_hist[6], 1u);            // ... without a search
+                    }
                 }
             }
+            // (track) a lane that searched has measured its bound afresh: the distance, a hair short (v_sqrt_f32 is good to an ulp)
+            if (track && in && !keep && j < end) wl[j] = make_float4(x, y, z, refine ? 0.0f : __builtin_amdgcn_sqrtf(fmaxf(low2, 0.0f)) * 0.999999f);
             if (keep) { best = ub2p; bestg = pj; }
             refine = refine && in && !keep;
             const unsigned long long rmask = __ballot(refine);
@@ -738,10 +897,13 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             }
         }
     }
+    // column kSearchersCol of the row (beyond the sums' columns, which end at 29): how many lanes of the block searched -- summed with
+    // the rest by the refine fold and icp_finalize, which leaves the total in IcpState::searchers (the certificate's gate, compose())
+    if (lane == kSearchersCol) red[w][kSearchersCol] = (double)wsearch;
     __syncthreads();
     if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
         double sum = 0.0;
-        if (threadIdx.x < NACC) {
+        if (threadIdx.x < NACC || threadIdx.x == kSearchersCol) {
 #pragma unroll
             for (int w2 = 0; w2 < kIcpBlock / 64; ++w2) sum += red[w2][threadIdx.x];
         }
@@ -1312,7 +1474,36 @@ __device__ __forceinline__ void quat_mul_f(const float a[4], const float b[4], f
 
 // current = delta * current  (Isometry3 product, registration.rs:321 / :576); the current transform comes from the header the
 // kernel loaded at its start -- reading it again through `st` would be one more round trip to memory on the lane everything waits for
-__device__ void compose(const IcpHeader &hd, IcpState *st, const float dq[4], const float dt[3]) {
+__device__ void compose(const IcpHeader &hd, IcpState *st, const float dq[4], const float dt[3], const GridGeom &g, double searchers, double pairs, bool cert_active) {
+    // How far this update moves a point x: |R_d x + t_d - x| <= 2 |sin(theta / 2)| |x| + |t_d|, and 2 |sin(theta / 2)| = 2 |(i, j, k)| of
+    // the unit delta quaternion.  Left in the state for the next main pass's second-neighbour certificate (icp_correspond_reduce_kernel),
+    // which is switched on once the update is small against the cell edge for a point at the far corner of the target's box -- while
+    // the clouds still move by cells nothing would be certified and the bookkeeping would only cost.
+    {
+        const float ang = 2.0f * sqrtf(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]) * 1.0001f;
+        const float tn = sqrtf(dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2]) * 1.0001f;
+        const float rx_ = fmaxf(fabsf(g.minx), fabsf(g.maxx)), ry_ = fmaxf(fabsf(g.miny), fabsf(g.maxy)), rz_ = fmaxf(fabsf(g.minz), fabsf(g.maxz));
+        const float far = sqrtf(rx_ * rx_ + ry_ * ry_ + rz_ * rz_);
+        // (a hundredth of a cell edge: the uniform benchmark pair gets there after ~40 of its 50 iterations -- and hovers around a tenth
+        // of an edge from iteration 15 to 35, on and off: tools/dev/delta_probe.py --, the TUM-shaped pair after ~12)
+        const bool small = ang < 5e-3f && ang * far + tn < 0.01f * g.h;
+        // ... and switched on only where it has something to win (round 6): the pass that has just run still sent more than a tenth
+        // of its points to a search although the update is small -- sensor noise of the order of the point spacing, which the
+        // inscribed-ball test cannot get past (TUM-shaped pair: 85 %).  A clean pair (the uniform benchmark pair once aligned: 0 %) never
+        // pays the bookkeeping (one 16-byte read per point and pass, ~2 us per pass at 1 M points).  Once on it stays on while the
+        // updates stay small: its own success (0.75 % searchers) must not switch it off.
+        // Switching ON also asks for an update three times smaller than staying on does: the uniform benchmark pair hovers around the
+        // threshold for twenty iterations while 69 % of its points still search because the clouds still MOVE -- there the wider
+        // measuring scans and the bookkeeping cost 2 % of the whole job and certify nothing (measured: 17 440 vs 17 770 it/s).
+        // (d_ang >= 0 = the certificate is WANTED: the finalize launch tells the host -- run_chunked --, which enqueues the certificate's
+        // instantiation of the main pass from the chunk after next on; d_run counts the consecutive passes that instantiation has run
+        // with small updates: it maintains the bounds from 1 on and uses them from 2 on, and a pass of the plain kernel resets it)
+        const bool worth = hd.d_ang >= 0.0f || (searchers > 0.1 * pairs && ang * far + tn < 0.003f * g.h);
+        st->searchers = (uint32_t)fmin(searchers, 4.0e9);
+        st->d_ang = (small && worth) ? ang : -1.0f;
+        st->d_t = tn;
+        st->d_run = (small && worth && cert_active) ? min(hd.d_run + 1u, 1000000u) : 0u;          // a pass that did not maintain the bounds invalidates them
+    }
     const float cq[4] = {hd.q[0], hd.q[1], hd.q[2], hd.q[3]};
     const float ct[3] = {hd.t[0], hd.t[1], hd.t[2]};
     const float zero[3] = {0.0f, 0.0f, 0.0f};
@@ -1419,7 +1610,7 @@ constexpr int kFinalizeThreads = 512;
 // the calling block (kFinalizeThreads threads): fixed-order sum of the rows, solve, compose, bookkeeping
 template <int MODE>
 __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
-                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE], const IcpHeader &hd) {
+                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE], const IcpHeader &hd, bool cert_active = false) {
     const bool done = hd.done != 0;
     constexpr bool P2PLANE = MODE != 0;        // GICP solves the same 6x6 system from the same 29 words (gicp.rs:258-281)
     if (do_sum) {
@@ -1490,7 +1681,7 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
         quat_mul_f(qz, qy, zy);
         quat_mul_f(zy, qx, rot);
         const float dt[3] = {(float)x[3], (float)x[4], (float)x[5]};
-        compose(hd, st, rot, dt);
+        compose(hd, st, rot, dt, g, S[kSearchersCol], cnt, cert_active);
         finish_iteration(hd, st, (float)(S[27] / cnt), (uint32_t)cnt);
     } else {
         const double cnt = S[16];
@@ -1510,7 +1701,7 @@ __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblo
         rotmat_to_quat(R, dq);
         float dt[3];
         for (int r = 0; r < 3; ++r) dt[r] = (float)(cq[r] - (R[r][0] * cs[0] + R[r][1] * cs[1] + R[r][2] * cs[2]));
-        compose(hd, st, dq, dt);
+        compose(hd, st, dq, dt, g, S[kSearchersCol], cnt, cert_active);
         double nmse = S[15];                               // sum |s - q|^2 before the update (registration.rs:214)
         if (st->kiss) {
             // KISS-ICP measures AFTER applying delta (kiss_icp.rs:270-276).  With the optimal translation the
@@ -1531,7 +1722,7 @@ template <int MODE>
 // the stream between two iterations (a 4-byte hipMemcpyAsync is a 4.7 us blit kernel; eight of them per 50-iteration call)
 __global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const double *__restrict__ partials, uint32_t nblocks,
                                                            IcpState *__restrict__ st, const GridGeom g, int do_sum, int do_apply,
-                                                           int32_t *__restrict__ done_out) {
+                                                           int32_t *__restrict__ done_out, int cert_active) {
     // (the rows are requested before `done` is known: the test is one more round trip to memory in front of them otherwise)
     const IcpHeader hd = load_header(st);
     __shared__ double sm[kFinalizeThreads / 32][TC_ICP_SUMS_STRIDE];
@@ -1542,14 +1733,15 @@ __global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const do
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     finalize_body<MODE>(partials, nblocks, st, g, do_sum, 0, sm, hd);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    finalize_body<MODE>(partials, nblocks, st, g, 0, do_apply, sm, hd);
+    finalize_body<MODE>(partials, nblocks, st, g, 0, do_apply, sm, hd, cert_active != 0);
     const unsigned long long t2 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) { st->refine_ring_hist[0] += (uint32_t)(t1 - t0); st->refine_ring_hist[1] += (uint32_t)(t2 - t1); }
 #else
-    finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm, hd);
+    finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm, hd, cert_active != 0);
 #endif
     if (done_out && threadIdx.x == 0)      // (thread 0 wrote st->done itself)
-        __hip_atomic_store(done_out, (hd.done || st->done) ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (3 = the chunk has run, the registration goes on AND wants the second-neighbour certificate: compose(), run_chunked)
+        __hip_atomic_store(done_out, (hd.done || st->done) ? 1 : (st->d_ang >= 0.0f ? 3 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // after the last iteration: not-converged epilogue (registration.rs:343-369 / :595-601)
@@ -1645,7 +1837,7 @@ static TileGeom plan_tiles(const GridGeom &g, size_t ns) {
 static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, const float4 *nrm, const float4 *src,
                              uint32_t ns, const IcpLaunch &l, IcpState *st, uint32_t *corr_pos, uint32_t *rlist,
                              double *partials, bool do_sum, bool do_apply, bool do_reduce, const float4 *src_cov = nullptr,
-                             const float4 *vor = nullptr, int32_t *done_out = nullptr) {
+                             const float4 *vor = nullptr, int32_t *done_out = nullptr, float4 *wl = nullptr, bool cert = false) {
     hipStream_t s = ctx->stream;
     const int dbg = debug_flags() | (ctx->profiling == 3 ? 8 : 0);
     double *refine_rows = partials + (size_t)l.nblocks * TC_ICP_SUMS_STRIDE;
@@ -1654,14 +1846,17 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
             ProfScope ps(ctx, mode == 1 ? "icp_correspond_reduce_p2plane" : mode == 2 ? "icp_correspond_reduce_gicp" : "icp_correspond_reduce_p2p", true);
             auto kern = mode == 1 ? icp_correspond_reduce_kernel<1> : mode == 2 ? icp_correspond_reduce_kernel<2> : icp_correspond_reduce_kernel<0>;
             if (dbg & 8) kern = mode == 1 ? icp_correspond_reduce_kernel<1, true> : mode == 2 ? icp_correspond_reduce_kernel<2, true> : icp_correspond_reduce_kernel<0, true>;
+            // the certificate's instantiation (point-to-point and point-to-plane; the counting instantiation and GICP stay plain)
+            cert = cert && wl != nullptr && mode != 2 && !(dbg & 8);
+            if (cert) kern = mode == 1 ? icp_correspond_reduce_kernel<1, false, true> : icp_correspond_reduce_kernel<0, false, true>;
             const float4 *vor_arg = (dbg & 4) ? nullptr : vor;
             unsigned long long *times_arg = (dbg & 1024) ? (unsigned long long *)ctx->dbg_times.p : nullptr;
             if (ps.active())          // a timed launch: the events carry the kernel's own start / end stamps (ProfScope)
                 hipExtLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, ps.e0, ps.e1, 0, tv, nrm, const_cast<float4 *>(src), ns, l.chunk,
-                                      (const IcpState *)st, rlist, partials, dbg, src_cov, vor_arg, times_arg, tv.pts12);
+                                      (const IcpState *)st, rlist, partials, dbg, src_cov, vor_arg, times_arg, tv.pts12, wl);
             else
                 hipLaunchKernelGGL(kern, dim3(l.nblocks), dim3(kIcpBlock), 0, s, tv, nrm, const_cast<float4 *>(src), ns, l.chunk, st, rlist, partials, dbg, src_cov,
-                                   vor_arg, times_arg, tv.pts12);
+                                   vor_arg, times_arg, tv.pts12, wl);
         }
         ProfScope ps(ctx, "icp_refine");
         auto kern = mode == 1 ? icp_refine_kernel<1> : mode == 2 ? icp_refine_kernel<2> : icp_refine_kernel<0>;
@@ -1672,7 +1867,7 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
         ProfScope ps(ctx, "icp_finalize");
         const uint32_t rows = kRefineBlocks;      // the refine pass folded the main pass's rows into its own
         auto kern = mode == 0 ? icp_finalize_kernel<0> : icp_finalize_kernel<1>;
-        hipLaunchKernelGGL(kern, dim3(1), dim3(kFinalizeThreads), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0, (do_apply && !(dbg & 32)) ? 1 : 0, do_apply ? done_out : nullptr);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kFinalizeThreads), 0, s, refine_rows, rows, st, tv.g, do_sum ? 1 : 0, (do_apply && !(dbg & 32)) ? 1 : 0, do_apply ? done_out : nullptr, (cert && do_reduce) ? 1 : 0);
     }
 }
 
@@ -1715,9 +1910,10 @@ __global__ void __launch_bounds__(256) icp_pack12_kernel(const float4 *__restric
 }
 
 // the loop's working copy of the ordered source: x, y, z and, in w, the position of the point's current match (none yet)
-__global__ void __launch_bounds__(256) icp_working_source_kernel(const float4 *__restrict__ src, uint32_t n, float4 *__restrict__ out) {
+__global__ void __launch_bounds__(256) icp_working_source_kernel(const float4 *__restrict__ src, uint32_t n, float4 *__restrict__ out, float4 *__restrict__ wl) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (wl) wl[i] = make_float4(0.f, 0.f, 0.f, 0.f);           // (no second-neighbour bound yet)
     float4 r = src[i];
     r.w = __uint_as_float(0xFFFFFFFFu);
     out[i] = r;
@@ -1730,6 +1926,7 @@ struct IcpSetup {
     DeviceIndex *tix = nullptr;      // the target's index: ctx->tgt_index, or a cloud handle's
     const float4 *src = nullptr;     // the source records in the order the loop walks them (w = original index)
     float4 *wsrc = nullptr;          // the loop's working copy of them (w = position of the current match): what the kernels read
+    float4 *wl = nullptr;            // per source point: reference position + second-neighbour bound of the main pass (behind the working copy)
 };
 // the matches as the refine / write-out kernels address them: the w of the working records, stride 4
 static inline uint32_t *match_words(float4 *wsrc) { return reinterpret_cast<uint32_t *>(wsrc) + 3; }
@@ -1754,6 +1951,7 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
     for (int i = 0; i < 4; ++i) hs->q[i] = init[i];
     for (int i = 0; i < 3; ++i) hs->t[i] = init[4 + i];
     hs->prev_mse = INFINITY;
+    hs->d_ang = -1.0f; hs->d_t = 0.0f; hs->d_run = 0;
     hs->conv_thr = conv_thr;
     hs->max_dist = max_dist;
     hs->kiss = kiss;
@@ -1784,11 +1982,12 @@ static tc_status icp_setup(tc_context *ctx, bool p2plane, const float *d_src, si
         out.tix->pts12_valid = true;
     }
     out.tv = view_of((*out.tix));
-    if (tc_status s = ensure(ctx, ctx->icp_wsrc, (ns + 4) * sizeof(float4))) return s;
+    if (tc_status s = ensure(ctx, ctx->icp_wsrc, 2 * (ns + 4) * sizeof(float4))) return s;
     out.wsrc = (float4 *)ctx->icp_wsrc.p;
+    out.wl = out.wsrc + ns + 4;
     if (ns > 0) {
         ProfScope ps(ctx, "icp_working_source");
-        hipLaunchKernelGGL(icp_working_source_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, out.src, (uint32_t)ns, out.wsrc);
+        hipLaunchKernelGGL(icp_working_source_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, out.src, (uint32_t)ns, out.wsrc, (float4 *)nullptr);
     }
     return TC_OK;
 }
@@ -1868,11 +2067,15 @@ static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate
     TC_HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d_flags, (void *)flags, 0));
     const size_t max_flags = 200;                                  // pinned bytes 1024 .. 2048 hold them (the bbox partials follow)
     size_t it = 0;
+    ctx->icp_cert = false;
     for (size_t c = 0; c < nchunks; ++c) {
         if (c >= 2 && c - 2 < max_flags) {
             // wait for chunk c - 2 (chunk c - 1 keeps the device busy meanwhile); spins, then yields the core (wait_pinned_word)
             if (tc_status s = wait_pinned_word(ctx, (volatile uint32_t *)&flags[c - 2], "ICP loop")) return s;
             if (flags[c - 2] == 1) break;
+            // (3: the registration wants the second-neighbour certificate -- small updates and still searching, compose() -- : the chunks
+            // enqueued from here on run its instantiation of the main pass; a function of the state after chunk c - 2, not of timing)
+            ctx->icp_cert = flags[c - 2] == 3;
         }
         if (c < max_flags) flags[c] = 0;
         for (size_t k = 0; k < chunk_len(c) && it < max_iters; ++k, ++it) {
@@ -1918,7 +2121,7 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     if (tc_status s = run_chunked(ctx, max_iters, dstate, [&](int32_t *done_out) -> tc_status {
             if (enq++ == vor_after() && !vor)
                 if (tc_status s = launch_target_nn_bounds(ctx, (*su.tix), su.tv, dstate, &vor)) return s;
-            launch_iteration(ctx, mode, su.tv, nrm, su.wsrc, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor, done_out);
+            launch_iteration(ctx, mode, su.tv, nrm, su.wsrc, (uint32_t)ns, su.l, dstate, corr_pos, corr + 2 * ns, partials, true, true, true, src_cov, vor, done_out, su.wl, ctx->icp_cert);
             return TC_OK;
         })) return s;
     if (mode == 0) {

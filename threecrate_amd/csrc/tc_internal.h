@@ -65,9 +65,15 @@ struct IcpState {
     uint32_t refine_total;  // statistics: queries served by the refine pass (sum / max over iterations)
     uint32_t refine_max;
     uint32_t refine_ring_hist[8];   // TC_REFINE_STATS builds only: exit ring of the refine queries
+    float    d_ang;         // the last update moved a point x by at most d_ang |x| + d_t (2 |sin(theta / 2)| and |translation| of the delta);
+    float    d_t;           // d_ang < 0: the second-neighbour certificate is off (the update is still large: icp.hip compose())
+    uint32_t d_run;         // consecutive updates small enough for it: the main pass maintains the bounds from 1 on and USES them from 2 on
+    uint32_t searchers;     // lanes of the last main pass that had to search (its rows' spare column, summed by icp_finalize): the certificate's gate
     double   sums[TC_ICP_SUMS_STRIDE];   // packed, fully reduced sums of the current iteration
 };
 
+static_assert(offsetof(IcpState, refine_ring_hist) % 8 == 4 && offsetof(IcpState, sums) % 8 == 0,
+              "refine_ring_hist[3..4] is ONE 64-bit counter of the statistics instantiation (icp.hip): it must sit on an 8-byte boundary");
 constexpr int kIcpBlock = 256;
 // padding behind the sorted records / the prefix sums: the ICP search reads a few entries past a
 // span (4-wide steps) and 16-byte windows of cell_start without clamping
@@ -181,6 +187,7 @@ struct tc_context {
     // search statistics of the ICP main pass, summed over the calls made in profiling mode 3 (tc_profile_enable(ctx, 3)):
     // iterations, wave trips, trips without a search, searches, candidate steps needed, candidate steps taken (slowest lanes)
     unsigned long long stat_icp[6] = {0, 0, 0, 0, 0, 0};
+    bool icp_cert = false;          // run_chunked: the chunks being enqueued run the certificate's instantiation of the main pass
     bool normals_hard_clean = false; // its header (count, exit ticket) is known to be zero: the last serving launch went through
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
