@@ -139,6 +139,31 @@ def correspondence_report(src, tgt, T, g_corr, r_corr):
     return int(len(diff))
 
 
+def own_transform_correspondence_report(src, tgt, g_T_prev, r_T_prev, g_corr, r_corr, max_diff=1000, near=1e-2):
+    """The correspondences of the LAST iteration of two runs whose transforms agree to rounding but not bit for bit (each side searched
+    under its OWN transform of the iteration before, g_T_prev / r_T_prev: 7 floats).  Every differing pair must be each side's nearest
+    candidate under that side's own transform (registration.rs:87-107: the first strict minimum, f32 distances of
+    nearest_neighbor.rs:162-167), and the two candidates must be near-tied (relative distance gap <= `near`): a flip that a
+    1e-7 change of the transform explains, not a search defect.  -> dict(differing, worst_relative_gap)."""
+    assert len(g_corr) == len(r_corr), (len(g_corr), len(r_corr))
+    assert np.array_equal(g_corr[:, 0], r_corr[:, 0])
+    diff = np.nonzero(g_corr[:, 1] != r_corr[:, 1])[0]
+    assert len(diff) <= max_diff, f"{len(diff)} correspondences differ: a defect, not near-ties"
+    worst = 0.0
+    for row in diff:
+        j = int(g_corr[row, 0]); a = int(g_corr[row, 1]); b = int(r_corr[row, 1])
+        tg = O.isometry_apply(g_T_prev, src[j:j + 1])[0]
+        tr = O.isometry_apply(r_T_prev, src[j:j + 1])[0]
+        ga, gb = d2_f32(tgt[a], tg), d2_f32(tgt[b], tg)
+        ra, rb = d2_f32(tgt[a], tr), d2_f32(tgt[b], tr)
+        assert ga <= gb, f"source {j}: under ITS transform the first side's choice {a} (d2 {ga}) is farther than {b} (d2 {gb})"
+        assert rb <= ra, f"source {j}: under ITS transform the second side's choice {b} (d2 {rb}) is farther than {a} (d2 {ra})"
+        gap = max(abs(float(ga) - float(gb)), abs(float(ra) - float(rb))) / max(float(ga), float(gb), 1e-30)
+        assert gap <= near, f"source {j}: candidates {a} / {b} are {gap:.3e} apart (relative): not a near-tie"
+        worst = max(worst, gap)
+    return {"differing": int(len(diff)), "worst_relative_gap": worst}
+
+
 def transform_budget(g_T, run_ref, run_exact, tol, scale=1.0):
     """The transform of a run against the oracle's: within `tol` x `scale` (north_star's 1e-5 Frobenius is stated for clouds of unit
     extent; one ulp of a translation at coordinates of 50 is already 4e-6) -- or, SHOWN not assumed, the reference's sequential f32
