@@ -37,10 +37,7 @@ __device__ __forceinline__ void isometry_apply(const float q[4], const float t[3
 
 // per-block bounding box partials (6 floats per block); the host folds the <= 256 rows
 // (min / max are order independent, so the result equals the reference's sequential fold).
-constexpr int kBboxBlocks = 256;
-// threads per block of the box kernel (round 6: 1024 instead of 256 -- the launch is a handful of dependent round trips with one wave per
-// SIMD, 15.7 us for 12 MB at 1 M points; sixteen waves per CU put four times the reads in flight for the same 256 x 30 atomics)
-constexpr int kBboxThreads = 1024;
+constexpr int kBboxBlocks = 256;          // (round 6: 1024-thread blocks -- four times the reads in flight for the same 256 x 30 atomics -- are SLOWER, 22.8 vs 18.0 us)
 // sbox (optional): four SAMPLE boxes per block.  Sample s = the points with index = s mod 4 whose multiplicative hash
 // falls into one sixteenth of its range: ~n/64 points each, pseudo-random in the index (NOT every 64th point: organised
 // scans are periodic in 64 -- beams, image columns -- and a sample must not be one beam).  A handful of far outliers
@@ -61,10 +58,10 @@ constexpr size_t kBboxStateBytes = 31 * kBboxAccStride * sizeof(uint32_t), kBbox
 // per step as three 16-byte reads (perfectly coalesced; the 12-byte records read one float at a time cost three gathers per
 // point), four steps in flight -- 1 M points are one round trip per thread instead of 16 dependent ones: 22 -> ~8 us.
 template <bool VEC>
-__global__ void __launch_bounds__(kBboxThreads) bbox_kernel(const float *__restrict__ xyz, uint32_t n, uint32_t *__restrict__ state, int robust,
+__global__ void __launch_bounds__(256) bbox_kernel(const float *__restrict__ xyz, uint32_t n, uint32_t *__restrict__ state, int robust,
                                                   float *__restrict__ out, uint32_t *__restrict__ done) {
     const bool sbox = robust != 0;
-    __shared__ float sm[kBboxThreads / 64][30];
+    __shared__ float sm[4][30];
     // v[0..6): the exact box (min xyz | max xyz); v[6 + 6 s ..): sample box s (points with index = s mod 4 whose hash is drawn)
     float v[30];
 #pragma unroll
@@ -137,7 +134,7 @@ __global__ void __launch_bounds__(kBboxThreads) bbox_kernel(const float *__restr
     if (threadIdx.x < (sbox ? 30 : 6)) {
         const bool is_min = threadIdx.x % 6 < 3;
         float r = sm[0][threadIdx.x];
-        for (int w = 1; w < kBboxThreads / 64; ++w) r = is_min ? fminf(r, sm[w][threadIdx.x]) : fmaxf(r, sm[w][threadIdx.x]);
+        for (int w = 1; w < 4; ++w) r = is_min ? fminf(r, sm[w][threadIdx.x]) : fmaxf(r, sm[w][threadIdx.x]);
         if (is_min) atomicMin(&acc[threadIdx.x * kBboxAccStride], f2ord(r)); else atomicMax(&acc[threadIdx.x * kBboxAccStride], f2ord(r));
     }
     __shared__ uint32_t s_last;
@@ -500,7 +497,7 @@ tc_status exclusive_scan_u32(tc_context *ctx, const uint32_t *d_in, uint32_t n, 
 static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, float mn[3], float mx[3], float *rmn, float *rmx,
                                  bool *clamped) {
     hipStream_t st = ctx->stream;
-    const int nb = (int)((n + kBboxThreads - 1) / kBboxThreads);
+    const int nb = (int)((n + 255) / 256);
     const int bb = std::min(nb, kBboxBlocks);
     const bool robust = rmn != nullptr && n >= 4096;
     // The blocks fold into device accumulators, the last one stores the 30 floats (exact box + four sample boxes) into the pinned
@@ -524,9 +521,9 @@ static tc_status cloud_bbox_impl(tc_context *ctx, const float *d_xyz, size_t n, 
     {
         ProfScope ps(ctx, "bbox");
         if (((uintptr_t)d_xyz & 15u) == 0u)
-            hipLaunchKernelGGL(bbox_kernel<true>, dim3(std::min((int)((n / 4 + kBboxThreads - 1) / kBboxThreads) + 1, kBboxBlocks)), dim3(kBboxThreads), 0, st, d_xyz, (uint32_t)n, d_state, robust ? 1 : 0, d_out, d_done);
+            hipLaunchKernelGGL(bbox_kernel<true>, dim3(std::min((int)((n / 4 + 255) / 256) + 1, kBboxBlocks)), dim3(256), 0, st, d_xyz, (uint32_t)n, d_state, robust ? 1 : 0, d_out, d_done);
         else
-            hipLaunchKernelGGL(bbox_kernel<false>, dim3(bb), dim3(kBboxThreads), 0, st, d_xyz, (uint32_t)n, d_state, robust ? 1 : 0, d_out, d_done);
+            hipLaunchKernelGGL(bbox_kernel<false>, dim3(bb), dim3(256), 0, st, d_xyz, (uint32_t)n, d_state, robust ? 1 : 0, d_out, d_done);
     }
     TC_HIP_TRY(ctx, hipGetLastError());
     if (poll) {
