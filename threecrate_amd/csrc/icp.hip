@@ -315,73 +315,84 @@ __device__ __forceinline__ void nn_search_pruned(const GridView &gv, float x, fl
         mask &= mask - 1u;
     }
     float second = INFINITY;          // (track2) the second smallest distance seen, a record met twice counting twice (the safe side)
-    // (the step as a generic lambda instantiated twice: with the second minimum as a wave-uniform `if` INSIDE one loop, the plain
-    // loop -- a single basic block, and measurably sensitive to that -- would be cut in two by a branch per step)
-    auto step = [&](auto with_second) {
-        const int kn = mask ? __ffs(mask) - 1 : 0;
-        const uint2 nse = spans[kn][threadIdx.x];
-        // The candidates come from the PACKED copy of the sorted records (12 bytes each, DeviceIndex::pts12): four records = 48
-        // bytes = THREE 16-byte reads (dword aligned) instead of four 12-byte reads of the 16-byte records.  The pass is bound by L1
-        // look-ups -- one per lane and read instruction, whatever its width: round 5, profiles/r05_ab_pack12.txt: 42.9 -> 40.5 us
-        // per moving-phase pass, the cold first pass 57 -> 51 us, whole job +2.9 %.  Same bits (same coordinates, same order).
-        // 12 j by two full-rate instructions (v_mul_lo_u32 is quarter rate, and the compiler re-forms it from shifts); j < 2^28
-        uint32_t o;
-        asm("v_lshlrev_b32 %0, 2, %1\n\tv_lshl_add_u32 %0, %1, 3, %0" : "=&v"(o) : "v"(j));
-        auto add = [](float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-        // four records = three 16-byte registers -> the smallest of their four distances and its position (lowest on ties)
-        float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;          // (the step's four distances, for the second smallest of track2)
-        auto quad = [&](const f32x4 &ra, const f32x4 &rb, const f32x4 &rc, uint32_t jb, float &m, uint32_t &im) {
-            const f32x2 d0 = ra.xy - qxy, d1 = ra.zw - qzx, d2 = rb.xy - qyz, d3 = rb.zw - qxy, d4 = rc.xy - qzx, d5 = rc.zw - qyz;
-            const f32x2 s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3, s4 = d4 * d4, s5 = d5 * d5;
-            const float v0 = add(add(s0.x, s0.y), s1.x), v1 = add(add(s1.y, s2.x), s2.y);
-            const float v2 = add(add(s3.x, s3.y), s4.x), v3 = add(add(s4.y, s5.x), s5.y);
-            const bool b01 = v1 < v0, b23 = v3 < v2;
-            const float m01 = b01 ? v1 : v0, m23 = b23 ? v3 : v2;
-            const uint32_t i01 = b01 ? jb + 1 : jb, i23 = b23 ? jb + 3 : jb + 2;
-            const bool bb = m23 < m01;
-            m = bb ? m23 : m01;
-            im = bb ? i23 : i01;
-            w0 = v0; w1 = v1; w2 = v2; w3 = v3;
-        };
-        const f32x4 ra = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o, 0, 0));
-        const f32x4 rb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 16u, 0, 0));
-        const f32x4 rc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 32u, 0, 0));
+    // The candidate step, ONE text for both loops (a macro, not a lambda: wrapped in a generic lambda the plain loop came out one
+    // instruction longer -- v_cmp_ne + select where the inline text gets v_add_co's carry for `mask != 0` -- and the benchmark's main pass
+    // 1 % slower, profiles/r06_dense_trips_certificate.txt).  The comments of the step:
+    //   * The candidates come from the PACKED copy of the sorted records (12 bytes each, DeviceIndex::pts12): four records = 48 bytes =
+    //     THREE 16-byte reads (dword aligned) instead of four 12-byte reads of the 16-byte records (round 5, profiles/r05_ab_pack12.txt:
+    //     42.9 -> 40.5 us per moving-phase pass, the cold first pass 57 -> 51 us, whole job +2.9 %).  Same bits.
+    //   * 12 j by two instructions (v_mul_lo_u32 is quarter rate, and the compiler re-forms it from shifts); j < 2^28.
+    //   * four records = three 16-byte registers -> the smallest of their four distances and its position (lowest on ties).
+    //   * SECOND (the certificate's loop only): the step's own second smallest (of v0 .. v3 the loser of the final, or the smaller loser of
+    //     the semi-finals), then the two smallest of {best, second, m, that}: ~8 instructions, as v_min / v_max instructions (no
+    //     canonicalising v_max x, x).
 #if TC_ICP_STEP == 8
-        const f32x4 rd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 48u, 0, 0));
-        const f32x4 re = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 64u, 0, 0));
+#define TC_ICP_STEP8_LOADS \
+        const f32x4 rd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 48u, 0, 0)); \
+        const f32x4 re = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 64u, 0, 0)); \
         const f32x4 rf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 80u, 0, 0));
+#define TC_ICP_STEP8_QUAD { float m2; uint32_t im2; quad(rd, re, rf, j + 4, m2, im2); const bool b2 = m2 < m; m = b2 ? m2 : m; im = b2 ? im2 : im; }
+#else
+#define TC_ICP_STEP8_LOADS
+#define TC_ICP_STEP8_QUAD
 #endif
-        float m; uint32_t im;
-        quad(ra, rb, rc, j, m, im);
-#if TC_ICP_STEP == 8
-        { float m2; uint32_t im2; quad(rd, re, rf, j + 4, m2, im2); const bool b2 = m2 < m; m = b2 ? m2 : m; im = b2 ? im2 : im; }
-#endif
-        if constexpr (decltype(with_second)::value) {
-            // the step's own second smallest (of v0 .. v3 the loser of the final, or the smaller loser of the semi-finals), then the two
-            // smallest of {best, second, m, that}: ~8 instructions, only in the instantiation the certificate's passes run
-            auto mn = [](float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };      // (as instructions:
-            auto mx = [](float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };      //  no canonicalising v_max x, x)
-            const float m2 = mn(mx(mn(w0, w1), mn(w2, w3)), mn(mx(w0, w1), mx(w2, w3)));
+#define TC_ICP_SECOND_NONE
+#define TC_ICP_SECOND_TRACK \
+            auto mn = [](float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }; \
+            auto mx = [](float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }; \
+            const float m2 = mn(mx(mn(w0, w1), mn(w2, w3)), mn(mx(w0, w1), mx(w2, w3))); \
             second = mn(mx(best, m), mn(second, m2));
-        }
-        const bool upd = m < best;
-        best = upd ? m : best;
-        bestj = upd ? im : bestj;
-        j += TC_ICP_STEP;
-        if constexpr (STATS) ++nsteps;              // (candidate steps of this lane: only in the counting instantiation of the kernel)
-        const bool adv = j >= e && mask != 0u;
-        j = adv ? nse.x : j;
-        e = adv ? nse.y : e;
-        mask = adv ? (mask & (mask - 1u)) : mask;
-    };
-    // (T2: only the certificate's instantiation of the main pass holds the second loop at all -- compiled into the plain kernel, the
-    // inactive branch and its registers cost the benchmark pair 1.5 % of the whole job: profiles/r06_dense_trips_certificate.txt)
-    if constexpr (T2) {
-        if (track2) { while (j < e) step(std::true_type{}); }
-        else { while (j < e) step(std::false_type{}); }
-    } else {
-        while (j < e) step(std::false_type{});
+#define TC_ICP_CANDIDATE_STEP(SECOND) { \
+        const int kn = mask ? __ffs(mask) - 1 : 0; \
+        const uint2 nse = spans[kn][threadIdx.x]; \
+        uint32_t o; \
+        asm("v_lshlrev_b32 %0, 2, %1\n\tv_lshl_add_u32 %0, %1, 3, %0" : "=&v"(o) : "v"(j)); \
+        auto add = [](float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }; \
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f; \
+        auto quad = [&](const f32x4 &ra, const f32x4 &rb, const f32x4 &rc, uint32_t jb, float &m, uint32_t &im) { \
+            const f32x2 d0 = ra.xy - qxy, d1 = ra.zw - qzx, d2 = rb.xy - qyz, d3 = rb.zw - qxy, d4 = rc.xy - qzx, d5 = rc.zw - qyz; \
+            const f32x2 s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3, s4 = d4 * d4, s5 = d5 * d5; \
+            const float v0 = add(add(s0.x, s0.y), s1.x), v1 = add(add(s1.y, s2.x), s2.y); \
+            const float v2 = add(add(s3.x, s3.y), s4.x), v3 = add(add(s4.y, s5.x), s5.y); \
+            const bool b01 = v1 < v0, b23 = v3 < v2; \
+            const float m01 = b01 ? v1 : v0, m23 = b23 ? v3 : v2; \
+            const uint32_t i01 = b01 ? jb + 1 : jb, i23 = b23 ? jb + 3 : jb + 2; \
+            const bool bb = m23 < m01; \
+            m = bb ? m23 : m01; \
+            im = bb ? i23 : i01; \
+            w0 = v0; w1 = v1; w2 = v2; w3 = v3; \
+        }; \
+        const f32x4 ra = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o, 0, 0)); \
+        const f32x4 rb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 16u, 0, 0)); \
+        const f32x4 rc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pt_rsrc, o + 32u, 0, 0)); \
+        TC_ICP_STEP8_LOADS \
+        float m; uint32_t im; \
+        quad(ra, rb, rc, j, m, im); \
+        TC_ICP_STEP8_QUAD \
+        SECOND \
+        const bool upd = m < best; \
+        best = upd ? m : best; \
+        bestj = upd ? im : bestj; \
+        j += TC_ICP_STEP; \
+        if constexpr (STATS) ++nsteps; \
+        const bool adv = j >= e && mask != 0u; \
+        j = adv ? nse.x : j; \
+        e = adv ? nse.y : e; \
+        mask = adv ? (mask & (mask - 1u)) : mask; \
     }
+    if constexpr (T2) {
+        // (T2: only the certificate's instantiation of the main pass holds the second loop at all -- compiled into the plain kernel, the
+        // inactive branch and its registers cost the benchmark pair 1.5 % of the whole job)
+        if (track2) { while (j < e) TC_ICP_CANDIDATE_STEP(TC_ICP_SECOND_TRACK) }
+        else { while (j < e) TC_ICP_CANDIDATE_STEP(TC_ICP_SECOND_NONE) }
+    } else {
+        while (j < e) TC_ICP_CANDIDATE_STEP(TC_ICP_SECOND_NONE)
+    }
+#undef TC_ICP_CANDIDATE_STEP
+#undef TC_ICP_SECOND_TRACK
+#undef TC_ICP_SECOND_NONE
+#undef TC_ICP_STEP8_LOADS
+#undef TC_ICP_STEP8_QUAD
     TC_STAMP(2);
     // Ring-1 exactness rule: best <= ((1 + m_f - 2e-3) h)^2 + |q - q'|^2, m_f >= 0 the clearance of q' to the block's faces.  Nearly
     // every lane passes it with m_f = 0 already (the nearest neighbour lies within one cell edge): only the others form the
@@ -799,7 +810,9 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             // the certificate could never fire.  The superset it scans holds the same nearest neighbour.
             if (track) { ub2 = ub2p * 6.25f; if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f); }
             const unsigned long long smask = CERT ? smv[u] : __ballot(in && !keep);
+#ifndef TC_NO_WSEARCH
             wsearch += (uint32_t)__popcll(smask);
+#endif
             float low2 = 0.0f;
             if (CERT && dense) {
                 if (in && !keep) {          // the dense trips' result of this lane's query
@@ -1474,35 +1487,44 @@ __device__ __forceinline__ void quat_mul_f(const float a[4], const float b[4], f
 
 // current = delta * current  (Isometry3 product, registration.rs:321 / :576); the current transform comes from the header the
 // kernel loaded at its start -- reading it again through `st` would be one more round trip to memory on the lane everything waits for
-__device__ void compose(const IcpHeader &hd, IcpState *st, const float dq[4], const float dt[3], const GridGeom &g, double searchers, double pairs, bool cert_active) {
+__device__ void compose(const IcpHeader &hd, IcpState *st, const float dq[4], const float dt[3], const GridGeom &g, double searchers, double pairs, int cert_active) {
     // How far this update moves a point x: |R_d x + t_d - x| <= 2 |sin(theta / 2)| |x| + |t_d|, and 2 |sin(theta / 2)| = 2 |(i, j, k)| of
     // the unit delta quaternion.  Left in the state for the next main pass's second-neighbour certificate (icp_correspond_reduce_kernel),
-    // which is switched on once the update is small against the cell edge for a point at the far corner of the target's box -- while
-    // the clouds still move by cells nothing would be certified and the bookkeeping would only cost.
-    {
-        const float ang = 2.0f * sqrtf(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]) * 1.0001f;
-        const float tn = sqrtf(dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2]) * 1.0001f;
-        const float rx_ = fmaxf(fabsf(g.minx), fabsf(g.maxx)), ry_ = fmaxf(fabsf(g.miny), fabsf(g.maxy)), rz_ = fmaxf(fabsf(g.minz), fabsf(g.maxz));
-        const float far = sqrtf(rx_ * rx_ + ry_ * ry_ + rz_ * rz_);
-        // (a hundredth of a cell edge: the uniform benchmark pair gets there after ~40 of its 50 iterations -- and hovers around a tenth
-        // of an edge from iteration 15 to 35, on and off: tools/dev/delta_probe.py --, the TUM-shaped pair after ~12)
-        const bool small = ang < 5e-3f && ang * far + tn < 0.01f * g.h;
-        // ... and switched on only where it has something to win (round 6): the pass that has just run still sent more than a tenth
-        // of its points to a search although the update is small -- sensor noise of the order of the point spacing, which the
-        // inscribed-ball test cannot get past (TUM-shaped pair: 85 %).  A clean pair (the uniform benchmark pair once aligned: 0 %) never
-        // pays the bookkeeping (one 16-byte read per point and pass, ~2 us per pass at 1 M points).  Once on it stays on while the
-        // updates stay small: its own success (0.75 % searchers) must not switch it off.
-        // Switching ON also asks for an update three times smaller than staying on does: the uniform benchmark pair hovers around the
-        // threshold for twenty iterations while 69 % of its points still search because the clouds still MOVE -- there the wider
-        // measuring scans and the bookkeeping cost 2 % of the whole job and certify nothing (measured: 17 440 vs 17 770 it/s).
-        // (d_ang >= 0 = the certificate is WANTED: the finalize launch tells the host -- run_chunked --, which enqueues the certificate's
-        // instantiation of the main pass from the chunk after next on; d_run counts the consecutive passes that instantiation has run
-        // with small updates: it maintains the bounds from 1 on and uses them from 2 on, and a pass of the plain kernel resets it)
-        const bool worth = hd.d_ang >= 0.0f || (searchers > 0.1 * pairs && ang * far + tn < 0.003f * g.h);
+    // which is WANTED once the update is small against the cell edge for a point at the far corner of the target's box -- while
+    // the clouds still move by cells nothing would be certified and the bookkeeping would only cost -- AND has something to win: the
+    // pass that has just run still sent more than a tenth of its points to a search although the update is small -- sensor noise of the
+    // order of the point spacing, which the inscribed-ball test cannot get past (TUM-shaped pair: 85 %).  A clean pair (the uniform
+    // benchmark pair once aligned: 0 %) never pays the bookkeeping (one 16-byte read per point and pass, ~2 us per pass at 1 M points).
+    // Switching ON also asks for an update three times smaller than staying on does: the uniform benchmark pair hovers around the
+    // threshold for twenty iterations while 69 % of its points still search because the clouds still MOVE -- there the wider measuring
+    // scans and the bookkeeping cost 2 % of the whole job and certify nothing (measured: 17 440 vs 17 770 it/s).  Once on it stays on
+    // while the updates stay small: its own success (0.75 % searchers) must not switch it off.
+    // (d_ang >= 0 = WANTED: the finalize launch tells the host -- run_chunked --, which enqueues the certificate's instantiation of the
+    // main pass from the chunk after next on; d_run counts the consecutive passes that instantiation has run with small updates: it
+    // maintains the bounds from 1 on and uses them from 2 on, and a pass of the plain kernel resets it.)
+    // This is one lane's dependent chain at the end of every iteration: the gate is decided before anything is computed, and the
+    // lengths come from v_sqrt_f32 (their thresholds carry margins of 1e-4; three correctly rounded square roots were 0.4 us per iteration).
+    // Evaluated where somebody reads the answer: by the finalize launch that ends a chunk (bit 1 of cert_active: the host reads the word it
+    // leaves) and after every pass of the certificate's instantiation (bit 0); the other iterations keep the state as it is.
+    if (cert_active != 0) {
         st->searchers = (uint32_t)fmin(searchers, 4.0e9);
-        st->d_ang = (small && worth) ? ang : -1.0f;
+        const bool was_on = hd.d_ang >= 0.0f;
+        bool wanted = false;
+        float ang = -1.0f, tn = 0.0f;
+        if (was_on || searchers > 0.1 * pairs) {
+            ang = 2.0f * __builtin_amdgcn_sqrtf(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]) * 1.0001f;
+            tn = __builtin_amdgcn_sqrtf(dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2]) * 1.0001f;
+            const float rx_ = fmaxf(fabsf(g.minx), fabsf(g.maxx)), ry_ = fmaxf(fabsf(g.miny), fabsf(g.maxy)), rz_ = fmaxf(fabsf(g.minz), fabsf(g.maxz));
+            const float far = __builtin_amdgcn_sqrtf(rx_ * rx_ + ry_ * ry_ + rz_ * rz_) * 1.0001f;
+            // (a hundredth of a cell edge to stay on, three thousandths to switch on: the uniform benchmark pair gets below the first after
+            // ~40 of its 50 iterations -- and hovers around a tenth of an edge from iteration 15 to 35: tools/dev/delta_probe.py --, the
+            // TUM-shaped pair after ~12)
+            const float moved = ang * far + tn;
+            wanted = ang < 5e-3f && moved < (was_on ? 0.01f : 0.003f) * g.h;
+        }
+        st->d_ang = wanted ? ang : -1.0f;
         st->d_t = tn;
-        st->d_run = (small && worth && cert_active) ? min(hd.d_run + 1u, 1000000u) : 0u;          // a pass that did not maintain the bounds invalidates them
+        st->d_run = (wanted && (cert_active & 1)) ? min(hd.d_run + 1u, 1000000u) : 0u;          // a pass that did not maintain the bounds invalidates them
     }
     const float cq[4] = {hd.q[0], hd.q[1], hd.q[2], hd.q[3]};
     const float ct[3] = {hd.t[0], hd.t[1], hd.t[2]};
@@ -1610,7 +1632,7 @@ constexpr int kFinalizeThreads = 512;
 // the calling block (kFinalizeThreads threads): fixed-order sum of the rows, solve, compose, bookkeeping
 template <int MODE>
 __device__ void finalize_body(const double *__restrict__ partials, uint32_t nblocks, IcpState *__restrict__ st, const GridGeom &g,
-                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE], const IcpHeader &hd, bool cert_active = false) {
+                              int do_sum, int do_apply, double (*sm)[TC_ICP_SUMS_STRIDE], const IcpHeader &hd, int cert_active = 0) {
     const bool done = hd.done != 0;
     constexpr bool P2PLANE = MODE != 0;        // GICP solves the same 6x6 system from the same 29 words (gicp.rs:258-281)
     if (do_sum) {
@@ -1733,11 +1755,11 @@ __global__ void __launch_bounds__(kFinalizeThreads) icp_finalize_kernel(const do
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     finalize_body<MODE>(partials, nblocks, st, g, do_sum, 0, sm, hd);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    finalize_body<MODE>(partials, nblocks, st, g, 0, do_apply, sm, hd, cert_active != 0);
+    finalize_body<MODE>(partials, nblocks, st, g, 0, do_apply, sm, hd, cert_active | (done_out != nullptr ? 2 : 0));
     const unsigned long long t2 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) { st->refine_ring_hist[0] += (uint32_t)(t1 - t0); st->refine_ring_hist[1] += (uint32_t)(t2 - t1); }
 #else
-    finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm, hd, cert_active != 0);
+    finalize_body<MODE>(partials, nblocks, st, g, do_sum, do_apply, sm, hd, cert_active | (done_out != nullptr ? 2 : 0));
 #endif
     if (done_out && threadIdx.x == 0)      // (thread 0 wrote st->done itself)
         // (3 = the chunk has run, the registration goes on AND wants the second-neighbour certificate: compose(), run_chunked)
