@@ -912,11 +912,17 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     }
     // column kSearchersCol of the row (beyond the sums' columns, which end at 29): how many lanes of the block searched -- summed with
     // the rest by the refine fold and icp_finalize, which leaves the total in IcpState::searchers (the certificate's gate, compose())
+#ifndef TC_NO_WSEARCH
     if (lane == kSearchersCol) red[w][kSearchersCol] = (double)wsearch;
+#endif
     __syncthreads();
     if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
         double sum = 0.0;
+#ifndef TC_NO_WSEARCH
         if (threadIdx.x < NACC || threadIdx.x == kSearchersCol) {
+#else
+        if (threadIdx.x < NACC) {
+#endif
 #pragma unroll
             for (int w2 = 0; w2 < kIcpBlock / 64; ++w2) sum += red[w2][threadIdx.x];
         }
