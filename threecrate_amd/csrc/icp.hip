@@ -2097,7 +2097,14 @@ static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate
     TC_HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d_flags, (void *)flags, 0));
     const size_t max_flags = 200;                                  // pinned bytes 1024 .. 2048 hold them (the bbox partials follow)
     size_t it = 0;
-    ctx->icp_cert = false;
+    // (a registration starts with the instantiation the context's previous one ended with: scans of one sensor follow each other, and
+    // the certificate's instantiation decides on the device, pass by pass, whether it tracks anything -- started from the first chunk it
+    // certifies from iteration ~12 of a TUM-shaped pair instead of 17; the results are the same bits either way)
+    // (the hint holds for the whole call: the certificate's instantiation costs a clean pair ~1.5 % of its passes, and the next call's
+    // hint is what THIS call's finalize launches last reported)
+    const bool sticky = ctx->icp_cert_hint && nchunks >= 3;          // (a call of one or two chunks never reads a word: no hint in, none out)
+    ctx->icp_cert = sticky;
+    struct Hint { tc_context *c; bool wanted; ~Hint() { c->icp_cert_hint = wanted; } } hint{ctx, sticky};
     for (size_t c = 0; c < nchunks; ++c) {
         if (c >= 2 && c - 2 < max_flags) {
             // wait for chunk c - 2 (chunk c - 1 keeps the device busy meanwhile); spins, then yields the core (wait_pinned_word)
@@ -2105,7 +2112,8 @@ static tc_status run_chunked(tc_context *ctx, size_t max_iters, IcpState *dstate
             if (flags[c - 2] == 1) break;
             // (3: the registration wants the second-neighbour certificate -- small updates and still searching, compose() -- : the chunks
             // enqueued from here on run its instantiation of the main pass; a function of the state after chunk c - 2, not of timing)
-            ctx->icp_cert = flags[c - 2] == 3;
+            hint.wanted = flags[c - 2] == 3;
+            ctx->icp_cert = sticky || hint.wanted;
         }
         if (c < max_flags) flags[c] = 0;
         for (size_t k = 0; k < chunk_len(c) && it < max_iters; ++k, ++it) {

@@ -188,6 +188,7 @@ struct tc_context {
     // iterations, wave trips, trips without a search, searches, candidate steps needed, candidate steps taken (slowest lanes)
     unsigned long long stat_icp[6] = {0, 0, 0, 0, 0, 0};
     bool icp_cert = false;          // run_chunked: the chunks being enqueued run the certificate's instantiation of the main pass
+    bool icp_cert_hint = false;     // ... and what the context's previous registration ended with (the next one starts with it)
     bool normals_hard_clean = false; // its header (count, exit ticket) is known to be zero: the last serving launch went through
     tc::DeviceIndex vox_index;      // voxel filter counting-sort buffers
     void *pinned = nullptr;         // small pinned host scratch (IcpState readback, bbox)
