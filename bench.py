@@ -581,7 +581,7 @@ def main():
         src_h, tgt_h, _ = synth.registration_pair(n, seed=1 + rank, transform=T_true, noise_sigma=NOISE_REL)
     src, tgt = torch.from_numpy(src_h).to(dev), torch.from_numpy(tgt_h).to(dev)
     ctx = tc.GpuContext(local_rank)
-    # sampled hipEvents around the dominant kernel only (every 17th launch: an event is a ~6 us bubble on the stream): ~1 % overhead in the timed region
+    # sampled hipEvents around the dominant kernel only (every 37th launch: an event is a ~6 us bubble on either side of the kernel on the stream: 27 samples and ~0.6 % of the timed region at the default 20 steps; every 17th until round 6)
     ctx.profile_enable(2)
 
     def step():

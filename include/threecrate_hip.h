@@ -530,7 +530,7 @@ void      tc_frame_stream_destroy(tc_frame_stream *s);
 tc_status tc_read_kitti_bin(const char *path, float *out_xyz, size_t capacity_points, size_t *n_points);
 
 /* ---- profiling ---- */
-/* on: 0 = off, 1 = hipEvents around every kernel, 2 = only around every 17th launch of the dominant
+/* on: 0 = off, 1 = hipEvents around every kernel, 2 = only around every 37th launch of the dominant
    kernel (icp_correspond_reduce): ~1 % overhead (an event is a ~6 us bubble on the stream), used inside bench.py's timed region,
    3 = no events; the ICP main pass counts its searches instead (tc_debug_counter, TC_COUNTER_ICP_*) */
 void   tc_profile_enable(tc_context *ctx, int on);

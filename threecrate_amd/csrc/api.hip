@@ -128,10 +128,10 @@ tc_status ensure(tc_context *ctx, DevBuf &b, size_t bytes) {
 
 ProfScope::ProfScope(tc_context *c, const char *name, bool dominant) : ctx(c) {
     if (ctx->profiling != 1 && ctx->profiling != 2) return;          // (3 = search statistics: no events)
-    // (mode 2: every 17th launch of the dominant kernel -- a stride coprime to the usual 50 iterations per call, so that the sampled
+    // (mode 2: every 37th launch of the dominant kernel (17th until round 6: the bubbles were 36 us of a 2.8 ms step) -- a stride coprime to the usual 50 iterations per call, so that the sampled
     // iteration indices walk through all of 0 .. 49 over the calls and the cold first pass is sampled as often as any other.  An event on the stream is a ~5.7 us bubble on either side of the kernel --
     // every 4th launch, as until round 4, was 2.9 us per ICP iteration = 5 % of the timed region, not the 1 % once estimated.)
-    if (ctx->profiling == 2 && (!dominant || (ctx->prof_tick++ % 17u) != 0)) return;
+    if (ctx->profiling == 2 && (!dominant || (ctx->prof_tick++ % 37u) != 0)) return;
     for (size_t i = 0; i < ctx->timers.size(); ++i)
         if (ctx->timers[i].name == name) { idx = (int)i; break; }
     if (idx < 0) { ctx->timers.push_back(KernelTimer{name, {}, 0, 0.0, 1e300, 0.0}); idx = (int)ctx->timers.size() - 1; }
