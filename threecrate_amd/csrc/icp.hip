@@ -2214,6 +2214,8 @@ static tc_status icp_run_mode(tc_context *ctx, int mode, const float *d_src, siz
     }
     fold_search_stats(ctx, hs);
     if (debug_flags() & 64)
+        fprintf(stderr, "[tc] icp: searching lanes at the last evaluation of the certificate's gate %u (d_run %u, wanted %d)\n", hs->searchers, hs->d_run, hs->d_ang >= 0.0f ? 1 : 0);
+    if (debug_flags() & 64)
         fprintf(stderr, "[tc] icp: %u iterations, refine queries total %u max %u  exit ring hist %u %u %u %u %u %u %u %u\n", hs->iterations,
                 hs->refine_total, hs->refine_max, hs->refine_ring_hist[0], hs->refine_ring_hist[1], hs->refine_ring_hist[2], hs->refine_ring_hist[3],
                 hs->refine_ring_hist[4], hs->refine_ring_hist[5], hs->refine_ring_hist[6], hs->refine_ring_hist[7]);
