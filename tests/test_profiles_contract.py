@@ -30,5 +30,7 @@ def test_kernel_names_of_the_three_instantiations_are_told_apart():
     short = ns["short"]
     assert short("void tc::icp_correspond_reduce_kernel<1, false, false>(tc::GridView, ...)") == "icp_correspond_reduce_kernel<1>"
     assert short("void tc::icp_correspond_reduce_kernel<1, false, true>(tc::GridView, ...)") == "icp_correspond_reduce_kernel<1> cert"
+    assert short("void tc::icp_correspond_reduce_kernel<1, false, false, true>(tc::GridView, ...)") == "icp_correspond_reduce_kernel<1>"        # a chunk's last pass (counts)
+    assert short("void tc::icp_correspond_reduce_kernel<1, false, true, false>(tc::GridView, ...)") == "icp_correspond_reduce_kernel<1> cert"
     assert short("void tc::icp_correspond_reduce_kernel<0, true, false>(tc::GridView, ...)") == "icp_correspond_reduce_kernel<0> stats"
     assert short("void tc::normals_tagged_kernel<19, 64, false, -2>(tc::GridView, tc::NormalParams, float*)") == "normals_tagged_kernel"

@@ -574,7 +574,11 @@ __host__ __device__ __forceinline__ uint4 *refine_entries(uint32_t *rlist) {
 // The product's instantiation carries none of it.
 // CERT: the instantiation that maintains and uses the second-neighbour certificate (round 6; chosen by the host per chunk of
 // iterations from the word the finalize launch leaves in the pinned block: run_chunked).  The plain instantiation holds none of it.
-template <int MODE, bool STATS = false, bool CERT = false>
+// COUNT: the instantiation that counts its searching lanes into the rows' spare column (the certificate's gate is evaluated by the finalize
+// launch that ends a chunk of iterations, so only a chunk's LAST main pass has to count; the counter costs the plain pass a scalar
+// register and 0.3 us -- profiles/r06_dense_trips_certificate.txt -- which the other 43 of 50 launches now do not pay: without it the plain
+// kernel is round 5's, instruction for instruction).  The certificate's instantiation always counts.
+template <int MODE, bool STATS = false, bool CERT = false, bool COUNT = false>
 __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) icp_correspond_reduce_kernel(
     GridView tgt, const float4 *__restrict__ tgt_nrm, float4 *wsrc, uint32_t ns, uint32_t chunk,
     const IcpState *__restrict__ st, uint32_t *__restrict__ rlist,
@@ -619,7 +623,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     const uint32_t wave_cap = chunk / kWavesPerBlock;
     uint4 *__restrict__ const wseg = refine_entries(rlist) + 2 * ((size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * wave_cap;
     uint32_t wcnt = 0;                                     // this wave's entries so far (wave-uniform)
-    uint32_t wsearch = 0;                                  // lanes of this wave that had to search (wave-uniform): the rows' spare column
+    [[maybe_unused]] uint32_t wsearch = 0;                 // lanes of this wave that had to search (wave-uniform): the rows' spare column (COUNT / CERT)
     const GridGeom &g = tgt.g;
     const float q[4] = {hd.q[0], hd.q[1], hd.q[2], hd.q[3]};
     const float t[3] = {hd.t[0], hd.t[1], hd.t[2]};
@@ -813,9 +817,7 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
             // the certificate could never fire.  The superset it scans holds the same nearest neighbour.
             if (track) { ub2 = ub2p * 6.25f; if (max_dist >= 0.0f) ub2 = fminf(ub2, max_dist * max_dist * 1.0001f); }
             const unsigned long long smask = CERT ? smv[u] : __ballot(in && !keep);
-#ifndef TC_NO_WSEARCH
-            wsearch += (uint32_t)__popcll(smask);
-#endif
+            if constexpr (COUNT || CERT) wsearch += (uint32_t)__popcll(smask);
             float low2 = 0.0f;
             if (CERT && dense) {
                 if (in && !keep) {          // the dense trips' result of this lane's query
@@ -915,17 +917,11 @@ __global__ void __launch_bounds__(kIcpBlock) __attribute__((amdgpu_waves_per_eu(
     }
     // column kSearchersCol of the row (beyond the sums' columns, which end at 29): how many lanes of the block searched -- summed with
     // the rest by the refine fold and icp_finalize, which leaves the total in IcpState::searchers (the certificate's gate, compose())
-#ifndef TC_NO_WSEARCH
-    if (lane == kSearchersCol) red[w][kSearchersCol] = (double)wsearch;
-#endif
+    if constexpr (COUNT || CERT) { if (lane == kSearchersCol) red[w][kSearchersCol] = (double)wsearch; }
     __syncthreads();
     if (threadIdx.x < TC_ICP_SUMS_STRIDE) {
         double sum = 0.0;
-#ifndef TC_NO_WSEARCH
-        if (threadIdx.x < NACC || threadIdx.x == kSearchersCol) {
-#else
-        if (threadIdx.x < NACC) {
-#endif
+        if (threadIdx.x < NACC || ((COUNT || CERT) && threadIdx.x == kSearchersCol)) {
 #pragma unroll
             for (int w2 = 0; w2 < kIcpBlock / 64; ++w2) sum += red[w2][threadIdx.x];
         }
@@ -1880,6 +1876,9 @@ static void launch_iteration(tc_context *ctx, int mode, const GridView &tv, cons
             // the certificate's instantiation (point-to-point and point-to-plane; the counting instantiation and GICP stay plain)
             cert = cert && wl != nullptr && mode != 2 && !(dbg & 8);
             if (cert) kern = mode == 1 ? icp_correspond_reduce_kernel<1, false, true> : icp_correspond_reduce_kernel<0, false, true>;
+            // a chunk's last main pass counts its searching lanes for the gate its finalize launch evaluates (point-to-point / point-to-plane)
+            else if (done_out != nullptr && wl != nullptr && mode != 2 && !(dbg & 8))
+                kern = mode == 1 ? icp_correspond_reduce_kernel<1, false, false, true> : icp_correspond_reduce_kernel<0, false, false, true>;
             const float4 *vor_arg = (dbg & 4) ? nullptr : vor;
             unsigned long long *times_arg = (dbg & 1024) ? (unsigned long long *)ctx->dbg_times.p : nullptr;
             if (ps.active())          // a timed launch: the events carry the kernel's own start / end stamps (ProfScope)

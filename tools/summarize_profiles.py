@@ -26,7 +26,9 @@ def short(name):
     # template arguments = ICP mode (0 point-to-point, 1 point-to-plane, 2 GICP) and, for the main pass, whether the launch also
     # runs the previous iteration's finalize step in its solver block ("fused": DESIGN 4.3)
     # (round 6: <MODE, STATS, CERT> -- the counting instantiation and the second-neighbour certificate's instantiation get a suffix)
-    m = re.search(r"icp_correspond_reduce_kernel<(\d)(?:, ?(true|false|1|0))?(?:, ?(true|false|1|0))?>", name)
+    # (a chunk's last main pass also counts its searching lanes: <MODE, false, false, true> -- the same kernel plus one scalar counter; it is
+    # folded into the plain row: the bench line's average is over both)
+    m = re.search(r"icp_correspond_reduce_kernel<(\d)(?:, ?(true|false|1|0))?(?:, ?(true|false|1|0))?(?:, ?(true|false|1|0))?>", name)
     if m:
         return f"icp_correspond_reduce_kernel<{m.group(1)}>" + (" stats" if m.group(2) in ("true", "1") else "") + (" cert" if m.group(3) in ("true", "1") else "")
     for k in ["icp_correspond_reduce_kernel<1>", "icp_correspond_reduce_kernel<0>", "icp_correspond_reduce_kernel<2>",
