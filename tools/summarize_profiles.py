@@ -46,10 +46,17 @@ def short(name):
 stats = load("stats", "kernel_stats")
 print("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 3 --warmup 1) ==")
 print(f"{'kernel':46s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'%':>6s}")
+# (instantiations that share a short name -- the plain main pass and its counting twin at the end of every chunk -- are ONE row: calls
+# and total time added, the average over both)
+merged = collections.OrderedDict()
 for r in stats:
-    print(f"{short(r['Name']):46s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.2f} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['Percentage']):6.2f}")
-    res.setdefault(short(r["Name"]), {})["avg_us"] = float(r["AverageNs"]) / 1e3
-    res[short(r["Name"])]["calls"] = int(r["Calls"])
+    m = merged.setdefault(short(r["Name"]), {"calls": 0, "total_ns": 0.0, "pct": 0.0})
+    m["calls"] += int(r["Calls"]); m["total_ns"] += float(r["TotalDurationNs"]); m["pct"] += float(r["Percentage"])
+for k, m in sorted(merged.items(), key=lambda kv: -kv[1]["total_ns"]):
+    avg = m["total_ns"] / max(m["calls"], 1) / 1e3
+    print(f"{k:46s} {m['calls']:>6d} {avg:10.2f} {m['total_ns']/1e6:10.3f} {m['pct']:6.2f}")
+    res.setdefault(k, {})["avg_us"] = avg
+    res[k]["calls"] = m["calls"]
 
 for sub, cname in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
     acc = collections.defaultdict(list)
